@@ -1,0 +1,27 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PKG_NAME = "nuclei-feature-extraction_amd"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def nfx():
+    """The product package (host mirror of the reference's FeatureSet interface over the C ABI)."""
+    return importlib.import_module(PKG_NAME)
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return importlib.import_module(PKG_NAME + ".synth")
