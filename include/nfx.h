@@ -1,0 +1,163 @@
+/*
+ * nfx.h -- C ABI of the MI355X-native per-nucleus feature-extraction engine.
+ *
+ * Drop-in boundary for the hot path of oxabz/nuclei-feature-extraction (reference paths below
+ * are file:line in that repository).  Plain pointers and sizes only: no tensor types, no
+ * allocation crosses the ABI, the caller owns every buffer.
+ *
+ * What each entry point replaces
+ *   nfx_feature_set_* / nfx_parse_feature_sets   args.rs:18-73 (names, `texture`/`all` expansion,
+ *                                                 registry order) and the `name()` strings of
+ *                                                 shape.rs:132-134, color.rs:104-106,
+ *                                                 texture.rs:169-171,312-314,371-373; column names
+ *                                                 of shape.rs:113-128, color.rs:80-99,
+ *                                                 texture.rs:81-157,244-301,346-361
+ *   nfx_compute_features_batched                  trait FeatureSet::compute_features_batched,
+ *                                                 features/mod.rs:12-28 (one set, one batch, f32
+ *                                                 patchs [N,3,ps,ps] + f32 masks [N,1,ps,ps])
+ *   nfx_preprocess_polygons                       preprocess_polygon, utils.rs:54-74
+ *   nfx_rasterize_polygons                        tch_utils::shapes::polygon call sites,
+ *                                                 utils.rs:90-95,152-157
+ *   nfx_extract                                   the body of the rayon pipeline main.rs:146-151 on
+ *                                                 packed u8 patches: preprocess + rasterise +
+ *                                                 u8/255 (utils.rs:172) + every selected set in
+ *                                                 CLI order + column concat (main.rs:76-89)
+ *   nfx_extract_tile                              same, patches gathered from a resident [3,H,W]
+ *                                                 u8 image by load_image_dataset's addressing rules
+ *                                                 (utils.rs:141-206)
+ *   nfx_centroid_key                              centroid_to_key_string, utils.rs:226-228
+ *
+ * Errors: every function that can fail returns an nfx_status; nfx_last_error(ctx) gives the
+ * text.  Degenerate nuclei do not fail: they yield NaN exactly where the reference's arithmetic
+ * does (empty mask -> 0/0, shape.rs:142-184).
+ *
+ * Threading: one context per device (or per host thread); calls on distinct contexts are
+ * concurrent and re-entrant (the reference invokes its feature sets from every rayon worker,
+ * main.rs:146-151).  A context is not internally locked.
+ *
+ * Memory spaces: with NFX_MEM_HOST all data pointers are host memory and the call is
+ * synchronous.  With NFX_MEM_DEVICE all data pointers are device memory of the context's GPU,
+ * the work is enqueued on the context's stream (nfx_ctx_set_stream) and the call returns
+ * without synchronising (stream-ordered: safe to chain, overlap H2D on another stream).
+ */
+#ifndef NFX_H
+#define NFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFX_VERSION 100 /* 0.1.0 */
+
+typedef struct nfx_ctx nfx_ctx;
+
+typedef enum {
+    NFX_OK = 0,
+    NFX_ERR_INVALID_ARGUMENT = 1,
+    NFX_ERR_UNSUPPORTED = 2,   /* e.g. patch size > 64 */
+    NFX_ERR_DEVICE = 3,        /* HIP runtime error, text in nfx_last_error */
+    NFX_ERR_OUT_OF_MEMORY = 4
+} nfx_status;
+
+/* registry order == args.rs `all` expansion order (args.rs:38-44) */
+typedef enum {
+    NFX_SET_GEOMETRY = 0, /* ShapeFeatureSet        12 columns */
+    NFX_SET_COLOR = 1,    /* ColorFeatureSet        18 columns */
+    NFX_SET_GLCM = 2,     /* GlcmFeatureSet        224 columns */
+    NFX_SET_GLRLM = 3,    /* GLRLMFeatureSet        68 columns */
+    NFX_SET_GABOR = 4,    /* GaborFilterFeatureSet  96 columns */
+    NFX_SET_COUNT = 5
+} nfx_feature_set;
+
+typedef enum { NFX_MEM_HOST = 0, NFX_MEM_DEVICE = 1 } nfx_mem;
+
+#define NFX_MAX_PATCH_SIZE 64 /* one mask row == one 64-bit word == one lane's register pair */
+
+/* ---- registry (no context, no GPU needed) ------------------------------------------------ */
+int nfx_version(void);
+int nfx_feature_set_count(void);
+/* FeatureSet::name(): "geometry","color","GLCM","GLRLM","gabor filter"; NULL if out of range */
+const char *nfx_feature_set_name(int set);
+/* CLI spelling accepted by args.rs:21-34: geometry color glcm glrlm gabor */
+const char *nfx_feature_set_cli_name(int set);
+int nfx_feature_set_num_columns(int set); /* -1 if out of range */
+/* writes the NUL-terminated name of column j (excluding the leading "centroid" key column);
+   returns its length, or -1 on bad index / short buffer */
+int nfx_feature_set_column_name(int set, int j, char *buf, size_t buflen);
+/* args.rs FeatureSet::from_str + flat(): case-insensitive; "texture" -> glcm,glrlm,gabor;
+   "all" -> geometry,color,glcm,glrlm,gabor; no de-duplication.  Returns the number of sets
+   written to out_sets (<= cap), -1 if a name is not a feature set, -2 if cap is too small. */
+int nfx_parse_feature_sets(const char *const *names, int n_names, int *out_sets, int cap);
+/* "{x},{y}" with Rust's f32 Display (shortest round-trip, positional).  Returns length or -1. */
+int nfx_centroid_key(float x, float y, char *buf, size_t buflen);
+
+/* ---- context ----------------------------------------------------------------------------- */
+nfx_status nfx_ctx_create(int device, nfx_ctx **out);
+void nfx_ctx_destroy(nfx_ctx *ctx);
+const char *nfx_last_error(const nfx_ctx *ctx);
+/* hipStream_t the NFX_MEM_DEVICE calls are enqueued on (NULL = the default stream) */
+nfx_status nfx_ctx_set_stream(nfx_ctx *ctx, void *hip_stream);
+/* blocks until everything enqueued by this context has finished */
+nfx_status nfx_ctx_synchronize(nfx_ctx *ctx);
+
+/* Per-kernel device timing with HIP events on the context's stream (off by default).
+   nfx_ctx_kernel_timing synchronises, then reports for kernel slot k: name, number of launches
+   and total milliseconds since the last reset.  Returns the number of slots. */
+nfx_status nfx_ctx_enable_timing(nfx_ctx *ctx, int on);
+int nfx_ctx_kernel_timing(nfx_ctx *ctx, int k, const char **name, int64_t *launches, double *total_ms);
+nfx_status nfx_ctx_reset_timing(nfx_ctx *ctx);
+
+/* ---- R1: utils.rs:54-74 -------------------------------------------------------------------
+   ring_offsets [n+1] (vertex index of each nucleus' outer ring, ring_offsets[0] == 0),
+   ring_xy [n_vertices][2] slide-pixel coordinates, closing duplicate included as listed;
+   n_vertices == ring_offsets[n] (passed by value so device-resident calls need no read-back).
+   Outputs: centroids_xy [n][2], centred_xy same shape as ring_xy. */
+nfx_status nfx_preprocess_polygons(nfx_ctx *ctx, int64_t n, int64_t n_vertices, const uint32_t *ring_offsets,
+                                   const float *ring_xy, float *centroids_xy, float *centred_xy, nfx_mem mem);
+
+/* ---- R2: tch_utils::shapes::polygon call sites utils.rs:90-95,152-157 ---------------------
+   centred polygons in, masks out.  Either output may be NULL:
+     masks_f32  [n][1][ps][ps] f32 in {0,1}  (the reference's tensor)
+     mask_rows  [n][ps] u64, bit c of word r == pixel (r,c)  (the engine's native form) */
+nfx_status nfx_rasterize_polygons(nfx_ctx *ctx, int64_t n, int64_t n_vertices, const uint32_t *poly_offsets,
+                                  const float *poly_xy, int ps, float *masks_f32, uint64_t *mask_rows, nfx_mem mem);
+
+/* ---- trait FeatureSet::compute_features_batched, features/mod.rs:21-27 --------------------
+   ONE feature set on ONE reference batch (hue statistics couple the nuclei of a batch,
+   color.rs:50-51,144-155, so the caller's batch partition is part of the result).
+     centroids_xy [n][2]           unused by the arithmetic (key column only); may be NULL
+     poly_offsets [n+1], poly_xy   centred polygons (utils.rs:66-73)
+     patchs [n][3][ps][ps] f32 in [0,1], masks [n][1][ps][ps] f32 in {0,1}
+     out [n][nfx_feature_set_num_columns(set)] row-major f32 */
+nfx_status nfx_compute_features_batched(nfx_ctx *ctx, int set, int64_t n, int64_t n_vertices,
+                                        const float *centroids_xy, const uint32_t *poly_offsets, const float *poly_xy,
+                                        const float *patchs, const float *masks, int ps, float *out, nfx_mem mem);
+
+/* ---- pipeline body main.rs:146-151 on packed patches --------------------------------------
+     sets[n_sets]                  feature sets in output order (as nfx_parse_feature_sets gives)
+     ring_offsets/ring_xy          raw outer rings (as nfx_preprocess_polygons)
+     patches_u8 [n][3][ps][ps]     planar RGB u8; the engine applies u8/255 (utils.rs:172)
+     batch_size                    the reference's par_chunks size (args.rs:107-108, default 100)
+     out_rows [n][F]               F = sum of the sets' column counts; rows in input order
+     out_centroids_xy [n][2]       for the key column; may be NULL */
+nfx_status nfx_extract(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t n_vertices,
+                       const uint32_t *ring_offsets, const float *ring_xy, const uint8_t *patches_u8, int ps,
+                       int batch_size, float *out_rows, float *out_centroids_xy, nfx_mem mem);
+
+/* same, patches gathered from image_u8 [3][H][W] (planar, tch::vision::image::load layout,
+   main.rs:26) by the rules of load_image_dataset, utils.rs:159-191 */
+nfx_status nfx_extract_tile(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t n_vertices,
+                            const uint32_t *ring_offsets, const float *ring_xy, const uint8_t *image_u8, int64_t H,
+                            int64_t W, int ps, int batch_size, float *out_rows, float *out_centroids_xy, nfx_mem mem);
+
+/* utils.rs:159-191 alone: crops [n][3][ps][ps] u8 out of image_u8 at the given centroids */
+nfx_status nfx_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids_xy, const uint8_t *image_u8, int64_t H,
+                              int64_t W, int ps, uint8_t *patches_u8, nfx_mem mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFX_H */

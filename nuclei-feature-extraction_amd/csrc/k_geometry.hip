@@ -1,0 +1,382 @@
+// k_geometry.hip -- polygon -> mask rasterisation and the "geometry" feature set on gfx950.
+//
+// Replaces (reference file:line):
+//   tch_utils::shapes::polygon call sites           utils.rs:90-95,152-157
+//   ShapeFeatureSet::compute_features_batched       shape.rs:16-130  (center_of_mass 219-226,
+//     major_minor_axes_w_angle 141-203, eccentricity 205-207, ellipse 80-87, eliptic_deviation 209-217,
+//     geometric_features::* 89-97)
+//
+// Layout: ONE WAVEFRONT PER NUCLEUS, ONE LANE PER MASK ROW.  A mask row (ps <= 64 pixels) is a
+// single 64-bit word held in a VGPR pair, so the whole mask of a nucleus lives in the wave's
+// registers: the scanline rasteriser XORs "all pixels left of the crossing" words edge by edge
+// (no cross-lane traffic at all), the image moments are popcounts of the row word against six
+// constant bit patterns, and only six integers per nucleus go through a wave reduction.  The mask
+// never touches LDS or HBM unless another feature set needs it (then 8 B per row are stored once).
+//
+// Compiled with -ffp-contract=off: the mask bits and the ellipse XOR count are integer results
+// that must match the CPU oracle bit for bit, so the f64/f32 expression trees below are
+// evaluated exactly as written.
+#include "nfx_internal.h"
+
+namespace nfx {
+
+static __device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static __device__ __forceinline__ float readlane_f(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// ---- scanline XOR rasteriser: returns this lane's row word ------------------------------------
+// pixel (r,c) sits at (c - ps/2, r - ps/2); edge (x1,y1)->(x2,y2) toggles it iff
+// (y1 > py) != (y2 > py) && px < (x2-x1)*(py-y1)/(y2-y1) + x1   (all f64).
+static __device__ __forceinline__ uint64_t raster_row(const uint32_t *__restrict__ poly_off,
+                                                      const float *__restrict__ poly_xy, int64_t i, int ps, int lane)
+{
+    const uint32_t v0 = poly_off[i];
+    const int V = (int)(poly_off[i + 1] - v0);
+    const double half = (double)ps / 2.0;
+    const double py = (double)lane - half;
+    uint64_t row = 0;
+    for (int base = 0; base < V; base += 64) {
+        const int cnt = (V - base) < 64 ? (V - base) : 64;
+        float fx1 = 0.f, fy1 = 0.f, fx2 = 0.f, fy2 = 0.f;
+        if (lane < cnt) {
+            const int a = base + lane;
+            const int b = (a + 1 == V) ? 0 : a + 1;
+            const float2 p1 = reinterpret_cast<const float2 *>(poly_xy)[v0 + a];
+            const float2 p2 = reinterpret_cast<const float2 *>(poly_xy)[v0 + b];
+            fx1 = p1.x; fy1 = p1.y; fx2 = p2.x; fy2 = p2.y;
+        }
+        for (int e = 0; e < cnt; ++e) {
+            const double x1 = (double)readlane_f(fx1, e), y1 = (double)readlane_f(fy1, e);
+            const double x2 = (double)readlane_f(fx2, e), y2 = (double)readlane_f(fy2, e);
+            if ((y1 > py) != (y2 > py)) {
+                const double xint = (x2 - x1) * (py - y1) / (y2 - y1) + x1;
+                // k = #{c in [0,ps) : (double)c - half < xint}; estimate by ceil, then make it exact
+                const double kf = ceil(xint + half);
+                int k = !(kf > 0.0) ? 0 : (kf >= (double)ps ? ps : (int)kf);
+                if (k > 0 && !((double)(k - 1) - half < xint)) --k;
+                if (k < ps && ((double)k - half < xint)) ++k;
+                row ^= (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+            }
+        }
+    }
+    return lane < ps ? row : 0ull;
+}
+
+// ---- LAPACK slanv2 (f32) as reached by sgeev on a 2x2 block; see DESIGN.md "orientation" -------
+static __device__ __forceinline__ float sign1(float x) { return __builtin_signbit(x) ? -1.0f : 1.0f; }
+
+static __device__ float slapy2(float x, float y)
+{
+    const float xa = fabsf(x), ya = fabsf(y);
+    const float w = xa > ya ? xa : ya;
+    const float z = xa > ya ? ya : xa;
+    if (z == 0.0f) return w;
+    const float t = z / w;
+    return w * sqrtf(1.0f + t * t);
+}
+
+static __device__ void slanv2(float a, float b, float c, float d, float &rt1, float &rt2, float &cs, float &sn)
+{
+    const float eps = 1.1920929e-07f, multpl = 4.0f;
+    if (c == 0.0f) {
+        cs = 1.0f; sn = 0.0f;
+    } else if (b == 0.0f) {
+        cs = 0.0f; sn = 1.0f;
+        const float t = d; d = a; a = t; b = -c; c = 0.0f;
+    } else if ((a - d) == 0.0f && sign1(b) != sign1(c)) {
+        cs = 1.0f; sn = 0.0f;
+    } else {
+        float temp = a - d;
+        const float p = 0.5f * temp;
+        const float bcmax = fmaxf(fabsf(b), fabsf(c));
+        const float bcmis = fminf(fabsf(b), fabsf(c)) * sign1(b) * sign1(c);
+        const float scale = fmaxf(fabsf(p), bcmax);
+        float z = p / scale * p + bcmax / scale * bcmis;
+        if (z >= multpl * eps) {
+            const float sq = sqrtf(scale) * sqrtf(z);
+            z = p + (__builtin_signbit(p) ? -fabsf(sq) : fabsf(sq));
+            a = d + z;
+            d = d - (bcmax / z) * bcmis;
+            const float tau = slapy2(c, z);
+            cs = z / tau;
+            sn = c / tau;
+            b = b - c;
+            c = 0.0f;
+        } else {
+            const float sigma = b + c;
+            float tau = slapy2(sigma, temp);
+            cs = sqrtf(0.5f * (1.0f + fabsf(sigma) / tau));
+            sn = -(p / (tau * cs)) * sign1(sigma);
+            const float aa = a * cs + b * sn, bb = -a * sn + b * cs;
+            const float cc = c * cs + d * sn, dd = -c * sn + d * cs;
+            a = aa * cs + cc * sn; b = bb * cs + dd * sn;
+            c = -aa * sn + cc * cs; d = -bb * sn + dd * cs;
+            temp = 0.5f * (a + d);
+            a = temp; d = temp;
+            if (c != 0.0f) {
+                if (b != 0.0f) {
+                    if (sign1(b) == sign1(c)) {
+                        const float sab = sqrtf(fabsf(b)), sac = sqrtf(fabsf(c));
+                        const float pp = __builtin_signbit(c) ? -fabsf(sab * sac) : fabsf(sab * sac);
+                        tau = 1.0f / sqrtf(fabsf(b + c));
+                        a = temp + pp; d = temp - pp;
+                        b = b - c; c = 0.0f;
+                        const float cs1 = sab * tau, sn1 = sac * tau;
+                        temp = cs * cs1 - sn * sn1;
+                        sn = cs * sn1 + sn * cs1;
+                        cs = temp;
+                    }
+                } else {
+                    b = -c; c = 0.0f;
+                    temp = cs; cs = -sn; sn = temp;
+                }
+            }
+        }
+    }
+    rt1 = a; rt2 = d;
+}
+
+// ---- mask-derived geometry columns from the wave's row words ------------------------------------
+// writes out[1]=major_axis [2]=minor_axis [3]=eccentricity [4]=orientation [8]=eliptic_deviation
+static __device__ void shape_from_row(uint64_t row, int ps, int lane, float *__restrict__ o)
+{
+    // per-row moments by popcount against the bit patterns "column index has bit j set"
+    constexpr uint64_t PAT[6] = {0xAAAAAAAAAAAAAAAAull, 0xCCCCCCCCCCCCCCCCull, 0xF0F0F0F0F0F0F0F0ull,
+                                 0xFF00FF00FF00FF00ull, 0xFFFF0000FFFF0000ull, 0xFFFFFFFF00000000ull};
+    const int kr = __popcll(row);
+    int sc = 0, scc = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const uint64_t mj = row & PAT[j];
+        const int pj = __popcll(mj);
+        sc += pj << j;
+        scc += pj << (2 * j);
+#pragma unroll
+        for (int k = j + 1; k < 6; ++k) scc += __popcll(mj & PAT[k]) << (j + k + 1);
+    }
+    const int K = wave_sum(kr);
+    const int sr = wave_sum(lane * kr);
+    const int scs = wave_sum(sc);
+    const int srr = wave_sum(lane * lane * kr);
+    const int src = wave_sum(lane * sc);
+    const int sccs = wave_sum(scc);
+
+    // center_of_mass (shape.rs:219-226): integer sums < 2^24 are exact in f32
+    const float mu_r = (float)sr / (float)K; // K == 0 -> NaN
+    const float mu_c = (float)scs / (float)K;
+    const float halfps = (float)ps / 2.0f;
+    const float cen0 = mu_r - halfps, cen1 = mu_c - halfps;
+
+    float major, minor, angle;
+    if (K == 0) {
+        major = minor = angle = __builtin_nanf("");
+    } else {
+        // covariance about the f32 means: exact integer moments, f64 closed form, rounded once
+        const double mr = (double)mu_r, mc = (double)mu_c, kd = (double)K;
+        const double Crr = (double)srr - 2.0 * mr * (double)sr + kd * mr * mr;
+        const double Crc = (double)src - mr * (double)scs - mc * (double)sr + kd * mr * mc;
+        const double Ccc = (double)sccs - 2.0 * mc * (double)scs + kd * mc * mc;
+        const float p = (float)Crr / (float)K;
+        const float q = (float)Crc / (float)K;
+        const float r = (float)Ccc / (float)K;
+        float w0, w1, cs, sn;
+        if (q == 0.0f) { w0 = p; w1 = r; cs = 1.0f; sn = 0.0f; }
+        else slanv2(p, q, q, r, w0, w1, cs, sn);
+        // eigenvectors V = [[cs,-sn],[sn,cs]]; the reference reads a ROW of V (shape.rs:191-195)
+        float mx, my, ea, eb;
+        if (w0 > w1) { ea = sqrtf(w0); eb = sqrtf(w1); mx = cs; my = -sn; }
+        else         { ea = sqrtf(w1); eb = sqrtf(w0); mx = sn; my = cs; }
+        angle = (float)atan2((double)mx, (double)my);
+        major = ea * 2.0f;
+        minor = eb * 2.0f;
+    }
+    const float hM = major * 0.5f, hm = minor * 0.5f;
+    const float ecc = sqrtf(hM * hM - hm * hm) / hM;
+
+    // ellipse (shape.rs:80-87) XOR mask, one row per lane
+    int xr = 0;
+    {
+        const double ct = cos((double)angle), st = sin((double)angle);
+        const double half = (double)ps / 2.0;
+        const double xc = (double)cen1, yc = (double)cen0, a = (double)major, b = (double)minor;
+        uint64_t ell = 0;
+        if (lane < ps && a > 0.0 && b > 0.0) { // a or b zero/NaN: every test is false
+            const double y = ((double)lane - half) - yc;
+            for (int c = 0; c < ps; ++c) {
+                const double x = ((double)c - half) - xc;
+                const double xrr = x * ct + y * st;
+                const double yrr = y * ct - x * st;
+                const double u = xrr / a, v = yrr / b;
+                if ((u * u + v * v) <= 1.0) ell |= 1ull << c;
+            }
+        }
+        xr = wave_sum(__popcll(ell ^ row));
+    }
+    if (lane == 0) {
+        o[1] = major;
+        o[2] = minor;
+        o[3] = ecc;
+        o[4] = angle;
+        o[8] = (float)xr / (float)K;
+    }
+}
+
+template <bool SHAPE>
+__global__ __launch_bounds__(256) void k_raster_shape(int64_t n, const uint32_t *__restrict__ poly_off,
+                                                      const float *__restrict__ poly_xy, int ps,
+                                                      uint64_t *__restrict__ rows_out, float *__restrict__ out, int F,
+                                                      int col0)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return; // wave-uniform
+    const uint64_t row = raster_row(poly_off, poly_xy, i, ps, lane);
+    if (rows_out && lane < ps) rows_out[i * ps + lane] = row;
+    if (SHAPE) shape_from_row(row, ps, lane, out + i * (int64_t)F + col0);
+}
+
+__global__ __launch_bounds__(256) void k_shape_from_rows(int64_t n, const uint64_t *__restrict__ rows, int ps,
+                                                         float *__restrict__ out, int F, int col0)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const uint64_t row = lane < ps ? rows[i * ps + lane] : 0ull;
+    shape_from_row(row, ps, lane, out + i * (int64_t)F + col0);
+}
+
+// ---- polygon-derived columns (geometric_features::*, shape.rs:89-97) -----------------------------
+// ONE LANE PER NUCLEUS: shoelace area, ring perimeter and Andrew's monotone chain are short
+// sequential f64 loops over ~30 vertices; 64 independent nuclei per wave keep every lane busy where a
+// wave-per-nucleus hull would idle most of them.  Sorted vertices and the hull stack live in a
+// global scratch area indexed by the polygon's own vertex offset.
+struct pt { double x, y; };
+
+static __device__ __forceinline__ bool pt_less(const pt &a, const pt &b)
+{
+    return (a.x < b.x) || (a.x == b.x && a.y < b.y);
+}
+static __device__ __forceinline__ double cross3(const pt &o, const pt &a, const pt &b)
+{
+    return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x);
+}
+static __device__ double ring_area(const pt *p, int n)
+{
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int j = (i + 1 == n) ? 0 : i + 1;
+        s += p[i].x * p[j].y - p[j].x * p[i].y;
+    }
+    return fabs(s) * 0.5;
+}
+static __device__ double ring_perimeter(const pt *p, int n)
+{
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int j = (i + 1 == n) ? 0 : i + 1;
+        const double dx = p[j].x - p[i].x, dy = p[j].y - p[i].y;
+        s += sqrt(dx * dx + dy * dy);
+    }
+    return s;
+}
+
+size_t polygon_scratch_bytes(int64_t n, int64_t total_vertices)
+{
+    // per nucleus: V original + V sorted + (2V+2) hull points
+    return sizeof(pt) * (size_t)(4 * total_vertices + 2 * n + 4);
+}
+
+__global__ __launch_bounds__(64) void k_polygon(int64_t n, const uint32_t *__restrict__ poly_off,
+                                                const float *__restrict__ poly_xy, pt *__restrict__ scratch,
+                                                float *__restrict__ out, int F, int col0)
+{
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v0 = poly_off[i];
+    const int V = (int)(poly_off[i + 1] - v0);
+    pt *p = scratch + 4 * (size_t)v0 + 2 * (size_t)i;
+    pt *s = p + V;
+    pt *h = s + V;
+    for (int k = 0; k < V; ++k) {
+        const float2 f = reinterpret_cast<const float2 *>(poly_xy)[v0 + k];
+        p[k].x = (double)f.x; p[k].y = (double)f.y;
+    }
+    const double PI = 3.14159265358979323846;
+    const double area = ring_area(p, V);
+    const double perim = ring_perimeter(p, V);
+    const double eq_perim = 2.0 * sqrt(PI * area);
+    const double compacity = 4.0 * PI * area / (perim * perim);
+
+    // insertion sort into s (lexicographic x then y)
+    for (int k = 0; k < V; ++k) {
+        const pt key = p[k];
+        int j = k - 1;
+        while (j >= 0 && pt_less(key, s[j])) { s[j + 1] = s[j]; --j; }
+        s[j + 1] = key;
+    }
+    int m = 0;
+    for (int k = 0; k < V; ++k) {
+        while (m >= 2 && cross3(h[m - 2], h[m - 1], s[k]) <= 0.0) --m;
+        h[m++] = s[k];
+    }
+    const int lower = m + 1;
+    for (int k = V - 2; k >= 0; --k) {
+        while (m >= lower && cross3(h[m - 2], h[m - 1], s[k]) <= 0.0) --m;
+        h[m++] = s[k];
+    }
+    if (m > 1) --m;
+    const double harea = ring_area(h, m);
+    const double hperim = ring_perimeter(h, m);
+    const double deviation = (harea - area) / harea;
+
+    float *o = out + i * (int64_t)F + col0;
+    o[0] = (float)area;
+    o[5] = (float)perim;
+    o[6] = (float)eq_perim;
+    o[7] = (float)compacity;
+    o[9] = (float)harea;
+    o[10] = (float)deviation;
+    o[11] = (float)hperim;
+}
+
+// ---- launchers ------------------------------------------------------------------------------------
+hipError_t launch_raster_shape(nfx_ctx *ctx, int64_t n, const uint32_t *poly_off, const float *poly_xy, int ps,
+                               uint64_t *rows_out, float *out, int F, int col0)
+{
+    if (n == 0) return hipSuccess;
+    ScopedTiming t(ctx, KS_RASTER_SHAPE);
+    const unsigned grid = (unsigned)((n + 3) / 4);
+    if (out)
+        hipLaunchKernelGGL(k_raster_shape<true>, dim3(grid), dim3(256), 0, ctx->stream, n, poly_off, poly_xy, ps, rows_out, out, F, col0);
+    else
+        hipLaunchKernelGGL(k_raster_shape<false>, dim3(grid), dim3(256), 0, ctx->stream, n, poly_off, poly_xy, ps, rows_out, out, F, col0);
+    return hipGetLastError();
+}
+
+hipError_t launch_shape_from_rows(nfx_ctx *ctx, int64_t n, const uint64_t *rows, int ps, float *out, int F, int col0)
+{
+    if (n == 0) return hipSuccess;
+    ScopedTiming t(ctx, KS_RASTER_SHAPE);
+    hipLaunchKernelGGL(k_shape_from_rows, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, n, rows, ps, out, F, col0);
+    return hipGetLastError();
+}
+
+hipError_t launch_polygon(nfx_ctx *ctx, int64_t n, const uint32_t *poly_off, const float *poly_xy, void *scratch,
+                          float *out, int F, int col0)
+{
+    if (n == 0) return hipSuccess;
+    ScopedTiming t(ctx, KS_POLYGON);
+    hipLaunchKernelGGL(k_polygon, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, n, poly_off, poly_xy,
+                       reinterpret_cast<pt *>(scratch), out, F, col0);
+    return hipGetLastError();
+}
+
+}  // namespace nfx

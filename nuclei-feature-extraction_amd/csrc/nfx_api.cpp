@@ -1,0 +1,639 @@
+// nfx_api.cpp -- the C ABI declared in include/nfx.h: registry, context, staging and the
+// orchestration of the HIP kernels.  Compiled with hipcc (host code only in this file).
+#include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <strings.h>
+
+#include "nfx_internal.h"
+
+using namespace nfx;
+
+namespace nfx {
+const char *const kKernelSlotNames[KS_COUNT] = {"k_preprocess", "k_raster_shape", "k_polygon",  "k_pack_masks", "k_gather_patches",
+                                                "k_hue_batch",  "k_color",        "k_glcm",     "k_glrlm",      "k_gabor"};
+}
+
+// ------------------------------------------------------------------------------------------------
+// registry: names exactly as the reference emits them
+// ------------------------------------------------------------------------------------------------
+static const char *const kSetNames[NFX_SET_COUNT] = {"geometry", "color", "GLCM", "GLRLM", "gabor filter"};
+static const char *const kSetCliNames[NFX_SET_COUNT] = {"geometry", "color", "glcm", "glrlm", "gabor"};
+
+static std::vector<std::string> g_cols[NFX_SET_COUNT];
+static std::once_flag g_cols_once;
+
+static std::string rust_f32_display(float v)
+{
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+    char buf[128];
+    auto r = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::fixed);
+    return std::string(buf, r.ptr);
+}
+
+static void build_columns()
+{
+    // shape.rs:113-128
+    g_cols[0] = {"area", "major_axis", "minor_axis", "eccentricity", "orientation", "perimeter", "equivalent_perimeter",
+                 "compacity", "eliptic_deviation", "convex_hull_area", "convex_deffect", "convex_perimeter"};
+    // color.rs:80-99
+    g_cols[1] = {"mean_r", "mean_g", "mean_b", "std_r", "std_g", "std_b", "mean_h", "mean_s", "mean_v",
+                 "std_h", "std_s", "std_v", "mean_haematoxylin", "mean_eosin", "mean_dab", "std_haematoxylin",
+                 "std_eosin", "std_dab"};
+    // texture.rs:19-20,81-157
+    static const int levels[4] = {32, 64, 128, 254};
+    static const int offs[4][2] = {{0, 1}, {1, 1}, {1, 0}, {1, -1}};
+    static const char *const gf[14] = {"correlation", "contrast", "dissimilarity", "entropy", "angular_second_moment",
+                                       "sum_average", "sum_variance", "sum_entropy", "sum_of_squares",
+                                       "inverse_difference_moment", "difference_average", "difference_variance",
+                                       "information_measure_correlation1", "information_measure_correlation2"};
+    for (int l = 0; l < 4; ++l)
+        for (int o = 0; o < 4; ++o)
+            for (int f = 0; f < 14; ++f) {
+                char b[128];
+                snprintf(b, sizeof b, "%s_%d_%d_%d", gf[f], offs[o][0], offs[o][1], levels[l]);
+                g_cols[2].push_back(b);
+            }
+    // texture.rs:176,244-301
+    static const int dirs[4][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}};
+    static const char *const rf[17] = {"short_run_emphasis", "long_run_emphasis", "gray_level_nonuniformity",
+                                       "run_length_nonuniformity", "low_gray_level_run_emphasis",
+                                       "high_gray_level_run_emphasis", "short_run_low_gray_level_emphasis",
+                                       "short_run_high_gray_level_emphasis", "long_run_low_gray_level_emphasis",
+                                       "long_run_high_gray_level_emphasis", "short_run_mid_gray_level_emphasis",
+                                       "long_run_mid_gray_level_emphasis", "short_run_extreme_gray_level_emphasis",
+                                       "long_run_extreme_gray_level_emphasis", "run_percentage", "run_length_mean",
+                                       "run_length_variance"};
+    for (int d = 0; d < 4; ++d)
+        for (int f = 0; f < 17; ++f) {
+            char b[128];
+            snprintf(b, sizeof b, "%s_%d_%d", rf[f], dirs[d][0], dirs[d][1]);
+            g_cols[3].push_back(b);
+        }
+    // texture.rs:319-320,346-361: angle = (j / 6) as f32 * 45.0, frequency = FREQUENCIES[j % 6] as f32
+    static const float freqs[6] = {0.5f, 1.0f, 2.0f, 4.0f, 6.0f, 8.0f};
+    for (int j = 0; j < 48; ++j) {
+        const std::string a = rust_f32_display((float)(j / 6) * 45.0f), f = rust_f32_display(freqs[j % 6]);
+        g_cols[4].push_back("gabor_angle_" + a + "_frequency_" + f + "_mean");
+        g_cols[4].push_back("gabor_angle_" + a + "_frequency_" + f + "_variance");
+    }
+}
+
+extern "C" {
+
+int nfx_version(void) { return NFX_VERSION; }
+int nfx_feature_set_count(void) { return NFX_SET_COUNT; }
+const char *nfx_feature_set_name(int set) { return (set >= 0 && set < NFX_SET_COUNT) ? kSetNames[set] : nullptr; }
+const char *nfx_feature_set_cli_name(int set) { return (set >= 0 && set < NFX_SET_COUNT) ? kSetCliNames[set] : nullptr; }
+int nfx_feature_set_num_columns(int set) { return (set >= 0 && set < NFX_SET_COUNT) ? kNumCols[set] : -1; }
+
+int nfx_feature_set_column_name(int set, int j, char *buf, size_t buflen)
+{
+    if (set < 0 || set >= NFX_SET_COUNT || !buf) return -1;
+    std::call_once(g_cols_once, build_columns);
+    if (j < 0 || j >= (int)g_cols[set].size()) return -1;
+    const std::string &s = g_cols[set][j];
+    if (s.size() + 1 > buflen) return -1;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
+int nfx_parse_feature_sets(const char *const *names, int n_names, int *out_sets, int cap)
+{
+    int m = 0;
+    auto push = [&](int s) {
+        if (m < cap) out_sets[m] = s;
+        ++m;
+    };
+    for (int i = 0; i < n_names; ++i) {
+        const char *s = names[i];
+        if (!s) return -1;
+        if (!strcasecmp(s, "geometry")) push(NFX_SET_GEOMETRY);
+        else if (!strcasecmp(s, "color")) push(NFX_SET_COLOR);
+        else if (!strcasecmp(s, "glcm")) push(NFX_SET_GLCM);
+        else if (!strcasecmp(s, "glrlm")) push(NFX_SET_GLRLM);
+        else if (!strcasecmp(s, "gabor")) push(NFX_SET_GABOR);
+        else if (!strcasecmp(s, "texture")) { push(NFX_SET_GLCM); push(NFX_SET_GLRLM); push(NFX_SET_GABOR); }
+        else if (!strcasecmp(s, "all")) { for (int k = 0; k < NFX_SET_COUNT; ++k) push(k); }
+        else return -1;
+    }
+    return m <= cap ? m : -2;
+}
+
+int nfx_centroid_key(float x, float y, char *buf, size_t buflen)
+{
+    const std::string s = rust_f32_display(x) + "," + rust_f32_display(y);
+    if (!buf || s.size() + 1 > buflen) return -1;
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// context, workspace, timing
+// ------------------------------------------------------------------------------------------------
+static nfx_status fail(nfx_ctx *ctx, nfx_status st, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    return st;
+}
+
+#define NFX_HIP(ctx, expr)                                                                                 \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? NFX_ERR_OUT_OF_MEMORY : NFX_ERR_DEVICE,           \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                                \
+    } while (0)
+
+namespace nfx {
+
+bool ws_reserve(nfx_ctx *ctx, size_t bytes)
+{
+    ctx->ws_off = 0;
+    if (bytes <= ctx->ws_cap) return true;
+    if (ctx->ws) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->ws);
+        ctx->ws = nullptr;
+        ctx->ws_cap = 0;
+    }
+    const size_t cap = bytes + (bytes >> 3) + (1u << 20);
+    if (hipMalloc(reinterpret_cast<void **>(&ctx->ws), cap) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    ctx->ws_cap = cap;
+    return true;
+}
+
+static size_t al(size_t b) { return (b + 255) & ~size_t(255); }
+
+void *ws_alloc(nfx_ctx *ctx, size_t bytes)
+{
+    const size_t a = al(bytes);
+    if (ctx->ws_off + a > ctx->ws_cap) return nullptr;
+    void *p = ctx->ws + ctx->ws_off;
+    ctx->ws_off += a;
+    return p;
+}
+
+static hipEvent_t get_event(nfx_ctx *ctx)
+{
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void timing_begin(nfx_ctx *ctx, int slot)
+{
+    if (!ctx->timing) return;
+    Timing t{get_event(ctx), get_event(ctx), slot};
+    (void)hipEventRecord(t.start, ctx->stream);
+    ctx->pending.push_back(t);
+}
+
+void timing_end(nfx_ctx *ctx)
+{
+    if (!ctx->timing || ctx->pending.empty()) return;
+    (void)hipEventRecord(ctx->pending.back().stop, ctx->stream);
+}
+
+static void timing_collect(nfx_ctx *ctx)
+{
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &t : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+            ctx->total_ms[t.slot] += ms;
+            ctx->launches[t.slot] += 1;
+        }
+        ctx->event_pool.push_back(t.start);
+        ctx->event_pool.push_back(t.stop);
+    }
+    ctx->pending.clear();
+}
+
+}  // namespace nfx
+
+extern "C" {
+
+nfx_status nfx_ctx_create(int device, nfx_ctx **out)
+{
+    if (!out) return NFX_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return NFX_ERR_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return NFX_ERR_DEVICE;
+    nfx_ctx *c = new nfx_ctx();
+    c->device = device;
+    *out = c;
+    return NFX_OK;
+}
+
+void nfx_ctx_destroy(nfx_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &t : ctx->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->gabor_tab) (void)hipFree(ctx->gabor_tab);
+    if (ctx->od_lut) (void)hipFree(ctx->od_lut);
+    delete ctx;
+}
+
+const char *nfx_last_error(const nfx_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+nfx_status nfx_ctx_set_stream(nfx_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return NFX_ERR_INVALID_ARGUMENT;
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return NFX_OK;
+}
+
+nfx_status nfx_ctx_synchronize(nfx_ctx *ctx)
+{
+    if (!ctx) return NFX_ERR_INVALID_ARGUMENT;
+    NFX_HIP(ctx, hipSetDevice(ctx->device));
+    NFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NFX_OK;
+}
+
+nfx_status nfx_ctx_enable_timing(nfx_ctx *ctx, int on)
+{
+    if (!ctx) return NFX_ERR_INVALID_ARGUMENT;
+    if (!on && ctx->timing) timing_collect(ctx);
+    ctx->timing = on != 0;
+    return NFX_OK;
+}
+
+int nfx_ctx_kernel_timing(nfx_ctx *ctx, int k, const char **name, int64_t *launches, double *total_ms)
+{
+    if (!ctx) return -1;
+    timing_collect(ctx);
+    if (k >= 0 && k < KS_COUNT) {
+        if (name) *name = kKernelSlotNames[k];
+        if (launches) *launches = ctx->launches[k];
+        if (total_ms) *total_ms = ctx->total_ms[k];
+    }
+    return KS_COUNT;
+}
+
+nfx_status nfx_ctx_reset_timing(nfx_ctx *ctx)
+{
+    if (!ctx) return NFX_ERR_INVALID_ARGUMENT;
+    timing_collect(ctx);
+    for (int k = 0; k < KS_COUNT; ++k) { ctx->launches[k] = 0; ctx->total_ms[k] = 0.0; }
+    return NFX_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// device-resident orchestration
+// ------------------------------------------------------------------------------------------------
+static nfx_status check_common(nfx_ctx *ctx, int64_t n, int64_t nv, int ps)
+{
+    if (!ctx) return NFX_ERR_INVALID_ARGUMENT;
+    if (n < 0 || nv < 0) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "negative size");
+    if (ps < 1) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "patch size must be >= 1");
+    if (ps > NFX_MAX_PATCH_SIZE) return fail(ctx, NFX_ERR_UNSUPPORTED, "patch size > 64 is not supported by the gfx950 row-word kernels");
+    if (nv > 0xFFFFFFFFll) return fail(ctx, NFX_ERR_UNSUPPORTED, "more than 2^32-1 vertices in one call");
+    return NFX_OK;
+}
+
+static int sets_total_columns(const int *sets, int n_sets)
+{
+    int F = 0;
+    for (int s = 0; s < n_sets; ++s) {
+        if (sets[s] < 0 || sets[s] >= NFX_SET_COUNT) return -1;
+        F += kNumCols[sets[s]];
+    }
+    return F;
+}
+
+static bool any_pixel_set(const int *sets, int n_sets)
+{
+    for (int s = 0; s < n_sets; ++s)
+        if (sets[s] != NFX_SET_GEOMETRY) return true;
+    return false;
+}
+
+static bool has_set(const int *sets, int n_sets, int which)
+{
+    for (int s = 0; s < n_sets; ++s)
+        if (sets[s] == which) return true;
+    return false;
+}
+
+// workspace bytes needed by extract_device (excluding host staging)
+static size_t extract_ws_bytes(const int *sets, int n_sets, int64_t n, int64_t nv, int ps, int batch_size, bool need_centroids,
+                               bool gather)
+{
+    size_t b = 0;
+    b += al(sizeof(float) * 2 * (size_t)nv);                     // centred polygons
+    if (need_centroids) b += al(sizeof(float) * 2 * (size_t)n);
+    if (any_pixel_set(sets, n_sets)) b += al(sizeof(uint64_t) * (size_t)n * ps);
+    if (has_set(sets, n_sets, NFX_SET_GEOMETRY)) b += al(polygon_scratch_bytes(n, nv));
+    if (gather) b += al((size_t)n * 3 * ps * ps);
+    if (has_set(sets, n_sets, NFX_SET_COLOR)) {
+        Job j; j.n = n; j.ps = ps; j.batch_size = batch_size;
+        b += al(color_scratch_bytes(j));
+    }
+    return b + 4096;
+}
+
+// everything on the device; ws already reserved
+static nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_off,
+                                 const float *ring_xy, const uint8_t *patches_u8, const uint8_t *image, int64_t H, int64_t W,
+                                 int ps, int batch_size, float *out_rows, float *out_centroids)
+{
+    const int F = sets_total_columns(sets, n_sets);
+    float *centred = (float *)ws_alloc(ctx, sizeof(float) * 2 * (size_t)nv);
+    float *centroids = out_centroids;
+    if (!centroids && image) centroids = (float *)ws_alloc(ctx, sizeof(float) * 2 * (size_t)n);
+    uint64_t *rows = nullptr;
+    const bool pix = any_pixel_set(sets, n_sets);
+    if (pix) rows = (uint64_t *)ws_alloc(ctx, sizeof(uint64_t) * (size_t)n * ps);
+    if (!centred || (pix && !rows) || (image && !centroids)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
+
+    NFX_HIP(ctx, launch_preprocess(ctx, n, ring_off, ring_xy, centroids, centred));
+    if (image && pix) {
+        uint8_t *gp = (uint8_t *)ws_alloc(ctx, (size_t)n * 3 * ps * ps);
+        if (!gp) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
+        NFX_HIP(ctx, launch_gather_patches(ctx, n, centroids, image, H, W, ps, gp));
+        patches_u8 = gp;
+    }
+    // rasterise once; the mask-derived geometry columns are produced in the same kernel
+    int geo_col = -1;
+    {
+        int col = 0;
+        for (int s = 0; s < n_sets; ++s) {
+            if (sets[s] == NFX_SET_GEOMETRY && geo_col < 0) geo_col = col;
+            col += kNumCols[sets[s]];
+        }
+    }
+    NFX_HIP(ctx, launch_raster_shape(ctx, n, ring_off, centred, ps, rows, geo_col >= 0 ? out_rows : nullptr, F, geo_col >= 0 ? geo_col : 0));
+
+    Job job;
+    job.n = n; job.ps = ps; job.batch_size = batch_size; job.poly_off = ring_off; job.poly_xy = centred;
+    job.patches = patches_u8; job.patches_f32 = false; job.mask_rows = rows; job.out = out_rows; job.F = F;
+
+    int col = 0;
+    bool geo_done = false;
+    void *poly_scr = nullptr;
+    for (int s = 0; s < n_sets; ++s) {
+        switch (sets[s]) {
+        case NFX_SET_GEOMETRY: {
+            if (!poly_scr) poly_scr = ws_alloc(ctx, polygon_scratch_bytes(n, nv));
+            void *scr = poly_scr;
+            if (!scr) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
+            if (geo_done) // a repeated "geometry" (args.rs does not de-duplicate): recompute into its own columns
+                NFX_HIP(ctx, launch_raster_shape(ctx, n, ring_off, centred, ps, nullptr, out_rows, F, col));
+            NFX_HIP(ctx, launch_polygon(ctx, n, ring_off, centred, scr, out_rows, F, col));
+            geo_done = true;
+            break;
+        }
+        case NFX_SET_COLOR: {
+            void *scr = ws_alloc(ctx, color_scratch_bytes(job));
+            if (!scr) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
+            NFX_HIP(ctx, launch_color(ctx, job, col, scr));
+            break;
+        }
+        case NFX_SET_GLCM: NFX_HIP(ctx, launch_glcm(ctx, job, col)); break;
+        case NFX_SET_GLRLM: NFX_HIP(ctx, launch_glrlm(ctx, job, col)); break;
+        case NFX_SET_GABOR: NFX_HIP(ctx, launch_gabor(ctx, job, col)); break;
+        }
+        col += kNumCols[sets[s]];
+    }
+    return NFX_OK;
+}
+
+// host staging helper: copies src (host) into the workspace
+template <typename T>
+static T *stage_in(nfx_ctx *ctx, const T *src, size_t count)
+{
+    T *d = (T *)ws_alloc(ctx, sizeof(T) * (count ? count : 1));
+    if (d && count && hipMemcpyAsync(d, src, sizeof(T) * count, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return nullptr;
+    return d;
+}
+
+extern "C" {
+
+nfx_status nfx_preprocess_polygons(nfx_ctx *ctx, int64_t n, int64_t nv, const uint32_t *ring_offsets, const float *ring_xy,
+                                   float *centroids_xy, float *centred_xy, nfx_mem mem)
+{
+    nfx_status st = check_common(ctx, n, nv, 1);
+    if (st != NFX_OK) return st;
+    if (!ring_offsets || (nv && !ring_xy)) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null input");
+    NFX_HIP(ctx, hipSetDevice(ctx->device));
+    if (mem == NFX_MEM_DEVICE) {
+        NFX_HIP(ctx, launch_preprocess(ctx, n, ring_offsets, ring_xy, centroids_xy, centred_xy));
+        return NFX_OK;
+    }
+    if (ring_offsets[n] != (uint32_t)nv) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "ring_offsets[n] != n_vertices");
+    if (!ws_reserve(ctx, al(4 * (n + 1)) + 2 * al(8 * nv) + al(8 * n) + 4096)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    uint32_t *d_off = stage_in(ctx, ring_offsets, (size_t)n + 1);
+    float *d_xy = stage_in(ctx, ring_xy, 2 * (size_t)nv);
+    float *d_cen = (float *)ws_alloc(ctx, 8 * (size_t)n + 8);
+    float *d_ctr = (float *)ws_alloc(ctx, 8 * (size_t)nv + 8);
+    if (!d_off || !d_xy || !d_cen || !d_ctr) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    NFX_HIP(ctx, launch_preprocess(ctx, n, d_off, d_xy, d_cen, d_ctr));
+    if (centroids_xy && n) NFX_HIP(ctx, hipMemcpyAsync(centroids_xy, d_cen, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (centred_xy && nv) NFX_HIP(ctx, hipMemcpyAsync(centred_xy, d_ctr, 8 * (size_t)nv, hipMemcpyDeviceToHost, ctx->stream));
+    NFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NFX_OK;
+}
+
+nfx_status nfx_rasterize_polygons(nfx_ctx *ctx, int64_t n, int64_t nv, const uint32_t *poly_offsets, const float *poly_xy, int ps,
+                                  float *masks_f32, uint64_t *mask_rows, nfx_mem mem)
+{
+    nfx_status st = check_common(ctx, n, nv, ps);
+    if (st != NFX_OK) return st;
+    if (!poly_offsets || (nv && !poly_xy)) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null input");
+    NFX_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t rows_b = sizeof(uint64_t) * (size_t)n * ps, mask_b = sizeof(float) * (size_t)n * ps * ps;
+    if (mem == NFX_MEM_DEVICE) {
+        uint64_t *rows = mask_rows;
+        if (!rows) {
+            if (!ws_reserve(ctx, al(rows_b) + 4096)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+            rows = (uint64_t *)ws_alloc(ctx, rows_b);
+        }
+        NFX_HIP(ctx, launch_raster_shape(ctx, n, poly_offsets, poly_xy, ps, rows, nullptr, 0, 0));
+        if (masks_f32) NFX_HIP(ctx, launch_unpack_masks(ctx, n, rows, ps, masks_f32));
+        return NFX_OK;
+    }
+    if (poly_offsets[n] != (uint32_t)nv) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "poly_offsets[n] != n_vertices");
+    if (!ws_reserve(ctx, al(4 * (n + 1)) + al(8 * nv) + al(rows_b) + al(mask_b) + 4096)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    uint32_t *d_off = stage_in(ctx, poly_offsets, (size_t)n + 1);
+    float *d_xy = stage_in(ctx, poly_xy, 2 * (size_t)nv);
+    uint64_t *d_rows = (uint64_t *)ws_alloc(ctx, rows_b + 8);
+    float *d_m = masks_f32 ? (float *)ws_alloc(ctx, mask_b + 8) : nullptr;
+    if (!d_off || !d_xy || !d_rows || (masks_f32 && !d_m)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    NFX_HIP(ctx, launch_raster_shape(ctx, n, d_off, d_xy, ps, d_rows, nullptr, 0, 0));
+    if (masks_f32) {
+        NFX_HIP(ctx, launch_unpack_masks(ctx, n, d_rows, ps, d_m));
+        if (n) NFX_HIP(ctx, hipMemcpyAsync(masks_f32, d_m, mask_b, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (mask_rows && n) NFX_HIP(ctx, hipMemcpyAsync(mask_rows, d_rows, rows_b, hipMemcpyDeviceToHost, ctx->stream));
+    NFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NFX_OK;
+}
+
+nfx_status nfx_compute_features_batched(nfx_ctx *ctx, int set, int64_t n, int64_t nv, const float *centroids_xy,
+                                        const uint32_t *poly_offsets, const float *poly_xy, const float *patchs, const float *masks,
+                                        int ps, float *out, nfx_mem mem)
+{
+    (void)centroids_xy;
+    nfx_status st = check_common(ctx, n, nv, ps);
+    if (st != NFX_OK) return st;
+    if (set < 0 || set >= NFX_SET_COUNT) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "unknown feature set");
+    if (!poly_offsets || (nv && !poly_xy) || !masks || !out || (set != NFX_SET_GEOMETRY && !patchs))
+        return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null input");
+    if (n > 0x7FFFFFFF) return fail(ctx, NFX_ERR_UNSUPPORTED, "batch too large");
+    NFX_HIP(ctx, hipSetDevice(ctx->device));
+    const int F = kNumCols[set];
+    const size_t P = (size_t)ps * ps;
+    Job job;
+    job.n = n; job.ps = ps; job.batch_size = (int)(n > 0 ? n : 1); job.patches_f32 = true; job.F = F;
+    size_t need = al(8 * (size_t)n * ps) + 4096;
+    if (set == NFX_SET_GEOMETRY) need += al(polygon_scratch_bytes(n, nv));
+    if (set == NFX_SET_COLOR) need += al(color_scratch_bytes(job));
+    if (mem == NFX_MEM_HOST) {
+        if (poly_offsets[n] != (uint32_t)nv) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "poly_offsets[n] != n_vertices");
+        need += al(4 * (n + 1)) + al(8 * nv) + al(4 * n * P) + al(12 * n * P) + al(4 * (size_t)n * F);
+    }
+    if (!ws_reserve(ctx, need)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    float *d_out = out;
+    if (mem == NFX_MEM_HOST) {
+        poly_offsets = stage_in(ctx, poly_offsets, (size_t)n + 1);
+        poly_xy = stage_in(ctx, poly_xy, 2 * (size_t)nv);
+        masks = stage_in(ctx, masks, (size_t)n * P);
+        if (set != NFX_SET_GEOMETRY) patchs = stage_in(ctx, patchs, 3 * (size_t)n * P);
+        d_out = (float *)ws_alloc(ctx, 4 * (size_t)n * F + 4);
+        if (!poly_offsets || !poly_xy || !masks || (set != NFX_SET_GEOMETRY && !patchs) || !d_out)
+            return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    }
+    uint64_t *rows = (uint64_t *)ws_alloc(ctx, 8 * (size_t)n * ps + 8);
+    if (!rows) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    NFX_HIP(ctx, launch_pack_masks(ctx, n, masks, ps, rows));
+    job.poly_off = poly_offsets; job.poly_xy = poly_xy; job.patches = patchs; job.mask_rows = rows; job.out = d_out;
+    switch (set) {
+    case NFX_SET_GEOMETRY: {
+        void *scr = ws_alloc(ctx, polygon_scratch_bytes(n, nv));
+        if (!scr) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+        NFX_HIP(ctx, launch_shape_from_rows(ctx, n, rows, ps, d_out, F, 0));
+        NFX_HIP(ctx, launch_polygon(ctx, n, poly_offsets, poly_xy, scr, d_out, F, 0));
+        break;
+    }
+    case NFX_SET_COLOR: {
+        void *scr = ws_alloc(ctx, color_scratch_bytes(job));
+        if (!scr) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+        NFX_HIP(ctx, launch_color(ctx, job, 0, scr));
+        break;
+    }
+    case NFX_SET_GLCM: NFX_HIP(ctx, launch_glcm(ctx, job, 0)); break;
+    case NFX_SET_GLRLM: NFX_HIP(ctx, launch_glrlm(ctx, job, 0)); break;
+    case NFX_SET_GABOR: NFX_HIP(ctx, launch_gabor(ctx, job, 0)); break;
+    }
+    if (mem == NFX_MEM_HOST) {
+        if (n) NFX_HIP(ctx, hipMemcpyAsync(out, d_out, 4 * (size_t)n * F, hipMemcpyDeviceToHost, ctx->stream));
+        NFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return NFX_OK;
+}
+
+static nfx_status extract_common(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_offsets,
+                                 const float *ring_xy, const uint8_t *patches_u8, const uint8_t *image, int64_t H, int64_t W, int ps,
+                                 int batch_size, float *out_rows, float *out_centroids, nfx_mem mem)
+{
+    nfx_status st = check_common(ctx, n, nv, ps);
+    if (st != NFX_OK) return st;
+    if (!sets || n_sets <= 0) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "no feature set selected");
+    const int F = sets_total_columns(sets, n_sets);
+    if (F < 0) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "unknown feature set");
+    if (batch_size < 1) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "batch_size must be >= 1");
+    const bool pix = any_pixel_set(sets, n_sets);
+    if (!ring_offsets || (nv && !ring_xy) || !out_rows || (pix && !patches_u8 && !image))
+        return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null input");
+    if (image && (H < 1 || W < 1)) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "empty image");
+    NFX_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)ps * ps;
+    size_t need = extract_ws_bytes(sets, n_sets, n, nv, ps, batch_size, image && !out_centroids, image && pix);
+    if (mem == NFX_MEM_HOST) {
+        if (ring_offsets[n] != (uint32_t)nv) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "ring_offsets[n] != n_vertices");
+        need += al(4 * (n + 1)) + al(8 * nv) + al(4 * (size_t)n * F) + al(8 * n);
+        if (pix) need += image ? al(3 * (size_t)H * W) : al(3 * (size_t)n * P);
+    }
+    if (!ws_reserve(ctx, need)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    if (mem == NFX_MEM_DEVICE)
+        return extract_device(ctx, sets, n_sets, n, nv, ring_offsets, ring_xy, patches_u8, image, H, W, ps, batch_size, out_rows, out_centroids);
+
+    uint32_t *d_off = stage_in(ctx, ring_offsets, (size_t)n + 1);
+    float *d_xy = stage_in(ctx, ring_xy, 2 * (size_t)nv);
+    const uint8_t *d_p = nullptr, *d_img = nullptr;
+    if (pix && image) d_img = stage_in(ctx, image, 3 * (size_t)H * W);
+    else if (pix) d_p = stage_in(ctx, patches_u8, 3 * (size_t)n * P);
+    float *d_out = (float *)ws_alloc(ctx, 4 * (size_t)n * F + 4);
+    float *d_cen = (float *)ws_alloc(ctx, 8 * (size_t)n + 8);
+    if (!d_off || !d_xy || (pix && !d_p && !d_img) || !d_out || !d_cen) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    st = extract_device(ctx, sets, n_sets, n, nv, d_off, d_xy, d_p, d_img, H, W, ps, batch_size, d_out, d_cen);
+    if (st != NFX_OK) return st;
+    if (n) NFX_HIP(ctx, hipMemcpyAsync(out_rows, d_out, 4 * (size_t)n * F, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_centroids && n) NFX_HIP(ctx, hipMemcpyAsync(out_centroids, d_cen, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    NFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NFX_OK;
+}
+
+nfx_status nfx_extract(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_offsets,
+                       const float *ring_xy, const uint8_t *patches_u8, int ps, int batch_size, float *out_rows,
+                       float *out_centroids_xy, nfx_mem mem)
+{
+    return extract_common(ctx, sets, n_sets, n, nv, ring_offsets, ring_xy, patches_u8, nullptr, 0, 0, ps, batch_size, out_rows,
+                          out_centroids_xy, mem);
+}
+
+nfx_status nfx_extract_tile(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_offsets,
+                            const float *ring_xy, const uint8_t *image_u8, int64_t H, int64_t W, int ps, int batch_size,
+                            float *out_rows, float *out_centroids_xy, nfx_mem mem)
+{
+    if (!image_u8) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null image");
+    return extract_common(ctx, sets, n_sets, n, nv, ring_offsets, ring_xy, nullptr, image_u8, H, W, ps, batch_size, out_rows,
+                          out_centroids_xy, mem);
+}
+
+nfx_status nfx_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids_xy, const uint8_t *image_u8, int64_t H, int64_t W, int ps,
+                              uint8_t *patches_u8, nfx_mem mem)
+{
+    nfx_status st = check_common(ctx, n, 0, ps);
+    if (st != NFX_OK) return st;
+    if (!centroids_xy || !image_u8 || !patches_u8 || H < 1 || W < 1) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null input");
+    NFX_HIP(ctx, hipSetDevice(ctx->device));
+    if (mem == NFX_MEM_DEVICE) {
+        NFX_HIP(ctx, launch_gather_patches(ctx, n, centroids_xy, image_u8, H, W, ps, patches_u8));
+        return NFX_OK;
+    }
+    const size_t pb = (size_t)n * 3 * ps * ps;
+    if (!ws_reserve(ctx, al(8 * n) + al(3 * (size_t)H * W) + al(pb) + 4096)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    float *d_c = stage_in(ctx, centroids_xy, 2 * (size_t)n);
+    uint8_t *d_i = stage_in(ctx, image_u8, 3 * (size_t)H * W);
+    uint8_t *d_p = (uint8_t *)ws_alloc(ctx, pb + 8);
+    if (!d_c || !d_i || !d_p) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    NFX_HIP(ctx, launch_gather_patches(ctx, n, d_c, d_i, H, W, ps, d_p));
+    if (n) NFX_HIP(ctx, hipMemcpyAsync(patches_u8, d_p, pb, hipMemcpyDeviceToHost, ctx->stream));
+    NFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NFX_OK;
+}
+
+}  // extern "C"

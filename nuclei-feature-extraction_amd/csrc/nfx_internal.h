@@ -1,0 +1,107 @@
+// nfx_internal.h -- shared declarations of the engine (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/nfx.h"
+
+namespace nfx {
+
+// kernel timing slots (nfx_ctx_kernel_timing)
+enum KernelSlot {
+    KS_PREPROCESS = 0,
+    KS_RASTER_SHAPE,
+    KS_POLYGON,
+    KS_PACK_MASKS,
+    KS_GATHER,
+    KS_HUE_BATCH,
+    KS_COLOR,
+    KS_GLCM,
+    KS_GLRLM,
+    KS_GABOR,
+    KS_COUNT
+};
+extern const char *const kKernelSlotNames[KS_COUNT];
+
+static constexpr int kNumCols[NFX_SET_COUNT] = {12, 18, 224, 68, 96};
+
+struct Timing {
+    hipEvent_t start, stop;
+    int slot;
+};
+
+}  // namespace nfx
+
+struct nfx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // grow-only device workspace with a bump pointer, reset at the start of every API call
+    char *ws = nullptr;
+    size_t ws_cap = 0, ws_off = 0;
+    // timing
+    bool timing = false;
+    std::vector<nfx::Timing> pending;
+    std::vector<hipEvent_t> event_pool;
+    int64_t launches[nfx::KS_COUNT] = {};
+    double total_ms[nfx::KS_COUNT] = {};
+    // Gabor filter tables (device), built lazily
+    float *gabor_tab = nullptr;
+    // u8 -> optical-density lookup (device), built lazily
+    float *od_lut = nullptr;
+};
+
+namespace nfx {
+
+// One unit of device work: nuclei [0,n) with everything resident on the device.
+struct Job {
+    int64_t n = 0;
+    int ps = 0;
+    int batch_size = 0;                 // reference batch (par_chunks) size; hue statistics couple within it
+    const uint32_t *poly_off = nullptr; // [n+1] centred polygons
+    const float *poly_xy = nullptr;
+    const void *patches = nullptr;      // [n,3,ps,ps] u8 or f32
+    bool patches_f32 = false;
+    const uint64_t *mask_rows = nullptr; // [n,ps]
+    float *out = nullptr;               // [n,F]
+    int F = 0;
+};
+
+// RAII-less helpers ---------------------------------------------------------------------------
+bool ws_reserve(nfx_ctx *ctx, size_t bytes);       // make capacity >= bytes (may reallocate: only before ws_alloc calls)
+void *ws_alloc(nfx_ctx *ctx, size_t bytes);        // 256-B aligned bump allocation; nullptr when exhausted
+void timing_begin(nfx_ctx *ctx, int slot);
+void timing_end(nfx_ctx *ctx);
+
+struct ScopedTiming {
+    nfx_ctx *c;
+    ScopedTiming(nfx_ctx *ctx, int slot) : c(ctx) { timing_begin(c, slot); }
+    ~ScopedTiming() { timing_end(c); }
+};
+
+// kernels (host launchers).  Every launcher enqueues on ctx->stream and returns hipGetLastError().
+hipError_t launch_preprocess(nfx_ctx *ctx, int64_t n, const uint32_t *ring_off, const float *ring_xy, float *centroids,
+                             float *centred);
+// rasterise (+ the mask-derived geometry columns when out != nullptr).  rows_out may be nullptr.
+hipError_t launch_raster_shape(nfx_ctx *ctx, int64_t n, const uint32_t *poly_off, const float *poly_xy, int ps,
+                               uint64_t *rows_out, float *out, int F, int col0);
+// geometry columns from existing mask rows (trait entry: masks are given, not rasterised)
+hipError_t launch_shape_from_rows(nfx_ctx *ctx, int64_t n, const uint64_t *rows, int ps, float *out, int F, int col0);
+// polygon-derived geometry columns; scratch: 3*total_vertices+2n+... doubles pairs (see k_geometry.hip)
+hipError_t launch_polygon(nfx_ctx *ctx, int64_t n, const uint32_t *poly_off, const float *poly_xy, void *scratch,
+                          float *out, int F, int col0);
+size_t polygon_scratch_bytes(int64_t n, int64_t total_vertices);
+hipError_t launch_pack_masks(nfx_ctx *ctx, int64_t n, const float *masks_f32, int ps, uint64_t *rows);
+hipError_t launch_unpack_masks(nfx_ctx *ctx, int64_t n, const uint64_t *rows, int ps, float *masks_f32);
+hipError_t launch_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids, const uint8_t *image, int64_t H,
+                                 int64_t W, int ps, uint8_t *patches);
+
+hipError_t launch_color(nfx_ctx *ctx, const Job &job, int col0, void *scratch);
+size_t color_scratch_bytes(const Job &job);
+hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0);
+hipError_t launch_glrlm(nfx_ctx *ctx, const Job &job, int col0);
+hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0);
+
+}  // namespace nfx

@@ -1,0 +1,75 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol include/nfx.h
+declares, and the registry reproduces the reference's names, column order and CLI expansion.
+No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(nfx):
+    hdr = open(os.path.join(ROOT, "include", "nfx.h")).read()
+    declared = set(re.findall(r"\b(nfx_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"nfx_ctx"}
+    assert declared == set(nfx.ABI_SYMBOLS), declared ^ set(nfx.ABI_SYMBOLS)
+    L = nfx.lib()
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert L.nfx_version() == 100
+
+
+def test_registry_names_and_counts(nfx):
+    assert nfx.lib().nfx_feature_set_count() == 5
+    # FeatureSet::name(): shape.rs:132-134, color.rs:104-106, texture.rs:169-171,312-314,371-373
+    assert [nfx.feature_set_name(s) for s in range(5)] == ["geometry", "color", "GLCM", "GLRLM", "gabor filter"]
+    assert [nfx.num_columns(s) for s in range(5)] == [12, 18, 224, 68, 96]
+    assert sum(nfx.num_columns(s) for s in range(5)) == 418
+    assert nfx.lib().nfx_feature_set_num_columns(7) == -1
+
+
+def test_column_names_follow_the_reference(nfx):
+    g = nfx.column_names(0)
+    assert g == ["area", "major_axis", "minor_axis", "eccentricity", "orientation", "perimeter", "equivalent_perimeter",
+                 "compacity", "eliptic_deviation", "convex_hull_area", "convex_deffect", "convex_perimeter"]   # shape.rs:113-128
+    c = nfx.column_names(1)
+    assert c[0] == "mean_r" and c[6] == "mean_h" and c[12] == "mean_haematoxylin" and c[17] == "std_dab"       # color.rs:80-99
+    t = nfx.column_names(2)
+    assert t[0] == "correlation_0_1_32" and t[13] == "information_measure_correlation2_0_1_32"                  # texture.rs:81-157
+    assert t[14] == "correlation_1_1_32" and t[3 * 14] == "correlation_1_-1_32" and t[-1] == "information_measure_correlation2_1_-1_254"
+    r = nfx.column_names(3)
+    assert r[0] == "short_run_emphasis_1_0" and r[16] == "run_length_variance_1_0" and r[-1] == "run_length_variance_-1_1"  # texture.rs:244-301
+    b = nfx.column_names(4)
+    assert b[0] == "gabor_angle_0_frequency_0.5_mean" and b[1] == "gabor_angle_0_frequency_0.5_variance"       # texture.rs:346-361
+    assert b[2] == "gabor_angle_0_frequency_1_mean" and b[12] == "gabor_angle_45_frequency_0.5_mean" and b[-1] == "gabor_angle_315_frequency_8_variance"
+    assert len(set(g + c + t + r + b)) == 418
+    assert nfx.all_column_names([0, 1])[0] == "centroid"
+
+
+def test_feature_set_cli_parsing(nfx):
+    # args.rs:18-49
+    assert nfx.parse_feature_sets(["geometry"]) == [0]
+    assert nfx.parse_feature_sets(["ALL"]) == [0, 1, 2, 3, 4]
+    assert nfx.parse_feature_sets(["Texture"]) == [2, 3, 4]
+    assert nfx.parse_feature_sets(["color", "all", "glcm"]) == [1, 0, 1, 2, 3, 4, 2]   # no de-dup, order kept
+    with pytest.raises(ValueError):
+        nfx.parse_feature_sets(["shape"])
+
+
+def test_centroid_keys_use_rust_f32_display(nfx):
+    # utils.rs:226-228, Rust Display for f32: shortest round-trip, positional, no trailing ".0"
+    assert nfx.centroid_key(100.0, 2047.96875) == "100,2047.9688"
+    assert nfx.centroid_key(0.1, -3.5) == "0.1,-3.5"
+    assert nfx.centroid_key(16777216.0, 1e-7) == "16777216,0.0000001"
+    assert nfx.centroid_key(float("nan"), 1.5) == "NaN,1.5"
+    assert nfx.centroids_to_key_strings([[1.25, 2.0]]) == ["1.25,2"]
+
+
+def test_no_cpu_fallback_without_gpu(nfx):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(nfx.NfxError):
+        nfx.Context(0)
