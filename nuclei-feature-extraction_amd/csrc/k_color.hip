@@ -1,0 +1,287 @@
+// k_color.hip -- the "color" feature set (masked RGB / HSV / HED statistics) on gfx950.
+//
+// Replaces (reference file:line):
+//   ColorFeatureSet::compute_features_batched   color.rs:11-102
+//   mean_std                                    color.rs:117-134
+//   circular_mean                               color.rs:144-155 (batch-coupled by its broadcast)
+//   tch_utils::color::{hsv_from_rgb,hed_from_rgb} call sites color.rs:45-46
+//
+// Two kernels:
+//   k_hue_batch  one lane per (reference batch, pixel): S = sum_j sin(hue_j), C = sum_j cos(hue_j)
+//                over every patch j of the batch.  This is the cheap form of the reference's
+//                [N,N,ps,ps] broadcast: nucleus i's circular mean is atan2(mask_i . S, mask_i . C).
+//   k_color      one wavefront per nucleus, lanes = columns of a mask row, only rows that hold mask
+//                pixels are visited.  Pass A dots the mask with S and C (-> mean_h); pass B streams
+//                the patch once, converts RGB->HSV/HED in registers and accumulates sum x and
+//                sum x^2 of nine channels in f64; the variance about the f32-rounded mean is then
+//                sum x^2 - 2 mu sum x + K mu^2 (the two-pass result of color.rs:123-128 without a
+//                second pass over the pixels).
+//   Blocks of one reference batch share blockIdx % 8, i.e. one XCD, so the batch's S/C images are
+//   served by that XCD's L2 to all of its nuclei.
+#include "nfx_internal.h"
+
+namespace nfx {
+
+template <typename T> struct Px;
+template <> struct Px<uint8_t> {
+    static __device__ __forceinline__ float ld(const uint8_t *p, size_t i) { return (float)p[i] / 255.0f; } // utils.rs:172
+};
+template <> struct Px<float> {
+    static __device__ __forceinline__ float ld(const float *p, size_t i) { return p[i]; }
+};
+
+static __device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Smith hexcone, H in degrees (DESIGN.md "colour transforms")
+static __device__ __forceinline__ void hsv_from_rgb(float r, float g, float b, float &h, float &s, float &v)
+{
+    const float mx = fmaxf(r, fmaxf(g, b));
+    const float mn = fminf(r, fminf(g, b));
+    const float d = mx - mn;
+    float hh;
+    if (d == 0.0f) hh = 0.0f;
+    else if (mx == r) { hh = (g - b) / d; if (hh < 0.0f) hh += 6.0f; } // |hh| <= 1: fmod(hh, 6) is the identity
+    else if (mx == g) hh = (b - r) / d + 2.0f;
+    else hh = (r - g) / d + 4.0f;
+    h = hh * 60.0f;
+    s = (mx == 0.0f) ? 0.0f : d / mx;
+    v = mx;
+}
+
+// optical density log(max(x,1e-6))/log(1e-6), evaluated in f64 and rounded (f32 inputs only;
+// u8 inputs use the 256-entry table built on the host with the same formula)
+static __device__ __forceinline__ float od_f32(float x)
+{
+    const float xc = x > 1e-6f ? x : 1e-6f;
+    return (float)(log((double)xc) / log(1e-6));
+}
+
+__constant__ float kHedFromRgb[3][3] = {
+    {1.87798273563385f, -1.0076786279678345f, -0.5561158061027527f},
+    {-0.06590805947780609f, 1.134730339050293f, -0.135521799325943f},
+    {-0.6019073724746704f, -0.48041418194770813f, 1.5735880136489868f},
+};
+
+static __device__ __forceinline__ void hed_from_od(float o0, float o1, float o2, float e[3])
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float s = o0 * kHedFromRgb[0][k];
+        s = s + o1 * kHedFromRgb[1][k];
+        s = s + o2 * kHedFromRgb[2][k];
+        e[k] = s > 0.0f ? s : 0.0f;
+    }
+}
+
+// ---- k_hue_batch ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_hue_batch(int64_t n, int ps, int batch_size, const T *__restrict__ patches,
+                                                   double *__restrict__ SC)
+{
+    const int P = ps * ps;
+    const int64_t b = blockIdx.y;
+    const int px = blockIdx.x * 256 + threadIdx.x;
+    if (px >= P) return;
+    const int64_t j0 = b * batch_size;
+    const int64_t j1 = (j0 + batch_size) < n ? (j0 + batch_size) : n;
+    const float deg2rad = (float)(3.14159265358979323846 / 180.0);
+    double S = 0.0, C = 0.0;
+    for (int64_t j = j0; j < j1; ++j) {
+        const T *p = patches + (size_t)j * 3 * P;
+        float h, s, v;
+        hsv_from_rgb(Px<T>::ld(p, px), Px<T>::ld(p, P + px), Px<T>::ld(p, 2 * P + px), h, s, v);
+        const float hr = h * deg2rad; // color.rs:147
+        S += (double)sinf(hr);
+        C += (double)cosf(hr);
+    }
+    SC[((size_t)b * 2 + 0) * P + px] = S;
+    SC[((size_t)b * 2 + 1) * P + px] = C;
+}
+
+// ---- k_color ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size, int64_t n_batches, int blocks_per_batch,
+                                               const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
+                                               const double *__restrict__ SC, const float *__restrict__ od_lut,
+                                               float *__restrict__ out, int F, int col0)
+{
+    __shared__ float s_od[256];
+    if (sizeof(T) == 1) {
+        s_od[threadIdx.x] = od_lut[threadIdx.x];
+        __syncthreads();
+    }
+    // XCD-aware block -> (batch, slot) map: every block of a batch has the same blockIdx % 8
+    const int64_t v = blockIdx.x;
+    const int64_t xcd = v & 7, slot = v >> 3;
+    const int64_t batch = (slot / blocks_per_batch) * 8 + xcd;
+    const int within = (int)(slot % blocks_per_batch);
+    if (batch >= n_batches) return;
+    const int lane = threadIdx.x & 63;
+    const int k_in_batch = within * 4 + (threadIdx.x >> 6);
+    const int64_t i = batch * batch_size + k_in_batch;
+    if (k_in_batch >= batch_size || i >= n) return; // wave-uniform
+
+    const int P = ps * ps;
+    const uint64_t myrow = lane < ps ? mask_rows[i * ps + lane] : 0ull;
+    const int rpi = ps <= 32 ? 2 : 1;          // rows per wave iteration
+    const int cw = ps <= 32 ? 32 : 64;         // lanes per row
+    const int c = lane & (cw - 1);
+    const int rsub = rpi == 2 ? (lane >> 5) : 0;
+    const uint64_t anyrow = __ballot(myrow != 0ull); // rows that hold mask pixels
+    const double *S = SC + (size_t)batch * 2 * P;
+    const double *Cc = S + P;
+
+    // pass A: K and the circular sums (color.rs:148-152)
+    int kcnt = 0;
+    double ss = 0.0, cc = 0.0;
+    for (int r0 = 0; r0 < ps; r0 += rpi) {
+        if (((anyrow >> r0) & (rpi == 2 ? 3ull : 1ull)) == 0ull) continue;
+        const int r = r0 + rsub;
+        const uint64_t w = __shfl(myrow, r & 63, 64);
+        if (r < ps && c < ps && ((w >> c) & 1ull)) {
+            const int p = r * ps + c;
+            kcnt += 1;
+            ss += S[p];
+            cc += Cc[p];
+        }
+    }
+    int K = kcnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) K += __shfl_xor(K, o, 64);
+    ss = wave_sum_f64(ss);
+    cc = wave_sum_f64(cc);
+    const float area = (float)K;
+    const float rad2deg = (float)(180.0 / 3.14159265358979323846);
+    const float sinm = (float)ss / area, cosm = (float)cc / area;
+    float mh = (float)atan2((double)sinm, (double)cosm);
+    mh = mh * rad2deg;
+    mh = mh + 360.0f;
+    mh = fmodf(mh, 360.0f); // color.rs:154
+
+    // pass B: sum x, sum x^2 of r g b h' s v he eo da
+    double s1[9], s2[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
+    const T *pp = patches + (size_t)i * 3 * P;
+    for (int r0 = 0; r0 < ps; r0 += rpi) {
+        if (((anyrow >> r0) & (rpi == 2 ? 3ull : 1ull)) == 0ull) continue;
+        const int r = r0 + rsub;
+        const uint64_t w = __shfl(myrow, r & 63, 64);
+        if (r < ps && c < ps && ((w >> c) & 1ull)) {
+            const int p = r * ps + c;
+            float x[9];
+            x[0] = Px<T>::ld(pp, p);
+            x[1] = Px<T>::ld(pp, P + p);
+            x[2] = Px<T>::ld(pp, 2 * P + p);
+            float h;
+            hsv_from_rgb(x[0], x[1], x[2], h, x[4], x[5]);
+            x[3] = h - mh; // color.rs:52
+            float o0, o1, o2;
+            if (sizeof(T) == 1) {
+                const uint8_t *pb = reinterpret_cast<const uint8_t *>(pp);
+                o0 = s_od[pb[p]]; o1 = s_od[pb[P + p]]; o2 = s_od[pb[2 * P + p]];
+            } else {
+                o0 = od_f32(x[0]); o1 = od_f32(x[1]); o2 = od_f32(x[2]);
+            }
+            hed_from_od(o0, o1, o2, &x[6]);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const double xd = (double)x[k];
+                s1[k] += xd;
+                s2[k] += xd * xd;
+            }
+        }
+    }
+    float mean[9], sd[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const double a = wave_sum_f64(s1[k]);
+        const double b = wave_sum_f64(s2[k]);
+        const float mu = (float)a / area;
+        const double mud = (double)mu;
+        double D = b - 2.0 * mud * a + (double)K * mud * mud; // sum (x-mu)^2 about the f32 mean
+        D = D > 0.0 ? D : (D == D ? 0.0 : D);                 // rounding can leave -1e-17; keep NaN
+        mean[k] = mu;
+        sd[k] = sqrtf((float)D / area);
+    }
+    if (lane == 0) {
+        float *o = out + i * (int64_t)F + col0; // column order color.rs:80-99
+        o[0] = mean[0]; o[1] = mean[1]; o[2] = mean[2];
+        o[3] = sd[0];   o[4] = sd[1];   o[5] = sd[2];
+        o[6] = mh;      o[7] = mean[4]; o[8] = mean[5];
+        o[9] = sd[3];   o[10] = sd[4];  o[11] = sd[5];
+        o[12] = mean[6]; o[13] = mean[7]; o[14] = mean[8];
+        o[15] = sd[6];  o[16] = sd[7];  o[17] = sd[8];
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+size_t color_scratch_bytes(const Job &job)
+{
+    const int64_t nb = job.batch_size > 0 ? (job.n + job.batch_size - 1) / job.batch_size : 0;
+    return sizeof(double) * 2 * (size_t)(nb > 0 ? nb : 1) * job.ps * job.ps + 256;
+}
+
+static hipError_t ensure_od_lut(nfx_ctx *ctx)
+{
+    if (ctx->od_lut) return hipSuccess;
+    float h[256];
+    for (int u = 0; u < 256; ++u) {
+        const float x = (float)u / 255.0f;
+        const float xc = x > 1e-6f ? x : 1e-6f;
+        h[u] = (float)(log((double)xc) / log(1e-6));
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->od_lut), sizeof(h));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(ctx->od_lut, h, sizeof(h), hipMemcpyHostToDevice);
+}
+
+hipError_t launch_color(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
+{
+    if (job.n == 0) return hipSuccess;
+    hipError_t e = ensure_od_lut(ctx);
+    if (e != hipSuccess) return e;
+    const int P = job.ps * job.ps;
+    const int64_t nb = (job.n + job.batch_size - 1) / job.batch_size;
+    double *SC = reinterpret_cast<double *>(scratch);
+    {
+        ScopedTiming t(ctx, KS_HUE_BATCH);
+        // gridDim.y is limited to 65535: walk the batches in slabs
+        for (int64_t b0 = 0; b0 < nb; b0 += 65535) {
+            const int64_t nbs = (nb - b0) < 65535 ? (nb - b0) : 65535;
+            const int64_t j0 = b0 * job.batch_size;
+            const int64_t nn = job.n - j0;
+            dim3 grid((unsigned)((P + 255) / 256), (unsigned)nbs);
+            if (job.patches_f32)
+                hipLaunchKernelGGL(k_hue_batch<float>, grid, dim3(256), 0, ctx->stream, nn, job.ps, job.batch_size,
+                                   reinterpret_cast<const float *>(job.patches) + (size_t)j0 * 3 * P, SC + (size_t)b0 * 2 * P);
+            else
+                hipLaunchKernelGGL(k_hue_batch<uint8_t>, grid, dim3(256), 0, ctx->stream, nn, job.ps, job.batch_size,
+                                   reinterpret_cast<const uint8_t *>(job.patches) + (size_t)j0 * 3 * P, SC + (size_t)b0 * 2 * P);
+        }
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    {
+        ScopedTiming t(ctx, KS_COLOR);
+        const int bpb = (job.batch_size + 3) / 4;
+        const int64_t nb8 = (nb + 7) / 8 * 8;
+        const int64_t blocks = nb8 * bpb;
+        if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
+        if (job.patches_f32)
+            hipLaunchKernelGGL(k_color<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
+                               reinterpret_cast<const float *>(job.patches), job.mask_rows, SC, ctx->od_lut, job.out, job.F, col0);
+        else
+            hipLaunchKernelGGL(k_color<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
+                               reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, SC, ctx->od_lut, job.out, job.F, col0);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+}  // namespace nfx

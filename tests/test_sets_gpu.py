@@ -1,0 +1,90 @@
+"""Parity of the pixel-consuming feature sets (HIP, through the C ABI) against the CPU oracle on the
+same seeded inputs: pipeline entry (u8 patches + raw rings) and trait entry (f32 patchs + f32 masks)."""
+import numpy as np
+import pytest
+
+import _oracle as orc
+import _parity as par
+
+pytestmark = pytest.mark.gpu
+
+SETS_READY = (0, 1, 2)   # grows as kernels land: geometry, color, glcm, glrlm, gabor
+
+
+@pytest.fixture(scope="module")
+def ctx(nfx):
+    c = nfx.Context(0)
+    yield c
+    c.close()
+
+
+def _inputs(ps, n, seed):
+    off, xy, pu8 = par.make_inputs(seed, n, ps)
+    e_off, e_xy = par.edge_case_rings(ps)
+    ne = len(e_off) - 1
+    off, xy = par.concat_rings((off, xy), (e_off, e_xy))
+    # edge-case nuclei get patches too (recycled)
+    pu8 = np.concatenate([pu8, pu8[:ne]])
+    return off, xy, pu8
+
+
+@pytest.mark.parametrize("set_id", [s for s in SETS_READY if s != 0])
+@pytest.mark.parametrize("ps,n,batch", [(32, 130, 100), (48, 70, 32), (64, 45, 100)])
+def test_pipeline_entry_matches_oracle(nfx, ctx, set_id, ps, n, batch):
+    off, xy, pu8 = _inputs(ps, n, seed=20 + set_id)
+    want, wcen = orc.extract([set_id], off, xy, pu8, ps, batch_size=batch)
+    got, gcen = ctx.extract([set_id], off, xy, pu8, ps, batch_size=batch)
+    assert np.array_equal(gcen, wcen, equal_nan=True)
+    par.assert_rows_close(got, want, par.column_scales(nfx, [set_id], ps), what=f"{nfx.feature_set_cli_name(set_id)} ps={ps}")
+
+
+@pytest.mark.parametrize("set_id", [s for s in SETS_READY if s != 0])
+def test_trait_entry_f32_matches_oracle(nfx, ctx, set_id):
+    ps, n = 48, 40
+    off, xy, pu8 = _inputs(ps, n, seed=40 + set_id)
+    n = len(off) - 1
+    cen, ctr = ctx.preprocess_polygons(off, xy)
+    masks = ctx.rasterize_polygons(off, ctr, ps)
+    # arbitrary f32 patch values (not k/255): the trait receives f32 tensors
+    rng = np.random.default_rng(5)
+    patchs = np.clip(pu8.astype(np.float32) / np.float32(255.0) + rng.uniform(-0.002, 0.002, pu8.shape).astype(np.float32), 0, 1).astype(np.float32)
+    patchs[0, :, :4, :4] = 0.0      # exercise max(rgb,1e-6) and v == 0
+    want = orc.compute_features_batched(set_id, off, ctr, patchs, masks[:, 0])
+    got = ctx.compute_features_batched(set_id, off, ctr, patchs, masks)
+    par.assert_rows_close(got, want, par.column_scales(nfx, [set_id], ps), what=f"trait {nfx.feature_set_cli_name(set_id)}")
+
+
+def test_all_ready_sets_concatenate_in_cli_order(nfx, ctx):
+    """main.rs:76-89: frames are concatenated in feature-set order; a repeated set is not de-duplicated."""
+    ps = 32
+    off, xy, pu8 = _inputs(ps, 60, seed=9)
+    sets = [s for s in [1, 0, 1, 2, 3, 4, 0] if s in SETS_READY]
+    want, _ = orc.extract(sets, off, xy, pu8, ps, batch_size=25)
+    got, _ = ctx.extract(sets, off, xy, pu8, ps, batch_size=25)
+    par.assert_rows_close(got, want, par.column_scales(nfx, sets, ps), what="concat")
+
+
+def test_batch_partition_is_part_of_the_result(nfx, ctx):
+    """color.rs:50-51,144-155: mean_h couples the nuclei of a batch -> a different batch size changes it."""
+    if 1 not in SETS_READY:
+        pytest.skip("color not built")
+    ps = 32
+    off, xy, pu8 = _inputs(ps, 64, seed=10)
+    a, _ = ctx.extract([1], off, xy, pu8, ps, batch_size=100)
+    b, _ = ctx.extract([1], off, xy, pu8, ps, batch_size=16)
+    valid = ~np.isnan(a[:, 6]) & ~np.isnan(b[:, 6])
+    assert np.abs(a[valid, 6] - b[valid, 6]).max() > 1e-3
+    np.testing.assert_array_equal(a[:, :6], b[:, :6])
+
+
+def test_device_memory_entry_equals_host_entry(nfx, ctx):
+    import torch
+    ps = 48
+    off, xy, pu8 = _inputs(ps, 200, seed=12)
+    sets = list(SETS_READY)
+    host, _ = ctx.extract(sets, off, xy, pu8, ps)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    dev, _ = ctx.extract(sets, torch.from_numpy(off.astype(np.int32)).cuda(), torch.from_numpy(xy).cuda(), torch.from_numpy(pu8).cuda(), ps)
+    torch.cuda.synchronize()
+    ctx.set_stream(0)
+    assert np.array_equal(dev.cpu().numpy(), host, equal_nan=True)
