@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- nuclei/sec of the per-nucleus feature path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--workload config3|config2|config5]
+
+A "step" is one pass of the hot path (polygon preprocessing + rasterisation + every selected feature
+set, rows gathered on rank 0) over one resident batch of synthetic nuclei.  Inputs are generated
+directly in HBM before the timed region (SURVEY.md §8d generator).  Scaling is weak: every rank holds
+its own index shard of `--nuclei` nuclei (shard boundaries are multiples of the reference batch size,
+SURVEY.md §8e), extracts it with no data-path collective, then the feature rows are gathered to rank 0
+over RCCL (the path's only exchange step, the reference's vstack under a mutex, main.rs:96-108).
+
+Default workload = BASELINE.json configs[2], the largest single-GPU configuration:
+1M nuclei, 48x48 patches, geometry+color+glcm (F=254), batch 100.
+
+The one JSON line also carries
+  roofline     -- the dominant kernel's algorithmic bytes / its average launch time (HIP events on the
+                  engine's stream, measured live in this process) against the HBM peak;
+  cpu_baseline -- the CPU oracle (oracle/nfx_oracle.c, a port of the reference's arithmetic, OpenMP
+                  over reference batches) timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "nuclei-feature-extraction_amd"
+
+WORKLOADS = {
+    # name: (nuclei per GPU, patch size, feature sets, BASELINE.json config it is)
+    "config2": (100_000, 32, ["geometry"], "configs[1]: 100k nuclei, 32x32, geometry"),
+    "config3": (1_000_000, 48, ["geometry", "color", "glcm"], "configs[2]: 1M nuclei, 48x48, geometry+color+glcm"),
+    "config5": (1_250_000, 64, ["all"], "configs[4] per-GPU shard: 1.25M nuclei, 64x64, all"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
+    ap.add_argument("--nuclei", type=int, default=0, help="nuclei per GPU (default: the workload's)")
+    ap.add_argument("--batch-size", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    nfx = importlib.import_module(PKG)
+    synth = importlib.import_module(PKG + ".synth")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_def, ps, set_names, wl_desc = WORKLOADS[args.workload]
+    n_local = args.nuclei or n_def
+    B = args.batch_size
+    n_local = max(B, (n_local // B) * B)          # shard boundary on a reference-batch boundary
+    sets = nfx.parse_feature_sets(set_names)
+    F = sum(nfx.num_columns(s) for s in sets)
+    cfg_idx = {"config2": 1, "config3": 2, "config5": 4}[args.workload]
+    seed = synth.SEED_BASE + cfg_idx
+
+    # ---- synthetic inputs, resident in HBM before the timed region ----------------------------------
+    i0 = rank * n_local
+    t0 = time.time()
+    off, xy = synth.polygons(seed, i0, n_local, ps)
+    d_off = torch.from_numpy(off.astype(np.int32)).to(dev)
+    d_xy = torch.from_numpy(xy).to(dev)
+    pixel_sets = any(s != nfx.GEOMETRY for s in sets)
+    d_patches = synth.patches(seed, i0, n_local, ps, xp=torch, device=dev) if pixel_sets else None
+    d_out = torch.empty((n_local, F), dtype=torch.float32, device=dev)
+    gather_list = [torch.empty((n_local, F), dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+
+    ctx = nfx.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+
+    def step():
+        ctx.extract(sets, d_off, d_xy, d_patches, ps, batch_size=B, out=d_out, want_centroids=False)
+        if world > 1:
+            dist.gather(d_out, gather_list, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.enable_timing(True)
+    ctx.reset_timing()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timing = ctx.kernel_timing()
+    ctx.enable_timing(False)
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    total_nuclei = n_local * world
+    value = total_nuclei * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (rank 0's events) -------------------------------------------
+    v_mean = float(len(xy)) / n_local
+    bytes_per_nucleus = (3 * ps * ps if pixel_sets else 0) + 8.0 * v_mean + 8 + 4 * F
+    dom = max(timing.items(), key=lambda kv: kv[1]["total_ms"])
+    dom_name, dom_t = dom
+    dom_avg_ms = dom_t["total_ms"] / max(1, dom_t["launches"])
+    launches_per_step = max(1, dom_t["launches"] // max(1, args.steps))
+    # a kernel launched once per step processes the rank's n_local nuclei per launch
+    achieved = bytes_per_nucleus * (n_local / launches_per_step) / (dom_avg_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "algorithmic_bytes_per_nucleus": round(bytes_per_nucleus, 1), "avg_launch_ms": round(dom_avg_ms, 4),
+                "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in timing.items() if v["launches"]}}
+
+    # ---- CPU baseline: the oracle port on a bounded sample, rank 0 at N=1 only --------------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle as orc      # checker / baseline only -- never on the product path
+        cores = os.cpu_count() or 1
+
+        def run_sample(m):
+            m = max(B, (m // B) * B)
+            m = min(m, n_local)
+            pu = d_patches[:m].cpu().numpy() if pixel_sets else np.zeros((m, 3, ps, ps), np.uint8)
+            so, sx = off[:m + 1], xy[:off[m]]
+            t = time.perf_counter()
+            rows, _ = orc.extract(sets, so, sx, pu, ps, batch_size=B, threads=cores)
+            return m, time.perf_counter() - t, rows
+
+        m0, dt0, _ = run_sample(max(B, cores * B))
+        rate0 = m0 / dt0
+        m1, dt1, rows = run_sample(int(rate0 * args.cpu_seconds))
+        # the sample doubles as an end-of-bench parity spot check of the resident result
+        got = d_out[:m1].cpu().numpy()
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _parity as par
+        par.assert_rows_close(got, rows, par.column_scales(nfx, sets, ps), what="bench sample vs oracle")
+        cpu = {"value": round(m1 / dt1, 1), "unit": "nuclei/s", "cores": cores, "kind": "port",
+               "sample": f"first {m1} nuclei of the same workload, oracle/nfx_oracle.c with OpenMP over reference batches ({cores} threads), {dt1:.1f} s"}
+
+    if rank == 0:
+        line = {
+            "metric": "nuclei/sec", "value": round(value, 1), "unit": "nuclei/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64 (u8 pixels, integer counts)", "data": "synthetic",
+            "config": {"workload": wl_desc, "nuclei_per_gpu": n_local, "patch_size": ps, "feature_sets": set_names,
+                       "columns": F, "batch_size": B, "sharding": f"index-sharded x{world}, rows gathered to rank 0 (RCCL)" if world > 1 else "single GPU",
+                       "inputs": "packed u8 patches + polygons resident in HBM", "gen_seconds": round(gen_s, 1)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

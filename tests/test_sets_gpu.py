@@ -8,7 +8,7 @@ import _parity as par
 
 pytestmark = pytest.mark.gpu
 
-SETS_READY = (0, 1, 2)   # grows as kernels land: geometry, color, glcm, glrlm, gabor
+SETS_READY = (0, 1, 2, 3, 4)   # grows as kernels land: geometry, color, glcm, glrlm, gabor
 
 
 @pytest.fixture(scope="module")
