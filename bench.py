@@ -147,7 +147,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import _oracle as orc      # checker / baseline only -- never on the product path
-        cores = os.cpu_count() or 1
+        # the GPU box grants 16 host cores per GPU (use NFX_CPU_THREADS to override)
+        cores = int(os.environ.get("NFX_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
 
         def run_sample(m):
             m = max(B, (m // B) * B)
