@@ -13,8 +13,11 @@
 // channels.  About 3 MFLOP per nucleus instead of 354.
 //
 // One 256-thread workgroup per nucleus (persistent): gray patch with a zero apron, and the two
-// row-pass planes U, W live in LDS (57 KB, two workgroups per CU); row passes cover only the
-// mask's column range and the rows within 15 of the mask; per-filter sums are f64.
+// row-pass planes U, W (with zero aprons, odd row stride) live in LDS (78 KB, two workgroups per CU).
+// Both passes are REGISTER-TILED: a thread loads a 37-value window once and produces 8 outputs
+// (480 FMAs per 37 LDS reads, filter taps in SGPRs); row passes cover only the mask's column range
+// and the rows within 15 of the mask; the 45/135-degree filter pairs share one column pass
+// (f+- = P1 -+ P2); per-filter sums are f64, reduced with DPP.
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -25,12 +28,16 @@ namespace nfx {
 
 static constexpr int GB_SIZE = 30, GB_PAD = 15, GB_THREADS = 256;
 static constexpr int GB_GW = NFX_MAX_PATCH_SIZE + GB_SIZE - 1; // gray row with apron: 93 floats
+static constexpr int GB_TS = 8;                                // outputs per thread in a strip
+static constexpr int GB_WIN = GB_TS + GB_SIZE - 1;             // 37 inputs feed 8 outputs
+static constexpr int GB_UW = NFX_MAX_PATCH_SIZE + 1;           // U/W row stride (odd: conflict-free both ways)
+static constexpr int GB_UH = NFX_MAX_PATCH_SIZE + GB_SIZE - 1 + GB_TS; // U/W rows incl. zero aprons: 101
 static constexpr int GB_MAX_GROUPS = 16, GB_MAX_FILTERS = 48;
 
 struct GaborGroup {
     float rc[GB_SIZE];
     float rs[GB_SIZE];
-    int has_w, first_filter, n_filters, pad;
+    int has_w, first_filter, n_filters, paired;
 };
 struct GaborFilter {
     float cc[GB_SIZE];
@@ -52,11 +59,36 @@ template <> struct BPx<float> {
     static __device__ __forceinline__ float ld(const float *p, size_t i) { return p[i]; }
 };
 
+// ---- DPP wave reduction (total valid in every lane via readlane 63) ------------------------------------
+template <int CTRL, int ROW_MASK>
+static __device__ __forceinline__ double gb_dpp(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 static __device__ __forceinline__ double bsum(double v)
 {
+    v += gb_dpp<0xB1, 0xF>(v);
+    v += gb_dpp<0x4E, 0xF>(v);
+    v += gb_dpp<0x141, 0xF>(v);
+    v += gb_dpp<0x140, 0xF>(v);
+    v += gb_dpp<0x142, 0xA>(v);
+    v += gb_dpp<0x143, 0xC>(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// 8 outputs of a 30-tap correlation from a 37-value register window
+static __device__ __forceinline__ void taps8(const float (&x)[GB_WIN], const float *__restrict__ w, float (&acc)[GB_TS])
+{
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    for (int o = 0; o < GB_TS; ++o) acc[o] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < GB_SIZE; ++j) {
+        const float wj = w[j]; // wave-uniform: scalar load
+#pragma unroll
+        for (int o = 0; o < GB_TS; ++o) acc[o] = fmaf(wj, x[o + j], acc[o]);
+    }
 }
 
 template <typename T>
@@ -65,16 +97,18 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
                                                          const GaborTables *__restrict__ tab, float *__restrict__ out,
                                                          int F, int col0)
 {
-    __shared__ float s_g[NFX_MAX_PATCH_SIZE * GB_GW];
-    __shared__ float s_U[NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE];
-    __shared__ float s_W[NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE];
-    __shared__ uint64_t s_rows[64];
-    __shared__ double s_part[4][GB_MAX_FILTERS][2];
+    __shared__ float s_g[NFX_MAX_PATCH_SIZE * GB_GW + 16];
+    __shared__ float s_U[GB_UH * GB_UW]; // row r lives at index r + GB_PAD; aprons stay zero
+    __shared__ float s_W[GB_UH * GB_UW];
+    __shared__ uint64_t s_rows[64 + GB_TS];
+    __shared__ double s_part[4][24][2];
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int P = ps * ps;
     const int gw = ps + GB_SIZE - 1;
-    for (int k = t; k < NFX_MAX_PATCH_SIZE * GB_GW; k += GB_THREADS) s_g[k] = 0.0f; // apron stays zero
+    for (int k = t; k < NFX_MAX_PATCH_SIZE * GB_GW + 16; k += GB_THREADS) s_g[k] = 0.0f; // apron stays zero
+    for (int k = t; k < GB_UH * GB_UW; k += GB_THREADS) { s_U[k] = 0.0f; s_W[k] = 0.0f; }
+    if (t < 64 + GB_TS) s_rows[t] = 0ull;
     __syncthreads();
     const int n_groups = tab->n_groups, n_filters = tab->n_filters;
 
@@ -105,63 +139,109 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
         const int ncol = cmax - cmin + 1;
         const int rlo = rmin - GB_PAD > 0 ? rmin - GB_PAD : 0;
         const int rhi = rmax + (GB_SIZE - 1 - GB_PAD) < ps - 1 ? rmax + (GB_SIZE - 1 - GB_PAD) : ps - 1;
-        const int nrow_rp = rhi - rlo + 1, nrow_cp = rmax - rmin + 1;
+        const int nrow_rp = rhi - rlo + 1;
+        const int nstrip_c = (ncol + GB_TS - 1) / GB_TS;              // column strips of the row pass
+        const int nstrip_r = (rmax - rmin + 1 + GB_TS - 1) / GB_TS;   // row strips of the column pass
 
         for (int g = 0; g < n_groups; ++g) {
             const GaborGroup &G = tab->groups[g];
             const bool has_w = G.has_w != 0;
-            // ---- row pass: U = gray (*) rc, W = gray (*) rs over rows [rlo,rhi], columns [cmin,cmax] ----
-            for (int k = t; k < nrow_rp * ncol; k += GB_THREADS) {
-                const int rr = k / ncol;
-                const int r = rlo + rr, c = cmin + (k - rr * ncol);
-                const float *src = &s_g[r * gw + c]; // gray column c-15 sits at apron index c
-                float u = 0.0f, w = 0.0f;
+            // ---- row pass: item = (row, strip of 8 columns); lanes run along rows (LDS stride gw, odd) ------
+            for (int k = t; k < nrow_rp * nstrip_c; k += GB_THREADS) {
+                const int st = k / nrow_rp;
+                const int r = rlo + (k - st * nrow_rp), c0 = cmin + st * GB_TS;
+                const float *src = &s_g[r * gw + c0]; // gray column c-15 sits at apron index c
+                float x[GB_WIN];
+#pragma unroll
+                for (int j = 0; j < GB_WIN; ++j) x[j] = src[j];
+                float acc[GB_TS];
+                taps8(x, G.rc, acc);
+                float *du = &s_U[(r + GB_PAD) * GB_UW + c0];
+#pragma unroll
+                for (int q = 0; q < GB_TS; ++q)
+                    if (c0 + q < ps) du[q] = acc[q];
                 if (has_w) {
+                    taps8(x, G.rs, acc);
+                    float *dw = &s_W[(r + GB_PAD) * GB_UW + c0];
 #pragma unroll
-                    for (int j = 0; j < GB_SIZE; ++j) {
-                        const float x = src[j];
-                        u = fmaf(G.rc[j], x, u);
-                        w = fmaf(G.rs[j], x, w);
-                    }
-                    s_W[r * ps + c] = w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < GB_SIZE; ++j) u = fmaf(G.rc[j], src[j], u);
+                    for (int q = 0; q < GB_TS; ++q)
+                        if (c0 + q < ps) dw[q] = acc[q];
                 }
-                s_U[r * ps + c] = u;
             }
             __syncthreads();
-            // ---- column passes at masked pixels ---------------------------------------------------------
-            for (int fi = 0; fi < G.n_filters; ++fi) {
-                const int f = G.first_filter + fi;
-                const GaborFilter &Fl = tab->filters[f];
-                const bool use_w = has_w && Fl.has_s != 0;
-                const float ws = Fl.wsign;
-                double s1 = 0.0, s2 = 0.0;
-                for (int k = t; k < nrow_cp * ncol; k += GB_THREADS) {
-                    const int rr = k / ncol;
-                    const int r = rmin + rr, c = cmin + (k - rr * ncol);
-                    if ((s_rows[r] >> c) & 1ull) {
-                        const int i0 = r - GB_PAD < 0 ? GB_PAD - r : 0;                       // first tap with r+i-15 >= 0
-                        const int i1 = r - GB_PAD + GB_SIZE > ps ? ps - (r - GB_PAD) : GB_SIZE; // one past the last tap
-                        float acc = 0.0f;
-                        if (use_w) {
-                            for (int ii = i0; ii < i1; ++ii) {
-                                const int q = (r + ii - GB_PAD) * ps + c;
-                                acc = fmaf(Fl.cc[ii], s_U[q], acc);
-                                acc = fmaf(-ws * Fl.cs[ii], s_W[q], acc);
-                            }
-                        } else {
-                            for (int ii = i0; ii < i1; ++ii) acc = fmaf(Fl.cc[ii], s_U[(r + ii - GB_PAD) * ps + c], acc);
+            // ---- column pass: item = (column, strip of 8 rows); lanes run along columns ---------------------
+            const int nf = G.n_filters;
+            double s1[6], s2[6];
+#pragma unroll
+            for (int f = 0; f < 6; ++f) { s1[f] = 0.0; s2[f] = 0.0; }
+            for (int k = t; k < ncol * nstrip_r; k += GB_THREADS) {
+                const int st = k / ncol;
+                const int c = cmin + (k - st * ncol), r0 = rmin + st * GB_TS;
+                unsigned mbits = 0; // mask bits of the 8 output pixels
+#pragma unroll
+                for (int q = 0; q < GB_TS; ++q) mbits |= (unsigned)((s_rows[r0 + q] >> c) & 1ull) << q;
+                if (mbits == 0u) continue;
+                float x[GB_WIN], acc[GB_TS];
+                const float *su = &s_U[r0 * GB_UW + c]; // row (r0 - 15) + 15
+#pragma unroll
+                for (int j = 0; j < GB_WIN; ++j) x[j] = su[j * GB_UW];
+                if (G.paired) { // two filters share cc, cs: f+ = P1 - P2, f- = P1 + P2
+                    const GaborFilter &Fl = tab->filters[G.first_filter];
+                    float p1[GB_TS], p2[GB_TS];
+                    taps8(x, Fl.cc, p1);
+                    const float *sw = &s_W[r0 * GB_UW + c];
+#pragma unroll
+                    for (int j = 0; j < GB_WIN; ++j) x[j] = sw[j * GB_UW];
+                    taps8(x, Fl.cs, p2);
+#pragma unroll
+                    for (int q = 0; q < GB_TS; ++q) {
+                        if ((mbits >> q) & 1u) {
+                            const double a = (double)(p1[q] - p2[q]), b = (double)(p1[q] + p2[q]);
+                            s1[0] += a; s2[0] += a * a;
+                            s1[1] += b; s2[1] += b * b;
                         }
-                        const double a = (double)acc;
-                        s1 += a;
-                        s2 += a * a;
+                    }
+                } else if (!has_w) { // A = 0: every filter of the group is a plain column pass over U
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) {
+                        if (f < nf) {
+                            taps8(x, tab->filters[G.first_filter + f].cc, acc);
+#pragma unroll
+                            for (int q = 0; q < GB_TS; ++q)
+                                if ((mbits >> q) & 1u) { const double a = (double)acc[q]; s1[f] += a; s2[f] += a * a; }
+                        }
+                    }
+                } else { // general: out = U (*) cc - wsign * W (*) cs
+                    float xw[GB_WIN];
+                    const float *sw = &s_W[r0 * GB_UW + c];
+#pragma unroll
+                    for (int j = 0; j < GB_WIN; ++j) xw[j] = sw[j * GB_UW];
+                    for (int f = 0; f < nf && f < 6; ++f) {
+                        const GaborFilter &Fl = tab->filters[G.first_filter + f];
+                        float p2[GB_TS];
+                        taps8(x, Fl.cc, acc);
+                        if (Fl.has_s) {
+                            taps8(xw, Fl.cs, p2);
+#pragma unroll
+                            for (int q = 0; q < GB_TS; ++q) acc[q] = acc[q] - Fl.wsign * p2[q];
+                        }
+#pragma unroll
+                        for (int q = 0; q < GB_TS; ++q)
+                            if ((mbits >> q) & 1u) {
+                                const double a = (double)acc[q];
+                                if (f == 0) { s1[0] += a; s2[0] += a * a; } else if (f == 1) { s1[1] += a; s2[1] += a * a; }
+                                else if (f == 2) { s1[2] += a; s2[2] += a * a; } else if (f == 3) { s1[3] += a; s2[3] += a * a; }
+                                else if (f == 4) { s1[4] += a; s2[4] += a * a; } else { s1[5] += a; s2[5] += a * a; }
+                            }
                     }
                 }
-                s1 = bsum(s1);
-                s2 = bsum(s2);
-                if (lane == 0) { s_part[wv][f][0] = s1; s_part[wv][f][1] = s2; }
+            }
+#pragma unroll
+            for (int f = 0; f < 6; ++f) {
+                if (f < nf) {
+                    const double a = bsum(s1[f]), b = bsum(s2[f]);
+                    if (lane == 0) { s_part[wv][G.first_filter + f][0] = a; s_part[wv][G.first_filter + f][1] = b; }
+                }
             }
             __syncthreads();
         }
@@ -245,6 +325,14 @@ static void build_tables(GaborTables &T)
             Fl.has_s = u.B != 0.0;
         }
         G.n_filters = nf - G.first_filter;
+        // two filters with the same column kernels and opposite sin sign (45 / 135 degrees) share one pass
+        G.paired = 0;
+        if (G.n_filters == 2 && G.has_w) {
+            const GaborFilter &f0 = T.filters[G.first_filter], &f1 = T.filters[G.first_filter + 1];
+            bool same = f0.has_s && f1.has_s && f0.wsign == 1.0f && f1.wsign == -1.0f;
+            for (int k = 0; k < GB_SIZE && same; ++k) same = f0.cc[k] == f1.cc[k] && f0.cs[k] == f1.cs[k];
+            G.paired = same ? 1 : 0;
+        }
     }
     T.n_filters = nf;
 }
@@ -254,7 +342,9 @@ static hipError_t ensure_tables(nfx_ctx *ctx)
     if (ctx->gabor_tab) return hipSuccess;
     static GaborTables T;
     build_tables(T);
-    if (T.n_groups > GB_MAX_GROUPS || T.n_filters > GB_MAX_FILTERS) return hipErrorInvalidValue;
+    if (T.n_groups > GB_MAX_GROUPS || T.n_filters > 24) return hipErrorInvalidValue;
+    for (int g = 0; g < T.n_groups; ++g)
+        if (T.groups[g].n_filters > 6) return hipErrorInvalidValue;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->gabor_tab), sizeof(GaborTables));
     if (e != hipSuccess) return e;
     return hipMemcpy(ctx->gabor_tab, &T, sizeof(GaborTables), hipMemcpyHostToDevice);
