@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--nuclei", type=int, default=0, help="nuclei per GPU (default: the workload's)")
     ap.add_argument("--batch-size", type=int, default=100)
+    ap.add_argument("--sets", default="", help="override the workload's feature sets (comma separated; experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
@@ -72,6 +73,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     n_def, ps, set_names, wl_desc = WORKLOADS[args.workload]
+    if args.sets:
+        set_names = args.sets.split(",")
+        wl_desc += f" [feature sets overridden: {args.sets}]"
     n_local = args.nuclei or n_def
     B = args.batch_size
     n_local = max(B, (n_local // B) * B)          # shard boundary on a reference-batch boundary

@@ -14,11 +14,14 @@
 //
 // One 256-thread workgroup per nucleus (persistent): gray patch with a zero apron, and the two
 // row-pass planes U, W (with zero aprons, odd row stride) live in LDS (78 KB, two workgroups per CU).
-// Both passes are REGISTER-TILED: a thread loads a 37-value window once and produces 8 outputs
-// (480 FMAs per 37 LDS reads, filter taps in SGPRs); row passes cover only the mask's column range
-// and the rows within 15 of the mask; the 45/135-degree filter pairs share one column pass
-// (f+- = P1 -+ P2); per-filter sums are f64, reduced with DPP.
+// Both passes are REGISTER-TILED and WAVE-STRIPED: wave w owns strip w (8, 12 or 16 outputs wide, chosen per
+// nucleus from the mask's bounding box so that four strips cover it); a lane loads a (TS+29)-value window once
+// and produces TS outputs, the 30 taps arrive as LDS broadcasts from a double-buffered per-group table.  Every
+// pass is exactly one round for every wave.  Row passes cover only the mask's column range and the rows within
+// 15 of the mask; the 45/135-degree filter pairs share one column pass (f+- = P1 -+ P2); per-strip sums are f32
+// about a per-filter shift (DC gain x mean masked gray), accumulated in f64 and reduced with DPP.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -28,11 +31,11 @@ namespace nfx {
 
 static constexpr int GB_SIZE = 30, GB_PAD = 15, GB_THREADS = 256;
 static constexpr int GB_GW = NFX_MAX_PATCH_SIZE + GB_SIZE - 1; // gray row with apron: 93 floats
-static constexpr int GB_TS = 8;                                // outputs per thread in a strip
-static constexpr int GB_WIN = GB_TS + GB_SIZE - 1;             // 37 inputs feed 8 outputs
 static constexpr int GB_UW = NFX_MAX_PATCH_SIZE + 1;           // U/W row stride (odd: conflict-free both ways)
-static constexpr int GB_UH = NFX_MAX_PATCH_SIZE + GB_SIZE - 1 + GB_TS; // U/W rows incl. zero aprons: 101
+static constexpr int GB_UH = NFX_MAX_PATCH_SIZE + GB_SIZE - 1; // U/W rows incl. zero aprons: 93
 static constexpr int GB_MAX_GROUPS = 16, GB_MAX_FILTERS = 48;
+static constexpr int GB_WSLOT = 32;                            // one 30-tap kernel padded to 32 floats
+static constexpr int GB_WBUF = GB_WSLOT * 14;                  // rc, rs + up to 6 x (cc, cs)
 
 struct GaborGroup {
     float rc[GB_SIZE];
@@ -44,6 +47,7 @@ struct GaborFilter {
     float cs[GB_SIZE];
     float wsign;
     int ch0, ch1, has_s;
+    float dc; // sum of the 2-D kernel: response to a constant image of 1
 };
 struct GaborTables {
     int n_groups, n_filters, pad0, pad1;
@@ -59,7 +63,7 @@ template <> struct BPx<float> {
     static __device__ __forceinline__ float ld(const float *p, size_t i) { return p[i]; }
 };
 
-// ---- DPP wave reduction (total valid in every lane via readlane 63) ------------------------------------
+// ---- DPP wave reduction; the total is returned in every lane -------------------------------------------
 template <int CTRL, int ROW_MASK>
 static __device__ __forceinline__ double gb_dpp(double v)
 {
@@ -78,16 +82,142 @@ static __device__ __forceinline__ double bsum(double v)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
-// 8 outputs of a 30-tap correlation from a 37-value register window
-static __device__ __forceinline__ void taps8(const float (&x)[GB_WIN], const float *__restrict__ w, float (&acc)[GB_TS])
+// TS outputs of a 30-tap correlation from a (TS+29)-value register window; taps come from LDS
+// (every lane reads the same address: a broadcast, one LDS cycle per ds_read_b128)
+template <int TS>
+static __device__ __forceinline__ void taps(const float (&x)[TS + GB_SIZE - 1], const float *w, float (&acc)[TS])
 {
+    float wr[GB_WSLOT];
 #pragma unroll
-    for (int o = 0; o < GB_TS; ++o) acc[o] = 0.0f;
+    for (int j = 0; j < GB_WSLOT; j += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(w + j);
+        wr[j] = v.x; wr[j + 1] = v.y; wr[j + 2] = v.z; wr[j + 3] = v.w;
+    }
 #pragma unroll
-    for (int j = 0; j < GB_SIZE; ++j) {
-        const float wj = w[j]; // wave-uniform: scalar load
+    for (int o = 0; o < TS; ++o) acc[o] = 0.0f;
 #pragma unroll
-        for (int o = 0; o < GB_TS; ++o) acc[o] = fmaf(wj, x[o + j], acc[o]);
+    for (int j = 0; j < GB_SIZE; ++j)
+#pragma unroll
+        for (int o = 0; o < TS; ++o) acc[o] = fmaf(wr[j], x[o + j], acc[o]);
+}
+
+// masked, shifted partial sums of one strip's TS outputs (f32 inside the strip, f64 across strips)
+template <int TS>
+static __device__ __forceinline__ void accumulate(const float (&v)[TS], unsigned mbits, float shift, double &s1, double &s2)
+{
+    float a = 0.0f, b = 0.0f;
+#pragma unroll
+    for (int q = 0; q < TS; ++q) {
+        const float d = ((mbits >> q) & 1u) ? v[q] - shift : 0.0f;
+        a += d;
+        b = fmaf(d, d, b);
+    }
+    s1 += (double)a;
+    s2 += (double)b;
+}
+
+struct GaborShared {
+    float *g, *U, *W;
+    const float *wt; // current group's taps: [rc | rs | cc0 | cs0 | cc1 | cs1 | ...] x 32 floats
+    const uint64_t *rows;
+};
+
+// One group (one row pass + its column passes) with strip size TS: wave w owns column strip w of the row pass
+// and row strip w of the column pass, so each pass is exactly one round for every wave.
+template <int TS>
+static __device__ __forceinline__ void gabor_group(const GaborShared &S, const GaborTables *__restrict__ tab, int g, int ps,
+                                                   int gw, int rlo, int nrow_rp, int rmin, int rmax, int cmin, int cmax,
+                                                   float mu_gray, int lane, int wv, double (&s1)[6], double (&s2)[6], int dbg)
+{
+    constexpr int WIN = TS + GB_SIZE - 1;
+    const GaborGroup &G = tab->groups[g];
+    const bool has_w = G.has_w != 0;
+    // ---- row pass: lanes run along rows (LDS stride gw, odd), the wave's strip along columns ----------------
+    {
+        const int c0 = cmin + wv * TS;
+        if (c0 <= cmax && lane < nrow_rp && !(dbg & 1)) {
+            const int r = rlo + lane;
+            int c0c = c0 < ps - TS ? c0 : ps - TS; // keep the window inside the apron row
+            c0c = c0c > 0 ? c0c : 0;
+            const float *src = &S.g[r * gw + c0c]; // gray column c-15 sits at apron index c
+            float x[WIN], acc[TS];
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) x[j] = src[j];
+            taps<TS>(x, S.wt, acc);
+            float *du = &S.U[(r + GB_PAD) * GB_UW + c0c];
+#pragma unroll
+            for (int q = 0; q < TS; ++q)
+                if (c0c + q < ps) du[q] = acc[q];
+            if (has_w) {
+                taps<TS>(x, S.wt + GB_WSLOT, acc);
+                float *dw = &S.W[(r + GB_PAD) * GB_UW + c0c];
+#pragma unroll
+                for (int q = 0; q < TS; ++q)
+                    if (c0c + q < ps) dw[q] = acc[q];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- column pass: lanes run along columns, the wave's strip along rows ------------------------------------
+    {
+        const int r0 = rmin + wv * TS;
+        const int c = cmin + lane;
+        if (r0 <= rmax && c <= cmax && !(dbg & 2)) {
+            int r0c = r0 < ps - TS ? r0 : ps - TS; // clamped strips overlap: rows below r0 are masked out
+            r0c = r0c > 0 ? r0c : 0;
+            unsigned mbits = 0;
+#pragma unroll
+            for (int q = 0; q < TS; ++q)
+                if (r0c + q >= r0) mbits |= (unsigned)((S.rows[r0c + q] >> c) & 1ull) << q;
+            if (mbits != 0u) {
+                const int nf = G.n_filters;
+                float x[WIN], acc[TS];
+                const float *su = &S.U[r0c * GB_UW + c]; // row (r0c - 15) + 15
+#pragma unroll
+                for (int j = 0; j < WIN; ++j) x[j] = su[j * GB_UW];
+                if (G.paired) { // two filters share cc, cs: f+ = P1 - P2, f- = P1 + P2
+                    float p2[TS], v[TS];
+                    taps<TS>(x, S.wt + 2 * GB_WSLOT, acc);
+                    const float *sw = &S.W[r0c * GB_UW + c];
+#pragma unroll
+                    for (int j = 0; j < WIN; ++j) x[j] = sw[j * GB_UW];
+                    taps<TS>(x, S.wt + 3 * GB_WSLOT, p2);
+#pragma unroll
+                    for (int q = 0; q < TS; ++q) v[q] = acc[q] - p2[q];
+                    accumulate<TS>(v, mbits, tab->filters[G.first_filter].dc * mu_gray, s1[0], s2[0]);
+#pragma unroll
+                    for (int q = 0; q < TS; ++q) v[q] = acc[q] + p2[q];
+                    accumulate<TS>(v, mbits, tab->filters[G.first_filter + 1].dc * mu_gray, s1[1], s2[1]);
+                } else if (!has_w) { // A = 0: every filter of the group is a plain column pass over U
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) {
+                        if (f < nf) {
+                            taps<TS>(x, S.wt + (2 + 2 * f) * GB_WSLOT, acc);
+                            accumulate<TS>(acc, mbits, tab->filters[G.first_filter + f].dc * mu_gray, s1[f], s2[f]);
+                        }
+                    }
+                } else { // general: out = U (*) cc - wsign * W (*) cs
+                    float xw[WIN], p2[TS];
+                    const float *sw = &S.W[r0c * GB_UW + c];
+#pragma unroll
+                    for (int j = 0; j < WIN; ++j) xw[j] = sw[j * GB_UW];
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) {
+                        if (f < nf) {
+                            const GaborFilter &Fl = tab->filters[G.first_filter + f];
+                            taps<TS>(x, S.wt + (2 + 2 * f) * GB_WSLOT, acc);
+                            if (Fl.has_s) {
+                                taps<TS>(xw, S.wt + (3 + 2 * f) * GB_WSLOT, p2);
+                                const float ws = Fl.wsign;
+#pragma unroll
+                                for (int q = 0; q < TS; ++q) acc[q] = acc[q] - ws * p2[q];
+                            }
+                            accumulate<TS>(acc, mbits, Fl.dc * mu_gray, s1[f], s2[f]);
+                        }
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -95,33 +225,48 @@ template <typename T>
 __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, const T *__restrict__ patches,
                                                          const uint64_t *__restrict__ mask_rows,
                                                          const GaborTables *__restrict__ tab, float *__restrict__ out,
-                                                         int F, int col0)
+                                                         int F, int col0, int dbg)
 {
+    __shared__ __attribute__((aligned(16))) float s_wt[2][GB_WBUF];
     __shared__ float s_g[NFX_MAX_PATCH_SIZE * GB_GW + 16];
     __shared__ float s_U[GB_UH * GB_UW]; // row r lives at index r + GB_PAD; aprons stay zero
     __shared__ float s_W[GB_UH * GB_UW];
-    __shared__ uint64_t s_rows[64 + GB_TS];
+    __shared__ uint64_t s_rows[64 + 16];
     __shared__ double s_part[4][24][2];
+    __shared__ float s_gsum[4];
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int P = ps * ps;
     const int gw = ps + GB_SIZE - 1;
     for (int k = t; k < NFX_MAX_PATCH_SIZE * GB_GW + 16; k += GB_THREADS) s_g[k] = 0.0f; // apron stays zero
     for (int k = t; k < GB_UH * GB_UW; k += GB_THREADS) { s_U[k] = 0.0f; s_W[k] = 0.0f; }
-    if (t < 64 + GB_TS) s_rows[t] = 0ull;
+    for (int k = t; k < 2 * GB_WBUF; k += GB_THREADS) (&s_wt[0][0])[k] = 0.0f;
+    if (t < 64 + 16) s_rows[t] = 0ull;
     __syncthreads();
     const int n_groups = tab->n_groups, n_filters = tab->n_filters;
+    GaborShared S;
+    S.g = s_g; S.U = s_U; S.W = s_W; S.rows = s_rows;
 
     for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
         if (t < 64) s_rows[t] = t < ps ? mask_rows[i * ps + t] : 0ull;
-        const T *pp = patches + (size_t)i * 3 * P;
-        for (int p = t; p < P; p += GB_THREADS) {
-            const int r = p / ps, c = p - r * ps;
-            float gs = BPx<T>::ld(pp, p) + BPx<T>::ld(pp, P + p);
-            gs = gs + BPx<T>::ld(pp, 2 * P + p);
-            s_g[r * gw + c + GB_PAD] = gs / 3.0f; // texture.rs:332
-        }
         __syncthreads();
+        const T *pp = patches + (size_t)i * 3 * P;
+        float gsum = 0.0f; // masked gray sum -> the shift that keeps the f32 partial sums well conditioned
+        {
+            int r = t / ps, c = t - r * ps;
+            const int dr = GB_THREADS / ps, dc = GB_THREADS - dr * ps;
+            for (int p = t; p < P; p += GB_THREADS) {
+                float gs = BPx<T>::ld(pp, p) + BPx<T>::ld(pp, P + p);
+                gs = gs + BPx<T>::ld(pp, 2 * P + p);
+                gs = gs / 3.0f; // texture.rs:332
+                s_g[r * gw + c + GB_PAD] = gs;
+                if ((s_rows[r] >> c) & 1ull) gsum += gs;
+                c += dc; r += dr;
+                if (c >= ps) { c -= ps; r += 1; }
+            }
+        }
+        gsum = (float)bsum((double)gsum);
+        if (lane == 0) s_gsum[wv] = gsum;
         // mask bounding box and area
         uint64_t orr = 0;
         int rmin = ps, rmax = -1, area = 0;
@@ -136,124 +281,57 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
             continue;
         }
         const int cmin = __ffsll((long long)orr) - 1, cmax = 63 - __clzll((long long)orr);
-        const int ncol = cmax - cmin + 1;
+        const int ncol = cmax - cmin + 1, nrow = rmax - rmin + 1;
         const int rlo = rmin - GB_PAD > 0 ? rmin - GB_PAD : 0;
         const int rhi = rmax + (GB_SIZE - 1 - GB_PAD) < ps - 1 ? rmax + (GB_SIZE - 1 - GB_PAD) : ps - 1;
         const int nrow_rp = rhi - rlo + 1;
-        const int nstrip_c = (ncol + GB_TS - 1) / GB_TS;              // column strips of the row pass
-        const int nstrip_r = (rmax - rmin + 1 + GB_TS - 1) / GB_TS;   // row strips of the column pass
-
-        for (int g = 0; g < n_groups; ++g) {
+        const int span = ncol > nrow ? ncol : nrow;   // both passes use the same strip size
+        // group 0's taps -> buffer 0 (the barrier inside the first gabor_group call is too late for the row pass,
+        // so this load is followed by its own barrier, which also publishes s_g and s_gsum)
+        for (int g = 0; g < ((dbg & 4) ? 0 : n_groups); ++g) {
             const GaborGroup &G = tab->groups[g];
-            const bool has_w = G.has_w != 0;
-            // ---- row pass: item = (row, strip of 8 columns); lanes run along rows (LDS stride gw, odd) ------
-            for (int k = t; k < nrow_rp * nstrip_c; k += GB_THREADS) {
-                const int st = k / nrow_rp;
-                const int r = rlo + (k - st * nrow_rp), c0 = cmin + st * GB_TS;
-                const float *src = &s_g[r * gw + c0]; // gray column c-15 sits at apron index c
-                float x[GB_WIN];
-#pragma unroll
-                for (int j = 0; j < GB_WIN; ++j) x[j] = src[j];
-                float acc[GB_TS];
-                taps8(x, G.rc, acc);
-                float *du = &s_U[(r + GB_PAD) * GB_UW + c0];
-#pragma unroll
-                for (int q = 0; q < GB_TS; ++q)
-                    if (c0 + q < ps) du[q] = acc[q];
-                if (has_w) {
-                    taps8(x, G.rs, acc);
-                    float *dw = &s_W[(r + GB_PAD) * GB_UW + c0];
-#pragma unroll
-                    for (int q = 0; q < GB_TS; ++q)
-                        if (c0 + q < ps) dw[q] = acc[q];
+            float *wt = s_wt[g & 1];
+            for (int k = t; k < (2 + 2 * G.n_filters) * GB_SIZE; k += GB_THREADS) {
+                const int slot = k / GB_SIZE, j = k - slot * GB_SIZE;
+                float v;
+                if (slot == 0) v = G.rc[j];
+                else if (slot == 1) v = G.rs[j];
+                else {
+                    const GaborFilter &Fl = tab->filters[G.first_filter + ((slot - 2) >> 1)];
+                    v = (slot & 1) ? Fl.cs[j] : Fl.cc[j];
                 }
+                wt[slot * GB_WSLOT + j] = v;
             }
-            __syncthreads();
-            // ---- column pass: item = (column, strip of 8 rows); lanes run along columns ---------------------
-            const int nf = G.n_filters;
+            __syncthreads(); // taps visible; every wave has left the previous group's column pass (U/W reusable)
+            const float mu_gray = (s_gsum[0] + s_gsum[1] + s_gsum[2] + s_gsum[3]) / (float)area;
+            S.wt = wt;
             double s1[6], s2[6];
 #pragma unroll
             for (int f = 0; f < 6; ++f) { s1[f] = 0.0; s2[f] = 0.0; }
-            for (int k = t; k < ncol * nstrip_r; k += GB_THREADS) {
-                const int st = k / ncol;
-                const int c = cmin + (k - st * ncol), r0 = rmin + st * GB_TS;
-                unsigned mbits = 0; // mask bits of the 8 output pixels
-#pragma unroll
-                for (int q = 0; q < GB_TS; ++q) mbits |= (unsigned)((s_rows[r0 + q] >> c) & 1ull) << q;
-                if (mbits == 0u) continue;
-                float x[GB_WIN], acc[GB_TS];
-                const float *su = &s_U[r0 * GB_UW + c]; // row (r0 - 15) + 15
-#pragma unroll
-                for (int j = 0; j < GB_WIN; ++j) x[j] = su[j * GB_UW];
-                if (G.paired) { // two filters share cc, cs: f+ = P1 - P2, f- = P1 + P2
-                    const GaborFilter &Fl = tab->filters[G.first_filter];
-                    float p1[GB_TS], p2[GB_TS];
-                    taps8(x, Fl.cc, p1);
-                    const float *sw = &s_W[r0 * GB_UW + c];
-#pragma unroll
-                    for (int j = 0; j < GB_WIN; ++j) x[j] = sw[j * GB_UW];
-                    taps8(x, Fl.cs, p2);
-#pragma unroll
-                    for (int q = 0; q < GB_TS; ++q) {
-                        if ((mbits >> q) & 1u) {
-                            const double a = (double)(p1[q] - p2[q]), b = (double)(p1[q] + p2[q]);
-                            s1[0] += a; s2[0] += a * a;
-                            s1[1] += b; s2[1] += b * b;
-                        }
-                    }
-                } else if (!has_w) { // A = 0: every filter of the group is a plain column pass over U
-#pragma unroll
-                    for (int f = 0; f < 6; ++f) {
-                        if (f < nf) {
-                            taps8(x, tab->filters[G.first_filter + f].cc, acc);
-#pragma unroll
-                            for (int q = 0; q < GB_TS; ++q)
-                                if ((mbits >> q) & 1u) { const double a = (double)acc[q]; s1[f] += a; s2[f] += a * a; }
-                        }
-                    }
-                } else { // general: out = U (*) cc - wsign * W (*) cs
-                    float xw[GB_WIN];
-                    const float *sw = &s_W[r0 * GB_UW + c];
-#pragma unroll
-                    for (int j = 0; j < GB_WIN; ++j) xw[j] = sw[j * GB_UW];
-                    for (int f = 0; f < nf && f < 6; ++f) {
-                        const GaborFilter &Fl = tab->filters[G.first_filter + f];
-                        float p2[GB_TS];
-                        taps8(x, Fl.cc, acc);
-                        if (Fl.has_s) {
-                            taps8(xw, Fl.cs, p2);
-#pragma unroll
-                            for (int q = 0; q < GB_TS; ++q) acc[q] = acc[q] - Fl.wsign * p2[q];
-                        }
-#pragma unroll
-                        for (int q = 0; q < GB_TS; ++q)
-                            if ((mbits >> q) & 1u) {
-                                const double a = (double)acc[q];
-                                if (f == 0) { s1[0] += a; s2[0] += a * a; } else if (f == 1) { s1[1] += a; s2[1] += a * a; }
-                                else if (f == 2) { s1[2] += a; s2[2] += a * a; } else if (f == 3) { s1[3] += a; s2[3] += a * a; }
-                                else if (f == 4) { s1[4] += a; s2[4] += a * a; } else { s1[5] += a; s2[5] += a * a; }
-                            }
-                    }
-                }
-            }
+            if (span <= 32) gabor_group<8>(S, tab, g, ps, gw, rlo, nrow_rp, rmin, rmax, cmin, cmax, mu_gray, lane, wv, s1, s2, dbg);
+            else if (span <= 48) gabor_group<12>(S, tab, g, ps, gw, rlo, nrow_rp, rmin, rmax, cmin, cmax, mu_gray, lane, wv, s1, s2, dbg);
+            else gabor_group<16>(S, tab, g, ps, gw, rlo, nrow_rp, rmin, rmax, cmin, cmax, mu_gray, lane, wv, s1, s2, dbg);
 #pragma unroll
             for (int f = 0; f < 6; ++f) {
-                if (f < nf) {
+                if (f < G.n_filters) {
                     const double a = bsum(s1[f]), b = bsum(s2[f]);
                     if (lane == 0) { s_part[wv][G.first_filter + f][0] = a; s_part[wv][G.first_filter + f][1] = b; }
                 }
             }
-            __syncthreads();
         }
-        // ---- mean / variance (texture.rs:339-344): var = sum f^2/K - mean^2 ---------------------------------
+        __syncthreads();
+        // ---- mean / variance (texture.rs:339-344) from the shifted sums: mean = c + s1/K, var = s2/K - (s1/K)^2 -----
         if (t < n_filters) {
             const GaborFilter &Fl = tab->filters[t];
             const double K = (double)area;
+            const float mu_gray = (s_gsum[0] + s_gsum[1] + s_gsum[2] + s_gsum[3]) / (float)area;
+            const double shift = (double)(Fl.dc * mu_gray);
             const double a = s_part[0][t][0] + s_part[1][t][0] + s_part[2][t][0] + s_part[3][t][0];
             const double b = s_part[0][t][1] + s_part[1][t][1] + s_part[2][t][1] + s_part[3][t][1];
-            const double mean = a / K;
-            double var = b / K - mean * mean;
+            const double m1 = a / K;
+            double var = b / K - m1 * m1;
             var = var > 0.0 ? var : 0.0;
+            const double mean = shift + m1;
             if (Fl.ch0 >= 0) { o[2 * Fl.ch0] = (float)mean; o[2 * Fl.ch0 + 1] = (float)var; }
             if (Fl.ch1 >= 0) { o[2 * Fl.ch1] = (float)mean; o[2 * Fl.ch1 + 1] = (float)var; }
         }
@@ -321,6 +399,12 @@ static void build_tables(GaborTables &T)
                 Fl.cs[k] = (float)(env(tk(k)) * sin(u.B * tk(k)));
             }
             Fl.wsign = u.A < 0.0 ? -1.0f : 1.0f; // sin(Ax) = sign(A) sin(|A|x)
+            {   // DC gain: sum_ij G(x_j)G(y_i) cos(A x_j + B y_i)
+                double dc = 0.0;
+                for (int ii = 0; ii < GB_SIZE; ++ii)
+                    for (int jj = 0; jj < GB_SIZE; ++jj) dc += env(tk(ii)) * env(tk(jj)) * cos(u.A * tk(jj) + u.B * tk(ii));
+                Fl.dc = (float)dc;
+            }
             Fl.ch0 = u.ch0; Fl.ch1 = u.ch1;
             Fl.has_s = u.B != 0.0;
         }
@@ -359,12 +443,14 @@ hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0)
     const int64_t maxb = 256 * 2 * 2;
     const unsigned grid = (unsigned)(job.n < maxb ? job.n : maxb);
     const GaborTables *tab = reinterpret_cast<const GaborTables *>(ctx->gabor_tab);
+    const char *dbg_env = getenv("NFX_GABOR_DBG"); // timing experiments only: 1 skip row pass, 2 skip column pass, 4 skip all groups
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;
     if (job.patches_f32)
         hipLaunchKernelGGL(k_gabor<float>, dim3(grid), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps,
-                           reinterpret_cast<const float *>(job.patches), job.mask_rows, tab, job.out, job.F, col0);
+                           reinterpret_cast<const float *>(job.patches), job.mask_rows, tab, job.out, job.F, col0, dbg);
     else
         hipLaunchKernelGGL(k_gabor<uint8_t>, dim3(grid), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps,
-                           reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, tab, job.out, job.F, col0);
+                           reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, tab, job.out, job.F, col0, dbg);
     return hipGetLastError();
 }
 
