@@ -5,7 +5,8 @@
 //                                                GLRLM_MAX_LENGTH=16, DIRECTIONS, 174-176)
 //   tch_utils::glrlm::{glrlm, glrlm_features}    call site texture.rs:193-215
 //
-// ONE SINGLE-WAVE WORKGROUP PER NUCLEUS (persistent, grid-stride).  The 24-level map of the patch
+// ONE WAVEFRONT PER NUCLEUS (persistent, grid-stride; four independent waves per workgroup, each with a
+// private LDS slice and no s_barrier -- a wave's LDS ops execute in order).  The 24-level map of the patch
 // is staged in LDS as one byte per pixel (0xFF outside the mask); lanes walk the mask rows
 // (lane = column), a lane whose pixel starts a run follows it for at most 16 steps and bumps one
 // of the 384 run-length bins with an LDS atomic.  The 17 features are weighted sums over the bins:
@@ -14,6 +15,7 @@
 // non-uniformity features are 16-lane / 4-lane butterfly reductions.  No table, no LDS traffic
 // beyond the bins themselves.
 #include "nfx_internal.h"
+#include "wave_ops.h"
 
 namespace nfx {
 
@@ -28,21 +30,18 @@ template <> struct RPx<float> {
     static __device__ __forceinline__ float ld(const float *p, size_t i) { return p[i]; }
 };
 
-static __device__ __forceinline__ double rsum(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+static __device__ __forceinline__ double rsum(double v) { return wave_total_f64(v); }
 
 template <typename T>
-__global__ __launch_bounds__(64) void k_glrlm(int64_t n, int ps, const T *__restrict__ patches,
+__global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__restrict__ patches,
                                               const uint64_t *__restrict__ mask_rows, float *__restrict__ out, int F,
                                               int col0)
 {
-    __shared__ uint8_t s_q[NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE];
-    __shared__ unsigned s_R[RL_BINS];
-    const int lane = threadIdx.x;
+    __shared__ uint8_t s_q_all[4][NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE];
+    __shared__ unsigned s_R_all[4][RL_BINS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint8_t *s_q = s_q_all[wv];
+    unsigned *s_R = s_R_all[wv];
     const int P = ps * ps;
     const int rpi = ps <= 32 ? 2 : 1, cw = ps <= 32 ? 32 : 64;
     const int c = lane & (cw - 1), rsub = rpi == 2 ? (lane >> 5) : 0;
@@ -63,15 +62,12 @@ __global__ __launch_bounds__(64) void k_glrlm(int64_t n, int ps, const T *__rest
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) s_R[lane + 64 * k] = 0u;
-    __syncthreads();
+    wave_lds_fence();
 
-    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wv; i < n; i += (int64_t)gridDim.x * 4) {
         const uint64_t myrow = lane < ps ? mask_rows[i * ps + lane] : 0ull;
         const uint64_t anyrow = __ballot(myrow != 0ull);
-        int np = __popcll(myrow);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) np += __shfl_xor(np, o, 64);
-        const double Np = (double)np; // pixel_count, texture.rs:196
+        const double Np = (double)wave_total_i32(__popcll(myrow)); // pixel_count, texture.rs:196
         const T *pp = patches + (size_t)i * 3 * P;
 
         // stage the 24-level map
@@ -92,7 +88,7 @@ __global__ __launch_bounds__(64) void k_glrlm(int64_t n, int ps, const T *__rest
                 s_q[p] = qv;
             }
         }
-        __syncthreads();
+        wave_lds_fence();
 
         for (int d = 0; d < 4; ++d) {
             const int dx = kRlDirs[d][0], dy = kRlDirs[d][1];
@@ -114,7 +110,7 @@ __global__ __launch_bounds__(64) void k_glrlm(int64_t n, int ps, const T *__rest
                     }
                 }
             }
-            __syncthreads();
+            wave_lds_fence();
             // weighted sums over the bins this lane owns
             double nr = 0, sre = 0, lre = 0, lgre = 0, hgre = 0, srlge = 0, srhge = 0, lrlge = 0, lrhge = 0;
             double srmge = 0, lrmge = 0, srege = 0, lrege = 0, rlm = 0, gln = 0, colsum = 0;
@@ -133,9 +129,7 @@ __global__ __launch_bounds__(64) void k_glrlm(int64_t n, int ps, const T *__rest
                 rlm += v * l;
                 colsum += v;
                 // row sum of gray level g_k over the 16 lanes that share lane/16
-                double rs = v;
-                rs += __shfl_xor(rs, 1, 64); rs += __shfl_xor(rs, 2, 64);
-                rs += __shfl_xor(rs, 4, 64); rs += __shfl_xor(rs, 8, 64);
+                const double rs = row16_total_f64(v);
                 if ((lane & 15) == 0) gln += rs * rs;
             }
             // column sum of run length l over the 4 lanes that share lane%16
@@ -160,7 +154,7 @@ __global__ __launch_bounds__(64) void k_glrlm(int64_t n, int ps, const T *__rest
                 o[15] = (float)mean;
                 o[16] = (float)(lre / nr - mean * mean); // sum R (l-mean)^2 / Nr
             }
-            __syncthreads();
+            wave_lds_fence();
         }
     }
 }
@@ -169,13 +163,13 @@ hipError_t launch_glrlm(nfx_ctx *ctx, const Job &job, int col0)
 {
     if (job.n == 0) return hipSuccess;
     ScopedTiming t(ctx, KS_GLRLM);
-    const int64_t maxb = 256 * 32;
-    const unsigned grid = (unsigned)(job.n < maxb ? job.n : maxb);
+    const int64_t maxb = 256 * 7 * 2, need = (job.n + 3) / 4; // 7 workgroups (28 waves) fit a CU's LDS
+    const unsigned grid = (unsigned)(need < maxb ? need : maxb);
     if (job.patches_f32)
-        hipLaunchKernelGGL(k_glrlm<float>, dim3(grid), dim3(64), 0, ctx->stream, job.n, job.ps,
+        hipLaunchKernelGGL(k_glrlm<float>, dim3(grid), dim3(256), 0, ctx->stream, job.n, job.ps,
                            reinterpret_cast<const float *>(job.patches), job.mask_rows, job.out, job.F, col0);
     else
-        hipLaunchKernelGGL(k_glrlm<uint8_t>, dim3(grid), dim3(64), 0, ctx->stream, job.n, job.ps,
+        hipLaunchKernelGGL(k_glrlm<uint8_t>, dim3(grid), dim3(256), 0, ctx->stream, job.n, job.ps,
                            reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, job.out, job.F, col0);
     return hipGetLastError();
 }
