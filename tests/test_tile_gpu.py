@@ -1,0 +1,64 @@
+"""§8f-1 patch addressing on the GPU (load_image_dataset, utils.rs:141-206): crops gathered from a
+resident [3,H,W] u8 image must equal the oracle's restatement byte for byte, incl. the zero-padding
+cases at the image border, and the tile entry must equal the packed-patch entry on those crops."""
+import numpy as np
+import pytest
+
+import _oracle as orc
+import _parity as par
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(nfx):
+    c = nfx.Context(0)
+    yield c
+    c.close()
+
+
+def _scene(synth, ps, n=120, H=300, W=340, seed=17):
+    s = synth.SEED_BASE + seed
+    cx, cy = synth.centres(s, 0, n, ps, W, H)
+    # force border cases: corners, edges, fractional centres
+    cx[:8] = [0.2, W - 0.3, 3.7, W - 4.1, ps / 2.0, W - ps / 2.0, 10.5, W / 2.0]
+    cy[:8] = [0.4, H - 0.2, H - 2.5, 2.2, ps / 2.0 - 0.5, H - ps / 2.0 + 0.5, H / 2.0, 0.0]
+    off, xy = synth.polygons(s, 0, n, ps, cx, cy)
+    img = synth.tile(s, H, W, off, xy, ps)
+    return off, xy, img
+
+
+@pytest.mark.parametrize("ps", [32, 48, 64])
+def test_gather_patches_matches_reference_addressing(synth, ctx, ps):
+    off, xy, img = _scene(synth, ps)
+    cen, _ = ctx.preprocess_polygons(off, xy)
+    got = ctx.gather_patches(cen, img, ps)
+    for i in range(len(cen)):
+        want = orc.crop_patch(img, cen[i, 0], cen[i, 1], ps)
+        assert np.array_equal(got[i], want), f"patch {i} at {cen[i]} differs in {(got[i] != want).sum()} bytes"
+    assert (got == 0).any() and (got != 0).any()
+
+
+def test_tile_entry_equals_packed_entry_and_oracle(nfx, synth, ctx):
+    ps = 48
+    off, xy, img = _scene(synth, ps, n=90)
+    sets = [0, 1, 2, 3, 4]
+    rows_t, cen_t = ctx.extract_tile(sets, off, xy, img, ps, batch_size=32)
+    patches = ctx.gather_patches(cen_t, img, ps)
+    rows_p, cen_p = ctx.extract(sets, off, xy, patches, ps, batch_size=32)
+    assert np.array_equal(rows_t, rows_p, equal_nan=True) and np.array_equal(cen_t, cen_p)
+    want, wcen = orc.extract(sets, off, xy, np.stack([orc.crop_patch(img, c[0], c[1], ps) for c in cen_t]), ps, batch_size=32)
+    assert np.array_equal(wcen, cen_t, equal_nan=True)
+    par.assert_rows_close(rows_t, want, par.column_scales(nfx, sets, ps), what="tile entry")
+
+
+def test_tile_entry_device_memory(nfx, synth, ctx):
+    import torch
+    ps = 32
+    off, xy, img = _scene(synth, ps, n=64)
+    host, _ = ctx.extract_tile([0, 1], off, xy, img, ps)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    dev, _ = ctx.extract_tile([0, 1], torch.from_numpy(off.astype(np.int32)).cuda(), torch.from_numpy(xy).cuda(), torch.from_numpy(img).cuda(), ps)
+    torch.cuda.synchronize()
+    ctx.set_stream(0)
+    assert np.array_equal(dev.cpu().numpy(), host, equal_nan=True)
