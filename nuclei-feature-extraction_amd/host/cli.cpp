@@ -1,0 +1,273 @@
+// cli.cpp -- `nuclei-feature-extraction <geometry> <slide> <output> [feature_sets]...`
+//
+// The C++ host of the MI355X engine behind the reference's command line (args.rs:76-113, readme.md:10):
+//   positionals  geometry (.geojson)  slide  output  feature_sets...   (geometry color glcm glrlm gabor texture all)
+//   flags        -o/--overwrite  -p/--patch-size <64>  -t/--thread-count <n>  -g/--gpus <i>...
+//                -b/--batch-size <100>  -v/--verbose
+// and its driver (main.rs:110-190): validate -> load geometry -> load image -> extract -> write by extension.
+// Differences, all stated at run time: there is no CPU compute path (without -g the engine uses GPU 0);
+// rows come out in input order (the reference's order is batch-completion order); only csv and json
+// writers exist (parquet/ipc need polars); only .png slides decode here (no JPEG / OpenSlide in this image).
+// The whole slide's nuclei are extracted by ONE nfx_extract_tile call per GPU -- 288 GB of HBM holds them.
+#include <algorithm>
+#include <charconv>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <sys/stat.h>
+#include <thread>
+#include <vector>
+
+#include "../../include/nfx.h"
+#include "geojson.hpp"
+#include "png.hpp"
+
+using namespace nfxhost;
+
+namespace {
+
+struct Args {
+    std::string geometry, slide, output;
+    std::vector<std::string> feature_sets;
+    bool overwrite = false, verbose = false, have_gpus = false;
+    int patch_size = 64, batch_size = 100;
+    long thread_count = -1;
+    std::vector<int> gpus;
+};
+
+bool g_debug = false;
+void log_error(const std::string &m) { fprintf(stderr, " ERROR nuclei_feature_extraction > %s\n", m.c_str()); }
+void log_info(const std::string &m) { fprintf(stderr, " INFO  nuclei_feature_extraction > %s\n", m.c_str()); }
+void log_debug(const std::string &m) { if (g_debug) fprintf(stderr, " DEBUG nuclei_feature_extraction > %s\n", m.c_str()); }
+
+[[noreturn]] void usage_error(const std::string &m)
+{
+    fprintf(stderr, "error: %s\n\nUsage: nuclei-feature-extraction [OPTIONS] <GEOMETRY> <SLIDE> <OUTPUT> [FEATURE_SETS]...\n", m.c_str());
+    exit(2); // clap's exit code for usage errors
+}
+
+bool exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+std::string extension(const std::string &p)
+{
+    const size_t slash = p.find_last_of('/');
+    const size_t dot = p.find_last_of('.');
+    if (dot == std::string::npos || (slash != std::string::npos && dot < slash) || dot + 1 == p.size()) return "";
+    if (dot == (slash == std::string::npos ? 0 : slash + 1)) return ""; // ".hidden" has no extension (Path::extension)
+    return p.substr(dot + 1);
+}
+bool is_int(const char *s) { if (!*s) return false; for (; *s; ++s) if (*s < '0' || *s > '9') return false; return true; }
+
+Args parse_args(int argc, char **argv)
+{
+    Args a;
+    std::vector<std::string> pos;
+    for (int i = 1; i < argc; ++i) {
+        const std::string s = argv[i];
+        auto need = [&](const char *name) -> const char * {
+            if (i + 1 >= argc) usage_error(std::string("a value is required for '") + name + "'");
+            return argv[++i];
+        };
+        if (s == "-o" || s == "--overwrite") a.overwrite = true;
+        else if (s == "-v" || s == "--verbose") a.verbose = true;
+        else if (s == "-p" || s == "--patch-size") { const char *v = need("--patch-size"); if (!is_int(v)) usage_error("invalid value for '--patch-size'"); a.patch_size = atoi(v); }
+        else if (s == "-b" || s == "--batch-size") { const char *v = need("--batch-size"); if (!is_int(v)) usage_error("invalid value for '--batch-size'"); a.batch_size = atoi(v); }
+        else if (s == "-t" || s == "--thread-count") { const char *v = need("--thread-count"); if (!is_int(v)) usage_error("invalid value for '--thread-count'"); a.thread_count = atol(v); }
+        else if (s == "-g" || s == "--gpus") {
+            a.have_gpus = true;
+            const char *v = need("--gpus");
+            if (!is_int(v)) usage_error("invalid value for '--gpus'");
+            a.gpus.push_back(atoi(v)); // clap 4: Vec<T> appends one value per occurrence (-g 0 -g 1)
+        } else if (s == "-h" || s == "--help") {
+            printf("Usage: nuclei-feature-extraction [OPTIONS] <GEOMETRY> <SLIDE> <OUTPUT> [FEATURE_SETS]...\n\n"
+                   "Arguments:\n  <GEOMETRY>         Input geometry file (.geojson)\n  <SLIDE>            Input slide file\n"
+                   "  <OUTPUT>           Output file (csv, json)\n  [FEATURE_SETS]...  geometry color glcm glrlm gabor texture all\n\n"
+                   "Options:\n  -o, --overwrite\n  -p, --patch-size <PATCH_SIZE>      [default: 64]\n  -t, --thread-count <THREAD_COUNT>\n"
+                   "  -g, --gpus <GPUS>...\n  -b, --batch-size <BATCH_SIZE>      [default: 100]\n  -v, --verbose\n  -h, --help\n");
+            exit(0);
+        } else if (s.size() > 1 && s[0] == '-' && !is_int(s.c_str() + 1)) usage_error("unexpected argument '" + s + "'");
+        else pos.push_back(s);
+    }
+    if (pos.size() < 3) usage_error("the following required arguments were not provided: <GEOMETRY> <SLIDE> <OUTPUT>");
+    a.geometry = pos[0]; a.slide = pos[1]; a.output = pos[2];
+    a.feature_sets.assign(pos.begin() + 3, pos.end());
+    return a;
+}
+
+std::vector<uint8_t> read_file(const std::string &path)
+{
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    const std::streamsize n = f.tellg();
+    f.seekg(0);
+    std::vector<uint8_t> b((size_t)n);
+    if (n && !f.read(reinterpret_cast<char *>(b.data()), n)) throw std::runtime_error("cannot read " + path);
+    return b;
+}
+
+void append_float(std::string &s, float v, bool json)
+{
+    if (std::isnan(v)) { s += json ? "null" : "NaN"; return; }
+    if (std::isinf(v)) { s += json ? "null" : (v < 0 ? "-inf" : "inf"); return; }
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof buf, v); // shortest round-trip
+    s.append(buf, r.ptr);
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    Args args = parse_args(argc, argv);
+    // handle_verbose (args.rs:116-126)
+    if (args.verbose) {
+        g_debug = true;
+        printf("Called Args :\n  geometry: %s\n  slide: %s\n  output: %s\n  patch_size: %d\n  batch_size: %d\n  overwrite: %d\n",
+               args.geometry.c_str(), args.slide.c_str(), args.output.c_str(), args.patch_size, args.batch_size, (int)args.overwrite);
+    }
+    // validate_paths (args.rs:137-171)
+    if (!exists(args.geometry)) { log_error("Geometry file does not exist : \"" + args.geometry + "\""); return 1; }
+    if (!exists(args.slide)) { log_error("Slide file does not exist : \"" + args.slide + "\""); return 1; }
+    if (exists(args.output) && !args.overwrite) {
+        log_error("Output file already exists : \"" + args.output + "\"\nUse --overwrite to overwrite it");
+        return 1;
+    }
+    const std::string oext = extension(args.output);
+    if (oext.empty()) { log_error("Output file must have an extension"); return 1; }
+    if (oext != "csv" && oext != "parquet" && oext != "pqt" && oext != "json" && oext != "ipc" && oext != "feather") {
+        log_error("Unsupported output format. Please use one of the following : csv, parquet, json, ipc, feather");
+        return 1;
+    }
+    if (oext != "csv" && oext != "json") {
+        log_error("Output format ." + oext + " needs the polars writers of the reference (main.rs:169-180); this build writes csv and json");
+        return 1;
+    }
+    // feature sets (args.rs:18-73)
+    std::vector<const char *> names;
+    for (auto &s : args.feature_sets) names.push_back(s.c_str());
+    std::vector<int> sets(5 * std::max<size_t>(1, names.size()));
+    const int n_sets = nfx_parse_feature_sets(names.data(), (int)names.size(), sets.data(), (int)sets.size());
+    if (n_sets < 0) {
+        for (auto &s : args.feature_sets) {
+            const char *one[1] = {s.c_str()};
+            int tmp[8];
+            if (nfx_parse_feature_sets(one, 1, tmp, 8) < 0) usage_error("invalid value '" + s + "' for '[FEATURE_SETS]...': " + s + " is not a valid feature set");
+        }
+        return 2;
+    }
+    if (n_sets == 0) { log_error("No feature set selected (the reference panics on features[0], main.rs:76)"); return 1; }
+    sets.resize((size_t)n_sets);
+    if (args.patch_size < 1 || args.patch_size > NFX_MAX_PATCH_SIZE) { log_error("patch size must be in 1..64 for the MI355X engine"); return 1; }
+    if (args.batch_size < 1) { log_error("batch size must be >= 1"); return 1; }
+    // validate_gpu (args.rs:173-183): here a GPU is always required
+    std::vector<int> gpus = args.gpus;
+    if (!args.have_gpus) {
+        log_info("no --gpus given: the reference would compute on the CPU; this engine has no CPU path and uses GPU 0");
+        gpus = {0};
+    }
+    std::vector<nfx_ctx *> ctxs;
+    for (int g : gpus) {
+        nfx_ctx *c = nullptr;
+        if (nfx_ctx_create(g, &c) != NFX_OK) { log_error("GPU " + std::to_string(g) + " does not exist"); return 1; }
+        ctxs.push_back(c);
+    }
+
+    try {
+        log_info("Loading the geojson");
+        double t0 = now_s();
+        const std::vector<uint8_t> gj = read_file(args.geometry);
+        Polygons poly = GeoJsonReader(std::string_view(reinterpret_cast<const char *>(gj.data()), gj.size())).parse();
+        log_debug("Loaded geojson in " + std::to_string(now_s() - t0) + " s (" + std::to_string(poly.size()) + " features)");
+
+        // load_input_image (main.rs:20-35)
+        const std::string sext = extension(args.slide);
+        ImageU8 img;
+        if (sext == "png") {
+            const std::vector<uint8_t> raw = read_file(args.slide);
+            img = decode_png(raw.data(), raw.size());
+        } else if (sext == "svs" || sext == "jpg" || sext == "jpeg") {
+            log_error("." + sext + " slides need OpenSlide / a JPEG decoder, which this image does not have; convert the region to .png");
+            return 1;
+        } else {
+            log_error("Unsupported input format. Please use one of the following : svs, png, jpg, jpeg");
+            return 1;
+        }
+        log_debug("Loaded image " + std::to_string(img.W) + "x" + std::to_string(img.H));
+
+        int F = 0;
+        for (int s : sets) F += nfx_feature_set_num_columns(s);
+        const int64_t n = (int64_t)poly.size();
+        std::vector<float> rows((size_t)n * F), cen((size_t)n * 2);
+        log_info("Extracting features");
+        t0 = now_s();
+        // index shards on reference-batch boundaries, one per GPU
+        const int R = (int)ctxs.size();
+        const int64_t B = args.batch_size, nb = (n + B - 1) / B, per = (nb + R - 1) / R;
+        std::vector<std::thread> th;
+        std::vector<std::string> errs((size_t)R);
+        for (int r = 0; r < R; ++r) {
+            th.emplace_back([&, r]() {
+                const int64_t i0 = std::min(r * per * B, n), i1 = std::min((r + 1) * per * B, n);
+                if (i1 <= i0) return;
+                std::vector<uint32_t> off((size_t)(i1 - i0 + 1));
+                const uint32_t base = poly.ring_offsets[(size_t)i0];
+                for (int64_t i = i0; i <= i1; ++i) off[(size_t)(i - i0)] = poly.ring_offsets[(size_t)i] - base;
+                const nfx_status st = nfx_extract_tile(ctxs[(size_t)r], sets.data(), n_sets, i1 - i0, off.back(), off.data(),
+                                                       poly.ring_xy.data() + 2 * (size_t)base, img.data.data(), img.H, img.W, args.patch_size,
+                                                       args.batch_size, rows.data() + (size_t)i0 * F, cen.data() + 2 * (size_t)i0, NFX_MEM_HOST);
+                if (st != NFX_OK) errs[(size_t)r] = nfx_last_error(ctxs[(size_t)r]);
+            });
+        }
+        for (auto &t : th) t.join();
+        for (auto &e : errs)
+            if (!e.empty()) { log_error("extraction failed: " + e); return 1; }
+        log_info("Extracted features for " + std::to_string(n) + "/" + std::to_string(n) + " patches");
+        log_debug("Extracted in " + std::to_string(now_s() - t0) + " s");
+
+        // writers (main.rs:161-189)
+        std::vector<std::string> header{"centroid"};
+        char name[256];
+        for (int s : sets)
+            for (int j = 0; j < nfx_feature_set_num_columns(s); ++j) {
+                nfx_feature_set_column_name(s, j, name, sizeof name);
+                header.push_back(name);
+            }
+        FILE *fo = fopen(args.output.c_str(), "wb");
+        if (!fo) { log_error("cannot create " + args.output); return 1; }
+        std::string line;
+        char key[128];
+        if (oext == "csv") {
+            for (size_t j = 0; j < header.size(); ++j) { if (j) line += ','; line += header[j]; }
+            line += '\n';
+            fwrite(line.data(), 1, line.size(), fo);
+            for (int64_t i = 0; i < n; ++i) {
+                line.clear();
+                nfx_centroid_key(cen[2 * (size_t)i], cen[2 * (size_t)i + 1], key, sizeof key);
+                line += '"'; line += key; line += '"'; // the key contains a comma
+                for (int j = 0; j < F; ++j) { line += ','; append_float(line, rows[(size_t)i * F + j], false); }
+                line += '\n';
+                fwrite(line.data(), 1, line.size(), fo);
+            }
+        } else { // json lines: one object per row
+            for (int64_t i = 0; i < n; ++i) {
+                line.clear();
+                nfx_centroid_key(cen[2 * (size_t)i], cen[2 * (size_t)i + 1], key, sizeof key);
+                line += "{\"centroid\":\""; line += key; line += '"';
+                for (int j = 0; j < F; ++j) { line += ",\""; line += header[(size_t)j + 1]; line += "\":"; append_float(line, rows[(size_t)i * F + j], true); }
+                line += "}\n";
+                fwrite(line.data(), 1, line.size(), fo);
+            }
+        }
+        fclose(fo);
+    } catch (const std::exception &e) {
+        log_error(e.what());
+        return 1;
+    }
+    for (auto c : ctxs) nfx_ctx_destroy(c);
+    return 0;
+}

@@ -1,0 +1,122 @@
+"""The C++ host CLI (nuclei-feature-extraction_amd/host/cli.cpp) behind the reference's command line
+(args.rs:76-113, main.rs:110-190).  CPU: argument surface and validation.  GPU: BASELINE.json configs[0]
+-- 1k synthetic nuclei GeoJSON + 2048^2 PNG tile, geometry set -- end to end against the oracle."""
+import csv
+import importlib
+import json
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+import _parity as par
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "nuclei-feature-extraction_amd", "bin", "nuclei-feature-extraction")
+
+
+def write_png(path, img):
+    """img: [3,H,W] u8 -> 8-bit RGB PNG, filter 'up' on odd rows to exercise the unfilter code."""
+    _, H, W = img.shape
+    rgb = np.ascontiguousarray(img.transpose(1, 2, 0))
+    raw = bytearray()
+    prev = np.zeros(W * 3, np.uint8)
+    for y in range(H):
+        line = rgb[y].reshape(-1)
+        if y % 2:
+            raw.append(2)
+            raw += ((line.astype(np.int16) - prev.astype(np.int16)) & 0xFF).astype(np.uint8).tobytes()
+        else:
+            raw.append(0)
+            raw += line.tobytes()
+        prev = line
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 2, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(bytes(raw), 1)) + chunk(b"IEND", b""))
+
+
+def write_geojson(path, off, xy, shuffle_keys=False):
+    feats = []
+    for i in range(len(off) - 1):
+        ring = xy[off[i]:off[i + 1]].astype(np.float64)
+        bbox = [float(ring[:, 0].min()), float(ring[:, 1].min()), float(ring[:, 0].max()), float(ring[:, 1].max())] if len(ring) else [0, 0, 0, 0]
+        geom = {"type": "Polygon", "coordinates": [[[float(x), float(y)] for x, y in ring], [[0.0, 0.0], [1.0, 0.0], [0.0, 1.0]]]}
+        f = {"type": "Feature", "id": f"n{i}", "bbox": bbox, "properties": {"objectType": "detection", "nested": {"a": [1, 2, {"b": None}]}}, "geometry": geom}
+        if shuffle_keys and i % 2:
+            f = dict(reversed(list(f.items())))
+        feats.append(f)
+    with open(path, "w") as fh:
+        json.dump({"type": "FeatureCollection", "features": feats}, fh)
+
+
+def run(*args):
+    return subprocess.run([CLI, *args], capture_output=True, text=True)
+
+
+def test_cli_exists_and_prints_usage():
+    assert os.path.exists(CLI), "build it: make -C nuclei-feature-extraction_amd/csrc"
+    r = run("--help")
+    assert r.returncode == 0 and "<GEOMETRY> <SLIDE> <OUTPUT>" in r.stdout and "--batch-size" in r.stdout
+
+
+def test_cli_argument_validation(tmp_path):
+    g, s, o = tmp_path / "a.geojson", tmp_path / "a.png", tmp_path / "o.csv"
+    assert run().returncode == 2                                    # clap: missing positionals
+    r = run(str(g), str(s), str(o), "geometry")
+    assert r.returncode == 1 and "Geometry file does not exist" in r.stderr          # args.rs:138-141
+    g.write_text("{}")
+    r = run(str(g), str(s), str(o), "geometry")
+    assert r.returncode == 1 and "Slide file does not exist" in r.stderr             # args.rs:142-145
+    s.write_bytes(b"")
+    o.write_text("x")
+    r = run(str(g), str(s), str(o), "geometry")
+    assert r.returncode == 1 and "Output file already exists" in r.stderr            # args.rs:147-153
+    r = run(str(g), str(s), str(tmp_path / "noext"), "geometry")
+    assert r.returncode == 1 and "must have an extension" in r.stderr                # args.rs:158-161
+    r = run(str(g), str(s), str(tmp_path / "o.txt"), "geometry")
+    assert r.returncode == 1 and "Unsupported output format" in r.stderr             # args.rs:162-165
+    r = run(str(g), str(s), str(tmp_path / "o2.csv"), "shape")
+    assert r.returncode == 2 and "is not a valid feature set" in r.stderr            # args.rs:32
+
+
+@pytest.mark.gpu
+def test_config1_end_to_end_csv(nfx, tmp_path):
+    """BASELINE.json configs[0]: 1k synthetic nuclei GeoJSON + 2048^2 tile, geometry set, ps 64, batch 100."""
+    synth = importlib.import_module("nuclei-feature-extraction_amd.synth")
+    n, ps, H, W = 1000, 64, 2048, 2048
+    seed = synth.SEED_BASE + 0
+    cx, cy = synth.centres(seed, 0, n, ps, W, H)
+    off, xy = synth.polygons(seed, 0, n, ps, cx, cy)
+    img = synth.tile(seed, H, W, off[:201], xy, ps)          # blobs for the first 200 nuclei are enough
+    write_png(tmp_path / "tile.png", img)
+    write_geojson(tmp_path / "nuclei.geojson", off, xy, shuffle_keys=True)
+    out = tmp_path / "features.csv"
+    r = run("-v", "-g", "0", str(tmp_path / "nuclei.geojson"), str(tmp_path / "tile.png"), str(out), "geometry", "color")
+    assert r.returncode == 0, r.stderr
+    rows = list(csv.reader(open(out)))
+    assert rows[0] == nfx.all_column_names([0, 1])
+    assert len(rows) == n + 1
+    got = np.array([[float(v) for v in r_[1:]] for r_ in rows[1:]], np.float32)
+    patches = np.stack([orc.crop_patch(img, *orc.preprocess_polygon(xy[off[i]:off[i + 1]])[0], ps) for i in range(n)])
+    want, cen = orc.extract([0, 1], off, xy, patches, ps, batch_size=100)
+    assert [r_[0] for r_ in rows[1:]] == nfx.centroids_to_key_strings(cen)           # utils.rs:226-232
+    par.assert_rows_close(got, want, par.column_scales(nfx, [0, 1], ps), what="cli csv")
+    # refuses to overwrite without -o, accepts with -o (args.rs:147-153)
+    assert run(str(tmp_path / "nuclei.geojson"), str(tmp_path / "tile.png"), str(out), "geometry").returncode == 1
+    assert run("-o", "-p", "32", "-b", "50", str(tmp_path / "nuclei.geojson"), str(tmp_path / "tile.png"), str(out), "GEOMETRY").returncode == 0
+    assert len(open(out).readline().split(",")) == 13
+
+
+@pytest.mark.gpu
+def test_geojson_requires_bbox(tmp_path):
+    (tmp_path / "g.geojson").write_text('{"features":[{"geometry":{"type":"Polygon","coordinates":[[[1,1],[5,1],[5,5],[1,1]]]}}]}')
+    write_png(tmp_path / "t.png", np.full((3, 16, 16), 200, np.uint8))
+    r = run(str(tmp_path / "g.geojson"), str(tmp_path / "t.png"), str(tmp_path / "o.csv"), "geometry")
+    assert r.returncode == 1 and "missing field `bbox`" in r.stderr                  # geojson.rs:17
