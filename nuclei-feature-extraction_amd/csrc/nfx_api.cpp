@@ -351,6 +351,10 @@ static size_t extract_ws_bytes(const int *sets, int n_sets, int64_t n, int64_t n
         Job j; j.n = n; j.ps = ps; j.batch_size = batch_size;
         b += al(color_scratch_bytes(j));
     }
+    if (has_set(sets, n_sets, NFX_SET_GLCM)) {
+        Job j; j.n = n; j.ps = ps;
+        b += al(glcm_scratch_bytes(j));
+    }
     return b + 4096;
 }
 
@@ -392,7 +396,7 @@ static nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int6
 
     int col = 0;
     bool geo_done = false;
-    void *poly_scr = nullptr;
+    void *poly_scr = nullptr, *glcm_scr = nullptr;
     for (int s = 0; s < n_sets; ++s) {
         switch (sets[s]) {
         case NFX_SET_GEOMETRY: {
@@ -411,7 +415,12 @@ static nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int6
             NFX_HIP(ctx, launch_color(ctx, job, col, scr));
             break;
         }
-        case NFX_SET_GLCM: NFX_HIP(ctx, launch_glcm(ctx, job, col)); break;
+        case NFX_SET_GLCM: {
+            if (!glcm_scr) glcm_scr = ws_alloc(ctx, glcm_scratch_bytes(job));
+            if (!glcm_scr) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
+            NFX_HIP(ctx, launch_glcm(ctx, job, col, glcm_scr));
+            break;
+        }
         case NFX_SET_GLRLM: NFX_HIP(ctx, launch_glrlm(ctx, job, col)); break;
         case NFX_SET_GABOR: NFX_HIP(ctx, launch_gabor(ctx, job, col)); break;
         }
@@ -510,6 +519,7 @@ nfx_status nfx_compute_features_batched(nfx_ctx *ctx, int set, int64_t n, int64_
     size_t need = al(8 * (size_t)n * ps) + 4096;
     if (set == NFX_SET_GEOMETRY) need += al(polygon_scratch_bytes(n, nv));
     if (set == NFX_SET_COLOR) need += al(color_scratch_bytes(job));
+    if (set == NFX_SET_GLCM) need += al(glcm_scratch_bytes(job));
     if (mem == NFX_MEM_HOST) {
         if (poly_offsets[n] != (uint32_t)nv) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "poly_offsets[n] != n_vertices");
         need += al(4 * (n + 1)) + al(8 * nv) + al(4 * n * P) + al(12 * n * P) + al(4 * (size_t)n * F);
@@ -543,7 +553,12 @@ nfx_status nfx_compute_features_batched(nfx_ctx *ctx, int set, int64_t n, int64_
         NFX_HIP(ctx, launch_color(ctx, job, 0, scr));
         break;
     }
-    case NFX_SET_GLCM: NFX_HIP(ctx, launch_glcm(ctx, job, 0)); break;
+    case NFX_SET_GLCM: {
+        void *scr = ws_alloc(ctx, glcm_scratch_bytes(job));
+        if (!scr) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+        NFX_HIP(ctx, launch_glcm(ctx, job, 0, scr));
+        break;
+    }
     case NFX_SET_GLRLM: NFX_HIP(ctx, launch_glrlm(ctx, job, 0)); break;
     case NFX_SET_GABOR: NFX_HIP(ctx, launch_gabor(ctx, job, 0)); break;
     }

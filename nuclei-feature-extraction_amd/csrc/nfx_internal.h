@@ -100,7 +100,8 @@ hipError_t launch_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids
 
 hipError_t launch_color(nfx_ctx *ctx, const Job &job, int col0, void *scratch);
 size_t color_scratch_bytes(const Job &job);
-hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0);
+hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch);
+size_t glcm_scratch_bytes(const Job &job);
 hipError_t launch_glrlm(nfx_ctx *ctx, const Job &job, int col0);
 hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0);
 
