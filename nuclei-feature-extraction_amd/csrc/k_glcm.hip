@@ -29,6 +29,8 @@
 // Instantiations per list-length class (entries per thread) keep the common small-mask case lean.  The ten sums of
 // every (level, offset) combination go to a scratch array; k_glcm_finish evaluates the 14 features with one lane
 // per combination (the f64 log/exp/divide chains would otherwise serialise 4-12 lanes of a workgroup per nucleus).
+#include <cstdlib>
+
 #include "nfx_internal.h"
 #include "wave_ops.h"
 
@@ -55,7 +57,7 @@ struct Small { // levels 32, 64, 128 (texture.rs:19), global level indices 0..2
     static constexpr int NL = 3;
     static constexpr int TAB_WORDS = 5456;               // 264 + 8 | 1040 + 8 | 4128 (+pad)
     static constexpr int HIST_WORDS = 768;               // hx32 0 | hx64 32 | hx128 96 | hs32 224 | hs64 288 | hs128 416
-    static constexpr int WPS = 4;                        // waves per SIMD requested
+    static constexpr int WPS = 3;                        // waves per SIMD requested (46 KB of LDS per workgroup)
     static __device__ __forceinline__ int L(int l) { return 32 << l; }
     static __device__ __forceinline__ int tab_off(int l) { return l == 0 ? 0 : (l == 1 ? 272 : 1320); }
     static __device__ __forceinline__ int hx_off(int l) { return l == 0 ? 0 : (l == 1 ? 32 : 96); }
@@ -122,7 +124,7 @@ struct GlcmShared {
     unsigned *tab, *hist;
     unsigned *ovf; // [0] = count, [1..] = cells that outgrew the rank tables: m | diag << 16 | level << 17
     double *part;
-    const float *idm;
+    uint8_t *qmap; // [NL][ps*ps] quantised level of every masked pixel, written once per nucleus
     const double *dO, *dD;
 };
 
@@ -179,7 +181,7 @@ static __device__ __forceinline__ void glcm_finish_offset(const GlcmShared &S, c
 // All passes of one nucleus whose mask holds K <= MAXK*256 pixels; entries live in registers.
 template <typename T, typename V, int MAXK>
 static __device__ __forceinline__ void glcm_body(const GlcmShared &S, const unsigned short *list, const float *u8lut,
-                                                 const uint64_t *rows, double (*comb)[GL_NACC], const T *pp, int ps, int K, int t)
+                                                 const uint64_t *rows, double *__restrict__ sums_i, const T *pp, int ps, int K, int t, int dbg)
 {
     const int P = ps * ps;
     int rc[MAXK];
@@ -191,11 +193,14 @@ static __device__ __forceinline__ void glcm_body(const GlcmShared &S, const unsi
         if (e < K) {
             const int pos = list[e];
             rc[k] = pos;
-            qa[k] = quant_pack<V>(gray_at<T>(pp, P, (pos >> 8) * ps + (pos & 255), u8lut));
+            const int p = (pos >> 8) * ps + (pos & 255);
+            qa[k] = quant_pack<V>(gray_at<T>(pp, P, p, u8lut));
+#pragma unroll
+            for (int l = 0; l < V::NL; ++l) S.qmap[l * P + p] = (uint8_t)(qa[k] >> (8 * l));
         }
     }
-    // packed levels of every entry's four neighbours (0xFFFFFFFF: no in-mask neighbour), loaded in one batch so
-    // the nucleus pays one global-memory round trip for them instead of one per offset
+    __syncthreads(); // level map complete; the list is in registers: its bytes become histograms + scratch
+    // packed levels of every entry's four neighbours (0xFFFFFFFF: no in-mask neighbour) from the LDS level map
     unsigned qn[4][MAXK];
 #pragma unroll
     for (int oi = 0; oi < 4; ++oi) {
@@ -205,12 +210,15 @@ static __device__ __forceinline__ void glcm_body(const GlcmShared &S, const unsi
             qn[oi][k] = 0xFFFFFFFFu;
             if (rc[k] >= 0) {
                 const int r2 = (rc[k] >> 8) + dy, c2 = (rc[k] & 255) + dx;
-                if (r2 < ps && c2 >= 0 && c2 < ps && ((rows[r2] >> c2) & 1ull))
-                    qn[oi][k] = quant_pack<V>(gray_at<T>(pp, P, r2 * ps + c2, u8lut));
+                if (r2 < ps && c2 >= 0 && c2 < ps && ((rows[r2] >> c2) & 1ull)) {
+                    unsigned q = 0;
+#pragma unroll
+                    for (int l = 0; l < V::NL; ++l) q |= (unsigned)S.qmap[l * P + r2 * ps + c2] << (8 * l);
+                    qn[oi][k] = q;
+                }
             }
         }
     }
-    __syncthreads(); // the list is in registers: its bytes become histograms + scratch
 #pragma unroll
     for (int j = 0; j < V::HIST_WORDS / GL_THREADS; ++j) S.hist[t + GL_THREADS * j] = 0u;
     if (t == 0) S.ovf[0] = 0u;
@@ -219,7 +227,7 @@ static __device__ __forceinline__ void glcm_body(const GlcmShared &S, const unsi
     LevelAcc prev[V::NL];
     unsigned prev_np = 0;
 #pragma unroll
-    for (int oi = 0; oi < 4; ++oi) {
+    for (int oi = 0; oi < ((dbg & 2) ? 0 : 4); ++oi) {
         unsigned qb[MAXK];
         unsigned np = 0;
 #pragma unroll
@@ -229,7 +237,7 @@ static __device__ __forceinline__ void glcm_body(const GlcmShared &S, const unsi
         }
         const unsigned np_w = wave_total_u32(np);
         // the previous offset's histograms are complete (barrier after its owners): fold them now
-        if (oi > 0) glcm_finish_offset<V>(S, prev, prev_np, t);
+        if (oi > 0 && !(dbg & 8)) glcm_finish_offset<V>(S, prev, prev_np, t);
 
         // ---- phase 1: one returning atomic per pair and level ---------------------------------------------
         LevelAcc A[V::NL];
@@ -238,7 +246,7 @@ static __device__ __forceinline__ void glcm_body(const GlcmShared &S, const unsi
         unsigned long long own = 0ull; // bit NL*k+l: entry k holds rank 0 of its level-l cell
 #pragma unroll
         for (int k = 0; k < MAXK; ++k) {
-            if (qb[k] != 0xFFFFFFFFu) {
+            if (qb[k] != 0xFFFFFFFFu && !(dbg & 16)) {
 #pragma unroll
                 for (int l = 0; l < V::NL; ++l) {
                     const unsigned a = (qa[k] >> (8 * l)) & 255u, b = (qb[k] >> (8 * l)) & 255u;
@@ -248,7 +256,7 @@ static __device__ __forceinline__ void glcm_body(const GlcmShared &S, const unsi
                     const unsigned rk = (atomicAdd(&S.tab[V::tab_off(l) + (idx >> 1)], 1u << sh) >> sh) & 0xFFFFu;
                     const unsigned s = a + b, d = hi - lo;
                     A[l].S1 += s; A[l].S2 += s * s; A[l].D1 += d; A[l].D2 += d * d;
-                    A[l].idm += S.idm[d];
+                    A[l].idm += __builtin_amdgcn_rcpf(1.0f + (float)(d * d)); // 1/(1+d^2), 1 ulp
                     const bool diag = lo == hi;
                     A[l].asmn += (diag ? 4u : 2u) * (2u * rk + 1u);
                     if (rk < (unsigned)GL_LUT) A[l].ents += diag ? S.dD[rk] : S.dO[rk];
@@ -263,14 +271,14 @@ static __device__ __forceinline__ void glcm_body(const GlcmShared &S, const unsi
             double v = 0.0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) v += S.part[(w * V::NL + l) * GL_NACC + a];
-            comb[V::level_index(l) * 4 + (oi - 1)][a] = v;
+            sums_i[(V::level_index(l) * 4 + (oi - 1)) * GL_NACC + a] = v;
         }
         // ---- phase 2: cell owners ------------------------------------------------------------------------------
 #pragma unroll
         for (int k = 0; k < MAXK; ++k) {
 #pragma unroll
             for (int l = 0; l < V::NL; ++l) {
-                if ((own >> (V::NL * k + l)) & 1ull) {
+                if (((own >> (V::NL * k + l)) & 1ull) && !(dbg & 4)) {
                     const unsigned a = (qa[k] >> (8 * l)) & 255u, b = (qb[k] >> (8 * l)) & 255u;
                     const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
                     unsigned short *cell = reinterpret_cast<unsigned short *>(S.tab + V::tab_off(l)) + (hi * (hi + 1u) / 2u + lo);
@@ -298,7 +306,7 @@ static __device__ __forceinline__ void glcm_body(const GlcmShared &S, const unsi
         double v = 0.0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) v += S.part[(w * V::NL + l) * GL_NACC + a];
-        comb[V::level_index(l) * 4 + 3][a] = v;
+        sums_i[(V::level_index(l) * 4 + 3) * GL_NACC + a] = v;
     }
     __syncthreads();
 }
@@ -307,19 +315,18 @@ static __device__ __forceinline__ void glcm_body(const GlcmShared &S, const unsi
 // k_lo < K <= MAXK*256 and skips the others.
 template <typename T, typename V, int MAXK>
 __global__ __launch_bounds__(GL_THREADS, V::WPS) void k_glcm(int64_t n, int ps, int k_lo, const T *__restrict__ patches,
-                                                             const uint64_t *__restrict__ mask_rows, double *__restrict__ sums)
+                                                             const uint64_t *__restrict__ mask_rows, double *__restrict__ sums, int dbg)
 {
     __shared__ unsigned s_tab[V::TAB_WORDS];
     // s_list (pixel list, 8 KB) is dead once every thread holds its entries in registers; the histograms
     // and the reduction scratch live in the same bytes afterwards.
     __shared__ __attribute__((aligned(16))) unsigned char s_alias[NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE * 2];
     __shared__ float s_u8[256];       // u8 -> u8/255.0f (utils.rs:172)
-    __shared__ float s_idm[256];      // 1/(1+d^2)
     __shared__ double s_dO[GL_LUT];   // 2[h(k+1)-h(k)]
     __shared__ double s_dD[GL_LUT];   // H(k+1)-H(k)
     __shared__ uint64_t s_rows[64];
     __shared__ unsigned s_rowstart[65];
-    __shared__ double s_comb[16][GL_NACC];
+    __shared__ uint8_t s_q[V::NL * NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE]; // level map, one byte plane per level
 
     unsigned short *s_list = reinterpret_cast<unsigned short *>(s_alias);
     GlcmShared S;
@@ -327,13 +334,12 @@ __global__ __launch_bounds__(GL_THREADS, V::WPS) void k_glcm(int64_t n, int ps, 
     S.hist = reinterpret_cast<unsigned *>(s_alias);                       // V::HIST_WORDS words
     S.part = reinterpret_cast<double *>(s_alias + V::HIST_WORDS * 4);     // [4 waves][NL][GL_NACC]: 960 B
     S.ovf = reinterpret_cast<unsigned *>(s_alias + V::HIST_WORDS * 4 + 1024); // 1 + up to 4032/128 * NL records
-    S.idm = s_idm; S.dO = s_dO; S.dD = s_dD;
+    S.qmap = s_q; S.dO = s_dO; S.dD = s_dD;
 
     const int t = threadIdx.x, lane = t & 63;
     const int P = ps * ps;
     for (int w = t; w < V::TAB_WORDS; w += GL_THREADS) s_tab[w] = 0u;
     s_u8[t] = (float)t / 255.0f;
-    s_idm[t] = 1.0f / (1.0f + (float)t * (float)t);
     if (t < GL_LUT) {
         s_dO[t] = 2.0 * (xlnx(t + 1) - xlnx(t));
         s_dD[t] = x2ln2x(t + 1) - x2ln2x(t);
@@ -379,15 +385,9 @@ __global__ __launch_bounds__(GL_THREADS, V::WPS) void k_glcm(int64_t n, int ps, 
         }
         __syncthreads();
         const T *pp = patches + (size_t)i * 3 * P;
-        glcm_body<T, V, MAXK>(S, s_list, s_u8, s_rows, s_comb, pp, ps, K, t);
+        if (!(dbg & 1)) glcm_body<T, V, MAXK>(S, s_list, s_u8, s_rows, sums + i * 16 * GL_NACC, pp, ps, K, t, dbg);
 
-        // ---- publish the combination sums; k_glcm_finish turns them into the 14 features ---------------------
-        if (t < V::NL * 4 * GL_NACC) {
-            const int cl = t / GL_NACC, a = t - cl * GL_NACC;
-            const int comb_idx = V::level_index(cl >> 2) * 4 + (cl & 3);
-            sums[(i * 16 + comb_idx) * GL_NACC + a] = s_comb[comb_idx][a];
-        }
-        // no trailing barrier: the next nucleus touches s_comb / the scratch only several barriers later
+        // (the ten sums of every combination went straight to `sums`; k_glcm_finish turns them into the features)
     }
 }
 
@@ -445,19 +445,21 @@ template <typename T, typename V>
 static void launch_variant(nfx_ctx *ctx, const Job &job, double *sums, unsigned grid)
 {
     const T *p = reinterpret_cast<const T *>(job.patches);
+    const char *dbg_env = getenv("NFX_GLCM_DBG"); // timing experiments only (phase skipping)
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;
     // K = 0 (empty mask) belongs to the first class: k_lo = -1
-    hipLaunchKernelGGL((k_glcm<T, V, 4>), dim3(grid), dim3(GL_THREADS), 0, ctx->stream, job.n, job.ps, -1, p, job.mask_rows, sums);
+    hipLaunchKernelGGL((k_glcm<T, V, 4>), dim3(grid), dim3(GL_THREADS), 0, ctx->stream, job.n, job.ps, -1, p, job.mask_rows, sums, dbg);
     if (job.ps * job.ps > 4 * GL_THREADS)
-        hipLaunchKernelGGL((k_glcm<T, V, 8>), dim3(grid), dim3(GL_THREADS), 0, ctx->stream, job.n, job.ps, 4 * GL_THREADS, p, job.mask_rows, sums);
+        hipLaunchKernelGGL((k_glcm<T, V, 8>), dim3(grid), dim3(GL_THREADS), 0, ctx->stream, job.n, job.ps, 4 * GL_THREADS, p, job.mask_rows, sums, dbg);
     if (job.ps * job.ps > 8 * GL_THREADS)
-        hipLaunchKernelGGL((k_glcm<T, V, GL_MAXK>), dim3(grid), dim3(GL_THREADS), 0, ctx->stream, job.n, job.ps, 8 * GL_THREADS, p, job.mask_rows, sums);
+        hipLaunchKernelGGL((k_glcm<T, V, GL_MAXK>), dim3(grid), dim3(GL_THREADS), 0, ctx->stream, job.n, job.ps, 8 * GL_THREADS, p, job.mask_rows, sums, dbg);
 }
 
 hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
 {
     if (job.n == 0) return hipSuccess;
     ScopedTiming t(ctx, KS_GLCM);
-    const int64_t maxb_small = 256 * 4 * 2, maxb_254 = 256 * 2 * 2; // resident workgroups per CU x2 for tail balance
+    const int64_t maxb_small = 256 * 3 * 2, maxb_254 = 256 * 2 * 2; // resident workgroups per CU x2 for tail balance
     const unsigned grid_s = (unsigned)(job.n < maxb_small ? job.n : maxb_small);
     const unsigned grid_l = (unsigned)(job.n < maxb_254 ? job.n : maxb_254);
     double *sums = reinterpret_cast<double *>(scratch);
