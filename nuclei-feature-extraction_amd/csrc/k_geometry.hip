@@ -209,13 +209,55 @@ static __device__ void shape_from_row(uint64_t row, int ps, int lane, float *__r
         const double xc = (double)cen1, yc = (double)cen0, a = (double)major, b = (double)minor;
         uint64_t ell = 0;
         if (lane < ps && a > 0.0 && b > 0.0) { // a or b zero/NaN: every test is false
+            // The set of columns passing the test is an interval (the ellipse is convex).  Its ends are estimated
+            // from the quadratic in x and then made EXACT by evaluating the reference test itself at the ends,
+            // so the result equals the per-pixel evaluation bit for bit at ~6 tests per row instead of ps.
             const double y = ((double)lane - half) - yc;
-            for (int c = 0; c < ps; ++c) {
+            auto inside = [&](int c) -> bool {
                 const double x = ((double)c - half) - xc;
                 const double xrr = x * ct + y * st;
                 const double yrr = y * ct - x * st;
                 const double u = xrr / a, v = yrr / b;
-                if ((u * u + v * v) <= 1.0) ell |= 1ull << c;
+                return (u * u + v * v) <= 1.0;
+            };
+            const double ia2 = 1.0 / (a * a), ib2 = 1.0 / (b * b);
+            const double qa = ct * ct * ia2 + st * st * ib2;
+            const double qb = 2.0 * y * ct * st * (ia2 - ib2);
+            const double qc = y * y * (st * st * ia2 + ct * ct * ib2) - 1.0;
+            const double disc = qb * qb - 4.0 * qa * qc;
+            const double shift = half + xc; // column = x + shift
+            const double xv = -qb / (2.0 * qa);
+            auto clampc = [&](double f) -> int { return f < 0.0 ? 0 : (f > (double)(ps - 1) ? ps - 1 : (int)f); };
+            // a pixel inside the interval, if there is one: the column nearest to the quadratic's vertex (or its
+            // neighbours, when rounding put the vertex on the other side of a pixel centre)
+            const int cm = clampc(floor(xv + shift + 0.5));
+            int seed = -1;
+#pragma unroll 1
+            for (int d = 0; d < 3 && seed < 0; ++d) {
+                const int c = cm + (d == 0 ? 0 : (d == 1 ? -1 : 1));
+                if (c >= 0 && c < ps && inside(c)) seed = c;
+            }
+            if (seed >= 0) {
+                const double sq = disc > 0.0 ? sqrt(disc) / (2.0 * qa) : 0.0;
+                int bound[2];
+#pragma unroll 1
+                for (int side = 0; side < 2; ++side) {
+                    const int dir = side == 0 ? -1 : 1;
+                    int e = side == 0 ? clampc(ceil(xv - sq + shift)) : clampc(floor(xv + sq + shift));
+                    e = side == 0 ? (e < seed ? e : seed) : (e > seed ? e : seed);
+                    bool grow = false; // first walk towards the seed until inside, then outwards while inside
+                    for (;;) {
+                        if (!grow && e == seed) grow = true;
+                        const int probe = grow ? e + dir : e;
+                        if (grow && (probe < 0 || probe >= ps)) break;
+                        const bool in = inside(probe);
+                        if (!grow) { if (in) grow = true; else e -= dir; }
+                        else { if (in) e = probe; else break; }
+                    }
+                    bound[side] = e;
+                }
+                const int len = bound[1] - bound[0] + 1;
+                ell = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << bound[0];
             }
         }
         xr = wave_sum(__popcll(ell ^ row));
@@ -256,8 +298,10 @@ __global__ __launch_bounds__(256) void k_shape_from_rows(int64_t n, const uint64
 // ---- polygon-derived columns (geometric_features::*, shape.rs:89-97) -----------------------------
 // ONE LANE PER NUCLEUS: shoelace area, ring perimeter and Andrew's monotone chain are short
 // sequential f64 loops over ~30 vertices; 64 independent nuclei per wave keep every lane busy where a
-// wave-per-nucleus hull would idle most of them.  Sorted vertices and the hull stack live in a
-// global scratch area indexed by the polygon's own vertex offset.
+// wave-per-nucleus hull would idle most of them.  The vertices are f32 in global memory (L1-resident, 250 B
+// per nucleus) and are widened to f64 on the fly -- exact; the sort permutation and the hull stack are BYTE
+// INDICES in a per-lane LDS slice (66 + 132 bytes), so nothing but the twelve results goes back to HBM.
+// Rings with more than 64 vertices take the same code with a global scratch slice instead.
 struct pt { double x, y; };
 
 static __device__ __forceinline__ bool pt_less(const pt &a, const pt &b)
@@ -268,76 +312,72 @@ static __device__ __forceinline__ double cross3(const pt &o, const pt &a, const 
 {
     return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x);
 }
-static __device__ double ring_area(const pt *p, int n)
-{
-    double s = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const int j = (i + 1 == n) ? 0 : i + 1;
-        s += p[i].x * p[j].y - p[j].x * p[i].y;
-    }
-    return fabs(s) * 0.5;
-}
-static __device__ double ring_perimeter(const pt *p, int n)
-{
-    double s = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const int j = (i + 1 == n) ? 0 : i + 1;
-        const double dx = p[j].x - p[i].x, dy = p[j].y - p[i].y;
-        s += sqrt(dx * dx + dy * dy);
-    }
-    return s;
-}
+
+static constexpr int PG_MAXV = 64;                 // ring length served from LDS
+static constexpr int PG_SLICE = 3 * PG_MAXV + 8;   // sort permutation (V) + hull stack (2V+2), one byte each
 
 size_t polygon_scratch_bytes(int64_t n, int64_t total_vertices)
 {
-    // per nucleus: V original + V sorted + (2V+2) hull points
-    return sizeof(pt) * (size_t)(4 * total_vertices + 2 * n + 4);
+    // long rings only: sort permutation + hull stack as 16-bit... kept simple: one u32 per slot
+    return sizeof(uint32_t) * (size_t)(3 * total_vertices + 4 * n + 16);
 }
 
-__global__ __launch_bounds__(64) void k_polygon(int64_t n, const uint32_t *__restrict__ poly_off,
-                                                const float *__restrict__ poly_xy, pt *__restrict__ scratch,
-                                                float *__restrict__ out, int F, int col0)
+template <typename IDX>
+static __device__ __forceinline__ void polygon_one(const float2 *__restrict__ v, int V, IDX *srt, IDX *hull, float *__restrict__ o)
 {
-    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t v0 = poly_off[i];
-    const int V = (int)(poly_off[i + 1] - v0);
-    pt *p = scratch + 4 * (size_t)v0 + 2 * (size_t)i;
-    pt *s = p + V;
-    pt *h = s + V;
-    for (int k = 0; k < V; ++k) {
-        const float2 f = reinterpret_cast<const float2 *>(poly_xy)[v0 + k];
-        p[k].x = (double)f.x; p[k].y = (double)f.y;
-    }
+    auto P = [&](int k) { const float2 f = v[k]; return pt{(double)f.x, (double)f.y}; };
     const double PI = 3.14159265358979323846;
-    const double area = ring_area(p, V);
-    const double perim = ring_perimeter(p, V);
+    // shoelace + perimeter in ring order
+    double sh = 0.0, perim = 0.0;
+    if (V > 0) {
+        pt a = P(0);
+        const pt first = a;
+        for (int k = 0; k < V; ++k) {
+            const pt b = (k + 1 == V) ? first : P(k + 1);
+            sh += a.x * b.y - b.x * a.y;
+            const double dx = b.x - a.x, dy = b.y - a.y;
+            perim += sqrt(dx * dx + dy * dy);
+            a = b;
+        }
+    }
+    const double area = fabs(sh) * 0.5;
     const double eq_perim = 2.0 * sqrt(PI * area);
     const double compacity = 4.0 * PI * area / (perim * perim);
 
-    // insertion sort into s (lexicographic x then y)
+    // insertion sort of the indices (lexicographic x then y; ties keep ring order, as a stable sort of the points would)
     for (int k = 0; k < V; ++k) {
-        const pt key = p[k];
+        const pt key = P(k);
         int j = k - 1;
-        while (j >= 0 && pt_less(key, s[j])) { s[j + 1] = s[j]; --j; }
-        s[j + 1] = key;
+        while (j >= 0 && pt_less(key, P(srt[j]))) { srt[j + 1] = srt[j]; --j; }
+        srt[j + 1] = (IDX)k;
     }
     int m = 0;
     for (int k = 0; k < V; ++k) {
-        while (m >= 2 && cross3(h[m - 2], h[m - 1], s[k]) <= 0.0) --m;
-        h[m++] = s[k];
+        const pt c = P(srt[k]);
+        while (m >= 2 && cross3(P(hull[m - 2]), P(hull[m - 1]), c) <= 0.0) --m;
+        hull[m++] = srt[k];
     }
     const int lower = m + 1;
     for (int k = V - 2; k >= 0; --k) {
-        while (m >= lower && cross3(h[m - 2], h[m - 1], s[k]) <= 0.0) --m;
-        h[m++] = s[k];
+        const pt c = P(srt[k]);
+        while (m >= lower && cross3(P(hull[m - 2]), P(hull[m - 1]), c) <= 0.0) --m;
+        hull[m++] = srt[k];
     }
     if (m > 1) --m;
-    const double harea = ring_area(h, m);
-    const double hperim = ring_perimeter(h, m);
+    double hsh = 0.0, hperim = 0.0;
+    if (m > 0) {
+        pt a = P(hull[0]);
+        const pt first = a;
+        for (int k = 0; k < m; ++k) {
+            const pt b = (k + 1 == m) ? first : P(hull[k + 1]);
+            hsh += a.x * b.y - b.x * a.y;
+            const double dx = b.x - a.x, dy = b.y - a.y;
+            hperim += sqrt(dx * dx + dy * dy);
+            a = b;
+        }
+    }
+    const double harea = fabs(hsh) * 0.5;
     const double deviation = (harea - area) / harea;
-
-    float *o = out + i * (int64_t)F + col0;
     o[0] = (float)area;
     o[5] = (float)perim;
     o[6] = (float)eq_perim;
@@ -345,6 +385,26 @@ __global__ __launch_bounds__(64) void k_polygon(int64_t n, const uint32_t *__res
     o[9] = (float)harea;
     o[10] = (float)deviation;
     o[11] = (float)hperim;
+}
+
+__global__ __launch_bounds__(64) void k_polygon(int64_t n, const uint32_t *__restrict__ poly_off,
+                                                const float *__restrict__ poly_xy, uint32_t *__restrict__ scratch,
+                                                float *__restrict__ out, int F, int col0)
+{
+    __shared__ uint8_t s_idx[64 * PG_SLICE];
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v0 = poly_off[i];
+    const int V = (int)(poly_off[i + 1] - v0);
+    const float2 *v = reinterpret_cast<const float2 *>(poly_xy) + v0;
+    float *o = out + i * (int64_t)F + col0;
+    if (V <= PG_MAXV) {
+        uint8_t *srt = s_idx + threadIdx.x * PG_SLICE;
+        polygon_one<uint8_t>(v, V, srt, srt + PG_MAXV, o);
+    } else {
+        uint32_t *srt = scratch + 3 * (size_t)v0 + 4 * (size_t)i;
+        polygon_one<uint32_t>(v, V, srt, srt + V, o);
+    }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------
@@ -375,7 +435,7 @@ hipError_t launch_polygon(nfx_ctx *ctx, int64_t n, const uint32_t *poly_off, con
     if (n == 0) return hipSuccess;
     ScopedTiming t(ctx, KS_POLYGON);
     hipLaunchKernelGGL(k_polygon, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, n, poly_off, poly_xy,
-                       reinterpret_cast<pt *>(scratch), out, F, col0);
+                       reinterpret_cast<uint32_t *>(scratch), out, F, col0);
     return hipGetLastError();
 }
 
