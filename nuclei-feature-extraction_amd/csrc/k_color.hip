@@ -19,6 +19,7 @@
 //   Blocks of one reference batch share blockIdx % 8, i.e. one XCD, so the batch's S/C images are
 //   served by that XCD's L2 to all of its nuclei.
 #include "nfx_internal.h"
+#include "wave_ops.h"
 
 namespace nfx {
 
@@ -30,12 +31,7 @@ template <> struct Px<float> {
     static __device__ __forceinline__ float ld(const float *p, size_t i) { return p[i]; }
 };
 
-static __device__ __forceinline__ double wave_sum_f64(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+static __device__ __forceinline__ double wave_sum_f64(double v) { return wave_total_f64(v); }
 
 // Smith hexcone, H in degrees (DESIGN.md "colour transforms")
 static __device__ __forceinline__ void hsv_from_rgb(float r, float g, float b, float &h, float &s, float &v)
@@ -79,28 +75,49 @@ static __device__ __forceinline__ void hed_from_od(float o0, float o1, float o2,
 }
 
 // ---- k_hue_batch ---------------------------------------------------------------------------------
-template <typename T>
+// VEC pixels per lane (one VEC-byte load per channel and patch; VEC = 4 when ps*ps is a multiple of 4)
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void k_hue_batch(int64_t n, int ps, int batch_size, const T *__restrict__ patches,
                                                    double *__restrict__ SC)
 {
     const int P = ps * ps;
     const int64_t b = blockIdx.y;
-    const int px = blockIdx.x * 256 + threadIdx.x;
+    const int px = (blockIdx.x * 256 + threadIdx.x) * VEC;
     if (px >= P) return;
     const int64_t j0 = b * batch_size;
     const int64_t j1 = (j0 + batch_size) < n ? (j0 + batch_size) : n;
     const float deg2rad = (float)(3.14159265358979323846 / 180.0);
-    double S = 0.0, C = 0.0;
+    double S[VEC], C[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) { S[q] = 0.0; C[q] = 0.0; }
     for (int64_t j = j0; j < j1; ++j) {
         const T *p = patches + (size_t)j * 3 * P;
-        float h, s, v;
-        hsv_from_rgb(Px<T>::ld(p, px), Px<T>::ld(p, P + px), Px<T>::ld(p, 2 * P + px), h, s, v);
-        const float hr = h * deg2rad; // color.rs:147
-        S += (double)sinf(hr);
-        C += (double)cosf(hr);
+        float r[VEC], g[VEC], bl[VEC];
+        if (sizeof(T) == 1 && VEC == 4) {
+            const uint8_t *pb = reinterpret_cast<const uint8_t *>(p);
+            const uchar4 r4 = *reinterpret_cast<const uchar4 *>(pb + px), g4 = *reinterpret_cast<const uchar4 *>(pb + P + px),
+                         b4 = *reinterpret_cast<const uchar4 *>(pb + 2 * P + px);
+            const uint8_t rr[4] = {r4.x, r4.y, r4.z, r4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) { r[q] = (float)rr[q] / 255.0f; g[q] = (float)gg[q] / 255.0f; bl[q] = (float)bb[q] / 255.0f; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) { r[q] = Px<T>::ld(p, px + q); g[q] = Px<T>::ld(p, P + px + q); bl[q] = Px<T>::ld(p, 2 * P + px + q); }
+        }
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            float h, sv, v;
+            hsv_from_rgb(r[q], g[q], bl[q], h, sv, v);
+            const float hr = h * deg2rad; // color.rs:147
+            S[q] += (double)sinf(hr);
+            C[q] += (double)cosf(hr);
+        }
     }
-    SC[((size_t)b * 2 + 0) * P + px] = S;
-    SC[((size_t)b * 2 + 1) * P + px] = C;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+        SC[((size_t)b * 2 + 0) * P + px + q] = S[q];
+        SC[((size_t)b * 2 + 1) * P + px + q] = C[q];
+    }
 }
 
 // ---- k_color ---------------------------------------------------------------------------------------
@@ -111,6 +128,9 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
                                                float *__restrict__ out, int F, int col0)
 {
     __shared__ float s_od[256];
+    // u8 patches are staged per wave into LDS with 16-byte coalesced loads: one HBM round trip per nucleus
+    // instead of one per mask row and pass (f32 patches -- the trait entry -- are read in place)
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_patch_all[]; // 4 x round16(3*ps*ps) bytes (u8 only)
     if (sizeof(T) == 1) {
         s_od[threadIdx.x] = od_lut[threadIdx.x];
         __syncthreads();
@@ -127,6 +147,21 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
     if (k_in_batch >= batch_size || i >= n) return; // wave-uniform
 
     const int P = ps * ps;
+    const T *pp = patches + (size_t)i * 3 * P;
+    const uint8_t *sp = nullptr; // the wave's staged copy (u8 only)
+    if (sizeof(T) == 1) {
+        uint8_t *dst = s_patch_all + (threadIdx.x >> 6) * ((3 * P + 15) & ~15);
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(pp);
+        const int nbytes = 3 * P;
+        if ((nbytes & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            for (int k = lane; k < nbytes / 16; k += 64)
+                reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(src)[k];
+        } else {
+            for (int k = lane; k < nbytes; k += 64) dst[k] = src[k];
+        }
+        sp = dst;
+        wave_lds_fence();
+    }
     const uint64_t myrow = lane < ps ? mask_rows[i * ps + lane] : 0ull;
     const int rpi = ps <= 32 ? 2 : 1;          // rows per wave iteration
     const int cw = ps <= 32 ? 32 : 64;         // lanes per row
@@ -150,9 +185,7 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
             cc += Cc[p];
         }
     }
-    int K = kcnt;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) K += __shfl_xor(K, o, 64);
+    const int K = wave_total_i32(kcnt);
     ss = wave_sum_f64(ss);
     cc = wave_sum_f64(cc);
     const float area = (float)K;
@@ -167,7 +200,6 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
     double s1[9], s2[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
-    const T *pp = patches + (size_t)i * 3 * P;
     for (int r0 = 0; r0 < ps; r0 += rpi) {
         if (((anyrow >> r0) & (rpi == 2 ? 3ull : 1ull)) == 0ull) continue;
         const int r = r0 + rsub;
@@ -175,16 +207,21 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
         if (r < ps && c < ps && ((w >> c) & 1ull)) {
             const int p = r * ps + c;
             float x[9];
-            x[0] = Px<T>::ld(pp, p);
-            x[1] = Px<T>::ld(pp, P + p);
-            x[2] = Px<T>::ld(pp, 2 * P + p);
+            unsigned b0 = 0, b1 = 0, b2 = 0;
+            if (sizeof(T) == 1) {
+                b0 = sp[p]; b1 = sp[P + p]; b2 = sp[2 * P + p];
+                x[0] = (float)b0 / 255.0f; x[1] = (float)b1 / 255.0f; x[2] = (float)b2 / 255.0f; // utils.rs:172
+            } else {
+                x[0] = Px<T>::ld(pp, p);
+                x[1] = Px<T>::ld(pp, P + p);
+                x[2] = Px<T>::ld(pp, 2 * P + p);
+            }
             float h;
             hsv_from_rgb(x[0], x[1], x[2], h, x[4], x[5]);
             x[3] = h - mh; // color.rs:52
             float o0, o1, o2;
             if (sizeof(T) == 1) {
-                const uint8_t *pb = reinterpret_cast<const uint8_t *>(pp);
-                o0 = s_od[pb[p]]; o1 = s_od[pb[P + p]]; o2 = s_od[pb[2 * P + p]];
+                o0 = s_od[b0]; o1 = s_od[b1]; o2 = s_od[b2];
             } else {
                 o0 = od_f32(x[0]); o1 = od_f32(x[1]); o2 = od_f32(x[2]);
             }
@@ -258,10 +295,14 @@ hipError_t launch_color(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
             const int64_t nn = job.n - j0;
             dim3 grid((unsigned)((P + 255) / 256), (unsigned)nbs);
             if (job.patches_f32)
-                hipLaunchKernelGGL(k_hue_batch<float>, grid, dim3(256), 0, ctx->stream, nn, job.ps, job.batch_size,
+                hipLaunchKernelGGL((k_hue_batch<float, 1>), grid, dim3(256), 0, ctx->stream, nn, job.ps, job.batch_size,
                                    reinterpret_cast<const float *>(job.patches) + (size_t)j0 * 3 * P, SC + (size_t)b0 * 2 * P);
-            else
-                hipLaunchKernelGGL(k_hue_batch<uint8_t>, grid, dim3(256), 0, ctx->stream, nn, job.ps, job.batch_size,
+            else if ((P & 3) == 0 && (reinterpret_cast<uintptr_t>(job.patches) & 3) == 0) {
+                dim3 grid4((unsigned)((P / 4 + 255) / 256), (unsigned)nbs);
+                hipLaunchKernelGGL((k_hue_batch<uint8_t, 4>), grid4, dim3(256), 0, ctx->stream, nn, job.ps, job.batch_size,
+                                   reinterpret_cast<const uint8_t *>(job.patches) + (size_t)j0 * 3 * P, SC + (size_t)b0 * 2 * P);
+            } else
+                hipLaunchKernelGGL((k_hue_batch<uint8_t, 1>), grid, dim3(256), 0, ctx->stream, nn, job.ps, job.batch_size,
                                    reinterpret_cast<const uint8_t *>(job.patches) + (size_t)j0 * 3 * P, SC + (size_t)b0 * 2 * P);
         }
         e = hipGetLastError();
@@ -274,10 +315,10 @@ hipError_t launch_color(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
         const int64_t blocks = nb8 * bpb;
         if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
         if (job.patches_f32)
-            hipLaunchKernelGGL(k_color<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
+            hipLaunchKernelGGL(k_color<float>, dim3((unsigned)blocks), dim3(256), 16, ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
                                reinterpret_cast<const float *>(job.patches), job.mask_rows, SC, ctx->od_lut, job.out, job.F, col0);
         else
-            hipLaunchKernelGGL(k_color<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
+            hipLaunchKernelGGL(k_color<uint8_t>, dim3((unsigned)blocks), dim3(256), 4 * ((3 * P + 15) & ~15), ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
                                reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, SC, ctx->od_lut, job.out, job.F, col0);
         e = hipGetLastError();
     }
