@@ -23,7 +23,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnfx.so")
+LIB_PATH = os.environ.get("NFX_LIB_PATH", os.path.join(_HERE, "libnfx.so"))  # override: kernel experiments only
 
 NFX_MEM_HOST, NFX_MEM_DEVICE = 0, 1
 GEOMETRY, COLOR, GLCM, GLRLM, GABOR = range(5)

@@ -250,6 +250,7 @@ void nfx_ctx_destroy(nfx_ctx *ctx)
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->gabor_tab) (void)hipFree(ctx->gabor_tab);
     if (ctx->od_lut) (void)hipFree(ctx->od_lut);
+    if (ctx->glcm_lut) (void)hipFree(ctx->glcm_lut);
     delete ctx;
 }
 

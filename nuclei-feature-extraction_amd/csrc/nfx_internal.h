@@ -51,6 +51,8 @@ struct nfx_ctx {
     float *gabor_tab = nullptr;
     // u8 -> optical-density lookup (device), built lazily
     float *od_lut = nullptr;
+    // GLCM rank-difference / x ln x tables (device), built lazily
+    double *glcm_lut = nullptr;
 };
 
 namespace nfx {
