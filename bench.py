@@ -68,7 +68,9 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # the collective path is taken for N > 1 (or when forced, to rehearse it on a one-GPU box)
+    use_dist = world > 1 or (os.environ.get("NFX_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -93,7 +95,7 @@ def main():
     pixel_sets = any(s != nfx.GEOMETRY for s in sets)
     d_patches = synth.patches(seed, i0, n_local, ps, xp=torch, device=dev) if pixel_sets else None
     d_out = torch.empty((n_local, F), dtype=torch.float32, device=dev)
-    gather_list = [torch.empty((n_local, F), dtype=torch.float32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gather_list = [torch.empty((n_local, F), dtype=torch.float32, device=dev) for _ in range(world)] if (use_dist and rank == 0) else None
     torch.cuda.synchronize()
     gen_s = time.time() - t0
 
@@ -103,11 +105,11 @@ def main():
 
     def step():
         ctx.extract(sets, d_off, d_xy, d_patches, ps, batch_size=B, out=d_out, want_centroids=False)
-        if world > 1:
+        if use_dist:
             dist.gather(d_out, gather_list, dst=0)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -126,7 +128,7 @@ def main():
     ctx.enable_timing(False)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     total_nuclei = n_local * world
@@ -185,7 +187,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     ctx.close()
 
