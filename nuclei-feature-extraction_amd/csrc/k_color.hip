@@ -109,8 +109,10 @@ __global__ __launch_bounds__(256) void k_hue_batch(int64_t n, int ps, int batch_
             float h, sv, v;
             hsv_from_rgb(r[q], g[q], bl[q], h, sv, v);
             const float hr = h * deg2rad; // color.rs:147
-            S[q] += (double)sinf(hr);
-            C[q] += (double)cosf(hr);
+            float sn, cs;
+            sincosf(hr, &sn, &cs); // one argument reduction for both (color.rs:148-149)
+            S[q] += (double)sn;
+            C[q] += (double)cs;
         }
     }
 #pragma unroll

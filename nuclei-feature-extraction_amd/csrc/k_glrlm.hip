@@ -6,14 +6,18 @@
 //   tch_utils::glrlm::{glrlm, glrlm_features}    call site texture.rs:193-215
 //
 // ONE WAVEFRONT PER NUCLEUS (persistent, grid-stride; four independent waves per workgroup, each with a
-// private LDS slice and no s_barrier -- a wave's LDS ops execute in order).  The 24-level map of the patch
-// is staged in LDS as one byte per pixel (0xFF outside the mask); lanes walk the mask rows
-// (lane = column), a lane whose pixel starts a run follows it for at most 16 steps and bumps one
-// of the 384 run-length bins with an LDS atomic.  The 17 features are weighted sums over the bins:
-// with bin = lane + 64k a lane always sees the same run length l = lane % 16 and six fixed gray
-// levels, so every weight is a register computed once per kernel; row/column sums for the
-// non-uniformity features are 16-lane / 4-lane butterfly reductions.  No table, no LDS traffic
-// beyond the bins themselves.
+// private LDS slice and no s_barrier -- a wave's LDS ops execute in order).  Runs are found BIT-PARALLEL:
+//   * staging (lane = column, coalesced): the 24-level value of every masked pixel goes to an LDS byte map,
+//     and for each of the four directions a ballot builds the row's "continues its predecessor" word
+//     C_d[r] (pixel and predecessor in the mask with equal level), filed under lane r;
+//   * per direction (lane = row): run starts are S = M & ~C.  Step k ANDs in the C word of the row k steps
+//     ahead (a one-lane shuffle), shifted by k*dx bits: what survives are the starts whose run is longer
+//     than k.  A 4-bit bit-sliced counter accumulates the survivors, so after <=15 steps every start
+//     knows min(length,16)-1 -- all pixels of a row advance together, with early exit when no run is alive;
+//   * each lane then walks its row's starts (ffs) and bumps one of the 384 run-length bins per RUN.
+// The 17 features are weighted sums over the bins: with bin = lane + 64k a lane always sees the same run
+// length l = lane % 16 and six fixed gray levels, so every weight is a register computed once per kernel;
+// row/column sums for the non-uniformity features are 16-lane / 4-lane butterfly reductions.
 #include "nfx_internal.h"
 #include "wave_ops.h"
 
@@ -37,14 +41,13 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
                                               const uint64_t *__restrict__ mask_rows, float *__restrict__ out, int F,
                                               int col0)
 {
-    __shared__ uint8_t s_q_all[4][NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE];
+    constexpr int QS = 68; // byte-map row stride: lane = row reads of one column spread over the banks
+    __shared__ uint8_t s_q_all[4][NFX_MAX_PATCH_SIZE * QS];
     __shared__ unsigned s_R_all[4][RL_BINS];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint8_t *s_q = s_q_all[wv];
     unsigned *s_R = s_R_all[wv];
     const int P = ps * ps;
-    const int rpi = ps <= 32 ? 2 : 1, cw = ps <= 32 ? 32 : 64;
-    const int c = lane & (cw - 1), rsub = rpi == 2 ? (lane >> 5) : 0;
 
     // per-lane constant weights: l = lane%16 + 1, g_k = lane/16 + 4k + 1
     const double l = (double)((lane & 15) + 1);
@@ -70,44 +73,72 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
         const double Np = (double)wave_total_i32(__popcll(myrow)); // pixel_count, texture.rs:196
         const T *pp = patches + (size_t)i * 3 * P;
 
-        // stage the 24-level map
-        for (int r0 = 0; r0 < ps; r0 += rpi) {
-            const int r = r0 + rsub;
-            const uint64_t w = __shfl(myrow, r & 63, 64);
-            if (r < ps && c < ps) {
-                const int p = r * ps + c;
-                uint8_t qv = 0xFF;
-                if ((w >> c) & 1ull) {
+        // ---- staging: level map + the four "continues" words of every row ---------------------------------
+        int clo[4] = {0, 0, 0, 0}, chi[4] = {0, 0, 0, 0}; // C_d[lane] as two 32-bit halves
+        unsigned qprev = 0xFFu;                             // the previous row's level in this lane's column
+        for (int r = 0; r < ps; ++r) {
+            const bool rowhas = (anyrow >> r) & 1ull;
+            unsigned q = 0xFFu;
+            if (rowhas) {
+                const uint64_t w = __shfl(myrow, r, 64);
+                if (lane < ps && ((w >> lane) & 1ull)) {
+                    const int p = r * ps + lane;
                     float gs = RPx<T>::ld(pp, p) + RPx<T>::ld(pp, P + p);
                     gs = gs + RPx<T>::ld(pp, 2 * P + p);
                     gs = gs / 3.0f;
-                    int q = (int)floorf(gs * (float)RL_LEVELS);
-                    q = q < 0 ? 0 : (q > RL_LEVELS - 1 ? RL_LEVELS - 1 : q);
-                    qv = (uint8_t)q;
+                    int qi = (int)floorf(gs * (float)RL_LEVELS);
+                    qi = qi < 0 ? 0 : (qi > RL_LEVELS - 1 ? RL_LEVELS - 1 : qi);
+                    q = (unsigned)qi;
+                    s_q[r * QS + lane] = (uint8_t)qi;
                 }
-                s_q[p] = qv;
+                // predecessors: (1,0) left; (1,1) up-left; (0,1) up; (-1,1) up-right      (dx,dy) texture.rs:176
+                unsigned ql = __shfl_up(q, 1, 64), pul = __shfl_up(qprev, 1, 64), pur = __shfl_down(qprev, 1, 64);
+                if (lane == 0) { ql = 0xFFu; pul = 0xFFu; }
+                if (lane == 63) pur = 0xFFu;
+                const bool on = q != 0xFFu;
+                const uint64_t c0 = __ballot(on && ql == q), c1 = __ballot(on && pul == q);
+                const uint64_t c2 = __ballot(on && qprev == q), c3 = __ballot(on && pur == q);
+                const bool mine = lane == r; // the ballots are wave-uniform: lane r files them (a v_cndmask per half)
+                clo[0] = mine ? (int)(unsigned)c0 : clo[0]; chi[0] = mine ? (int)(unsigned)(c0 >> 32) : chi[0];
+                clo[1] = mine ? (int)(unsigned)c1 : clo[1]; chi[1] = mine ? (int)(unsigned)(c1 >> 32) : chi[1];
+                clo[2] = mine ? (int)(unsigned)c2 : clo[2]; chi[2] = mine ? (int)(unsigned)(c2 >> 32) : chi[2];
+                clo[3] = mine ? (int)(unsigned)c3 : clo[3]; chi[3] = mine ? (int)(unsigned)(c3 >> 32) : chi[3];
             }
+            qprev = q;
         }
         wave_lds_fence();
 
         for (int d = 0; d < 4; ++d) {
             const int dx = kRlDirs[d][0], dy = kRlDirs[d][1];
-            for (int r0 = 0; r0 < ps; r0 += rpi) {
-                if (((anyrow >> r0) & (rpi == 2 ? 3ull : 1ull)) == 0ull) continue;
-                const int r = r0 + rsub;
-                if (r < ps && c < ps) {
-                    const unsigned q = s_q[r * ps + c];
-                    if (q != 0xFFu) {
-                        const int rp = r - dy, cp = c - dx;
-                        const bool cont = rp >= 0 && rp < ps && cp >= 0 && cp < ps && s_q[rp * ps + cp] == q;
-                        if (!cont) { // run start: follow it, lengths beyond 16 share the last bin
-                            int len = 1, rn = r + dy, cn = c + dx;
-                            while (len < RL_MAXLEN && rn >= 0 && rn < ps && cn >= 0 && cn < ps && s_q[rn * ps + cn] == q) {
-                                ++len; rn += dy; cn += dx;
-                            }
-                            atomicAdd(&s_R[q * RL_MAXLEN + (len - 1)], 1u);
-                        }
-                    }
+            const uint64_t C = ((uint64_t)(unsigned)chi[d] << 32) | (uint64_t)(unsigned)clo[d];
+            const uint64_t S = myrow & ~C;          // run starts of this lane's row
+            uint64_t alive = S, Y = C;              // alive: starts whose run is still growing; Y: C word of the row k steps ahead
+            uint64_t b0 = 0, b1 = 0, b2 = 0, b3 = 0; // bit-sliced min(length,16)-1 per start
+            for (int k = 1; k < RL_MAXLEN; ++k) {
+                if (dy) {
+                    Y = __shfl_down(Y, 1, 64);
+                    if (lane == 63) Y = 0ull;
+                }
+                const uint64_t X = dx > 0 ? (Y >> k) : (dx < 0 ? (Y << k) : Y);
+                alive &= X;
+                if (__ballot(alive != 0ull) == 0ull) break; // no run in this nucleus is longer than k
+                uint64_t c = alive, t;
+                t = b0 & c; b0 ^= c; c = t;
+                t = b1 & c; b1 ^= c; c = t;
+                t = b2 & c; b2 ^= c; c = t;
+                b3 ^= c;
+            }
+            // one bin update per run
+            {
+                uint64_t rem = S;
+                const int rbase = lane * QS;
+                while (rem) {
+                    const int pos = __ffsll((long long)rem) - 1;
+                    rem &= rem - 1ull;
+                    const unsigned len1 = (unsigned)((b0 >> pos) & 1ull) | ((unsigned)((b1 >> pos) & 1ull) << 1) |
+                                          ((unsigned)((b2 >> pos) & 1ull) << 2) | ((unsigned)((b3 >> pos) & 1ull) << 3);
+                    const unsigned q = s_q[rbase + pos];
+                    atomicAdd(&s_R[q * RL_MAXLEN + len1], 1u);
                 }
             }
             wave_lds_fence();
