@@ -10,7 +10,8 @@
 //
 //   * ONE WAVEFRONT PER NUCLEUS (single-wave workgroups, persistent): no cross-wave barrier or reduction,
 //     lanes stay busy to within K mod 64.  The mask's pixels are compacted into an LDS list of
-//     (position, four packed levels); every pixel is read from HBM and quantised exactly once;
+//     (position, four packed levels); the u8 patch is fetched with 16-byte coalesced loads into LDS (one HBM round
+//     trip per nucleus) and every masked pixel is quantised exactly once;
 //   * co-occurrence cells are counted with RETURNING LDS atomics.  The value the atomic returns is the
 //     pair's rank k inside its cell, and
 //         sum_cells G^2     = sum_pairs 2(2k+1)            (4(2k+1) on the diagonal)
@@ -135,26 +136,33 @@ static __device__ __forceinline__ void sweep(unsigned *tab, int words, unsigned 
 }
 
 // histogram entropies (sum n ln n per level and kind), clearing the words; the NLV marginal histograms end at
-// hx_end[], the sum histograms at hs_end[]
+// hx_end[], the sum histograms at hs_end[].  All twelve table look-ups of a lane are issued unconditionally and
+// together (x ln x is 0 for 0 and 1), so the lane pays one L2 round trip instead of twelve dependent ones.
 template <int NLV>
 static __device__ __forceinline__ void hist_fold(unsigned *hist, const GlcmLuts *__restrict__ lut, int lane, const int (&hx_end)[NLV],
                                                  const int (&hs_end)[NLV], double (&hxs)[NLV], double (&hss)[NLV])
 {
+    constexpr int NB = GL_HIST_WORDS / 64;
+    unsigned v[NB];
+    double e[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { v[j] = hist[lane + 64 * j]; hist[lane + 64 * j] = 0u; }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) e[j] = lut->xlnx[v[j] < (unsigned)GL_RANKS ? v[j] : 0u];
 #pragma unroll
     for (int l = 0; l < NLV; ++l) { hxs[l] = 0.0; hss[l] = 0.0; }
-    for (int b = lane; b < GL_HIST_WORDS; b += 64) {
-        const unsigned v = hist[b];
-        hist[b] = 0u;
-        if (v > 1u) {
-            const double e = v < (unsigned)GL_RANKS ? lut->xlnx[v] : (double)v * log((double)v);
-            bool done = false;
 #pragma unroll
-            for (int l = 0; l < NLV; ++l)
-                if (!done && b < hx_end[l]) { hxs[l] += e; done = true; }
+    for (int j = 0; j < NB; ++j) {
+        const int b = lane + 64 * j;
+        double ej = e[j];
+        if (v[j] >= (unsigned)GL_RANKS) ej = (double)v[j] * log((double)v[j]); // beyond the table: never for ps <= 45
+        bool done = false;
 #pragma unroll
-            for (int l = 0; l < NLV; ++l)
-                if (!done && b < hs_end[l]) { hss[l] += e; done = true; }
-        }
+        for (int l = 0; l < NLV; ++l)
+            if (!done && b < hx_end[l]) { hxs[l] += ej; done = true; }
+#pragma unroll
+        for (int l = 0; l < NLV; ++l)
+            if (!done && b < hs_end[l]) { hss[l] += ej; done = true; }
     }
 }
 
@@ -210,13 +218,23 @@ __global__ __launch_bounds__(64) void k_glcm(int64_t n, int ps, int k_lo, const 
         s_rowstart[lane] = (unsigned short)excl;
         const uint64_t anyrow = __ballot(myrow != 0ull);
         const T *pp = patches + (size_t)i * 3 * P;
+        // u8 patches: the whole patch comes in with 16-byte loads (one HBM round trip) into the table memory,
+        // which is idle until the list is built; the per-row loop below then reads LDS bytes
+        const uint8_t *staged = nullptr;
+        if (sizeof(T) == 1 && 3 * P <= TAB_WORDS * 4 && ((3 * P) & 15) == 0 && (reinterpret_cast<uintptr_t>(pp) & 15) == 0) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(pp);
+            uint4 *dst = reinterpret_cast<uint4 *>(s_tab);
+            for (int k = lane; k < (3 * P) / 16; k += 64) dst[k] = src[k];
+            staged = reinterpret_cast<const uint8_t *>(s_tab);
+            __syncthreads();
+        }
         // ---- compact list: every masked pixel is read and quantised once --------------------------------------
         for (int r = 0; r < ps; ++r) {
             if (!((anyrow >> r) & 1ull)) continue;
             const uint64_t w = __shfl(myrow, r, 64);
             const int base = __builtin_amdgcn_readlane(excl, r);
             if (lane < ps && ((w >> lane) & 1ull)) {
-                const float g = gray_at<T>(pp, P, r * ps + lane);
+                const float g = staged ? gray_at<uint8_t>(staged, P, r * ps + lane) : gray_at<T>(pp, P, r * ps + lane);
                 const unsigned q4 = quant(g, 32) | (quant(g, 64) << 8) | (quant(g, 128) << 16) | (quant(g, 254) << 24); // texture.rs:19
                 const int idx = base + __popcll(w & ((1ull << lane) - 1ull));
                 s_q[idx] = q4;
@@ -224,6 +242,11 @@ __global__ __launch_bounds__(64) void k_glcm(int64_t n, int ps, int k_lo, const 
             }
         }
         __syncthreads();
+        if (staged) { // hand the table memory back: dense tables zero, hash table empty
+            sweep(s_tab, GL_H128_OFF, 0u, lane);
+            sweep(s_tab + GL_H128_OFF, SLOTS, GL_EMPTY, lane);
+            __syncthreads();
+        }
         double *sums_i = sums + i * 16 * GL_NACC;
 
         for (int oi = 0; oi < 4; ++oi) {
