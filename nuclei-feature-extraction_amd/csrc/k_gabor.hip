@@ -95,10 +95,14 @@ static __device__ __forceinline__ void taps(const float (&x)[TS + GB_SIZE - 1], 
     }
 #pragma unroll
     for (int o = 0; o < TS; ++o) acc[o] = 0.0f;
+    // tap-major order, pinned: the TS FMAs of one tap hit TS different accumulators (independent, back-to-back
+    // issue).  Left alone, the scheduler serialises all 30 taps of one accumulator into a dependent chain.
 #pragma unroll
-    for (int j = 0; j < GB_SIZE; ++j)
+    for (int j = 0; j < GB_SIZE; ++j) {
 #pragma unroll
         for (int o = 0; o < TS; ++o) acc[o] = fmaf(wr[j], x[o + j], acc[o]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // masked, shifted partial sums of one strip's TS outputs (f32 inside the strip, f64 across strips)
@@ -145,15 +149,16 @@ static __device__ __forceinline__ void gabor_group(const GaborShared &S, const G
             for (int j = 0; j < WIN; ++j) x[j] = src[j];
             taps<TS>(x, S.wt, acc);
             float *du = &S.U[(r + GB_PAD) * GB_UW + c0c];
+            // unconditional stores (c0c <= ps - TS keeps them inside the row; for ps < TS they land in the row's unused
+            // tail): a guarded store makes the compiler sink each output's 30 FMAs into its own branch -- one
+            // dependent chain per output instead of TS independent ones
 #pragma unroll
-            for (int q = 0; q < TS; ++q)
-                if (c0c + q < ps) du[q] = acc[q];
+            for (int q = 0; q < TS; ++q) du[q] = acc[q];
             if (has_w) {
                 taps<TS>(x, S.wt + GB_WSLOT, acc);
                 float *dw = &S.W[(r + GB_PAD) * GB_UW + c0c];
 #pragma unroll
-                for (int q = 0; q < TS; ++q)
-                    if (c0c + q < ps) dw[q] = acc[q];
+                for (int q = 0; q < TS; ++q) dw[q] = acc[q];
             }
         }
     }
