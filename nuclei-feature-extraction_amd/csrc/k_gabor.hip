@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "nfx_internal.h"
+#include "wave_ops.h"
 
 namespace nfx {
 
@@ -41,6 +42,7 @@ struct GaborGroup {
     float rc[GB_SIZE];
     float rs[GB_SIZE];
     int has_w, first_filter, n_filters, paired;
+    float image[GB_WBUF]; // the group's taps exactly as they sit in LDS: [rc | rs | cc0 | cs0 | cc1 | cs1 | ...] x 32 floats
 };
 struct GaborFilter {
     float cc[GB_SIZE];
@@ -272,13 +274,15 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
         }
         gsum = (float)bsum((double)gsum);
         if (lane == 0) s_gsum[wv] = gsum;
-        // mask bounding box and area
-        uint64_t orr = 0;
-        int rmin = ps, rmax = -1, area = 0;
-        for (int r = 0; r < ps; ++r) {
-            const uint64_t w = s_rows[r];
-            if (w) { orr |= w; rmin = r < rmin ? r : rmin; rmax = r; area += __popcll(w); }
-        }
+        // mask bounding box and area: lane r looks at row r, the wave votes
+        const uint64_t wrow = s_rows[lane];
+        const uint64_t rowsany = __ballot(wrow != 0ull);
+        const int area = wave_total_i32(__popcll(wrow));
+        int olo = (int)(unsigned)wrow, ohi = (int)(unsigned)(wrow >> 32);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { olo |= __shfl_xor(olo, o, 64); ohi |= __shfl_xor(ohi, o, 64); }
+        const uint64_t orr = ((uint64_t)(unsigned)ohi << 32) | (uint64_t)(unsigned)olo;
+        const int rmin = rowsany ? __ffsll((long long)rowsany) - 1 : ps, rmax = rowsany ? 63 - __clzll((long long)rowsany) : -1;
         float *o = out + i * (int64_t)F + col0;
         if (area == 0) { // 0/0 in texture.rs:340-344
             if (t < 96) o[t] = __builtin_nanf("");
@@ -296,17 +300,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
         for (int g = 0; g < ((dbg & 4) ? 0 : n_groups); ++g) {
             const GaborGroup &G = tab->groups[g];
             float *wt = s_wt[g & 1];
-            for (int k = t; k < (2 + 2 * G.n_filters) * GB_SIZE; k += GB_THREADS) {
-                const int slot = k / GB_SIZE, j = k - slot * GB_SIZE;
-                float v;
-                if (slot == 0) v = G.rc[j];
-                else if (slot == 1) v = G.rs[j];
-                else {
-                    const GaborFilter &Fl = tab->filters[G.first_filter + ((slot - 2) >> 1)];
-                    v = (slot & 1) ? Fl.cs[j] : Fl.cc[j];
-                }
-                wt[slot * GB_WSLOT + j] = v;
-            }
+            if (t < GB_WBUF / 4) reinterpret_cast<float4 *>(wt)[t] = reinterpret_cast<const float4 *>(G.image)[t];
             __syncthreads(); // taps visible; every wave has left the previous group's column pass (U/W reusable)
             const float mu_gray = (s_gsum[0] + s_gsum[1] + s_gsum[2] + s_gsum[3]) / (float)area;
             S.wt = wt;
@@ -319,8 +313,9 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
 #pragma unroll
             for (int f = 0; f < 6; ++f) {
                 if (f < G.n_filters) {
-                    const double a = bsum(s1[f]), b = bsum(s2[f]);
-                    if (lane == 0) { s_part[wv][G.first_filter + f][0] = a; s_part[wv][G.first_filter + f][1] = b; }
+                    // each lane holds one strip's shifted sums (small numbers): an f32 wave reduction is exact enough
+                    const float a = wave_total_f32((float)s1[f]), b = wave_total_f32((float)s2[f]);
+                    if (lane == 0) { s_part[wv][G.first_filter + f][0] = (double)a; s_part[wv][G.first_filter + f][1] = (double)b; }
                 }
             }
         }
@@ -414,6 +409,12 @@ static void build_tables(GaborTables &T)
             Fl.has_s = u.B != 0.0;
         }
         G.n_filters = nf - G.first_filter;
+        for (int j = 0; j < GB_SIZE; ++j) { G.image[j] = G.rc[j]; G.image[GB_WSLOT + j] = G.rs[j]; }
+        for (int f = 0; f < G.n_filters && f < 6; ++f)
+            for (int j = 0; j < GB_SIZE; ++j) {
+                G.image[(2 + 2 * f) * GB_WSLOT + j] = T.filters[G.first_filter + f].cc[j];
+                G.image[(3 + 2 * f) * GB_WSLOT + j] = T.filters[G.first_filter + f].cs[j];
+            }
         // two filters with the same column kernels and opposite sin sign (45 / 135 degrees) share one pass
         G.paired = 0;
         if (G.n_filters == 2 && G.has_w) {
