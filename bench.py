@@ -143,8 +143,18 @@ def main():
     launches_per_step = max(1, dom_t["launches"] // max(1, args.steps))
     # a kernel launched once per step processes the rank's n_local nuclei per launch
     achieved = bytes_per_nucleus * (n_local / launches_per_step) / (dom_avg_ms * 1e-3) / 1e9
+    # HBM traffic of the dominant kernel from the PMC passes (rocprofv3 cannot run inside this process): taken from the
+    # committed summary of the same command when it matches this workload and kernel, else null
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            t = json.load(fh).get(args.workload)
+        if t and t["kernel"] == dom_name and n_local == n_def and not args.sets:
+            traffic = t["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "algorithmic_bytes_per_nucleus": round(bytes_per_nucleus, 1), "avg_launch_ms": round(dom_avg_ms, 4),
                 "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in timing.items() if v["launches"]}}
 
