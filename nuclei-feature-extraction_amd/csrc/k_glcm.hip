@@ -386,8 +386,10 @@ static void launch_classes(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, do
     const T *p = reinterpret_cast<const T *>(job.patches);
     const int P = job.ps * job.ps;
     auto grid = [&](int wgs_per_cu) { const int64_t m = 256ll * wgs_per_cu * 4; return (unsigned)(job.n < m ? job.n : m); };
-    // K = 0 (empty mask) belongs to the first class: k_lo = -1
-    hipLaunchKernelGGL((k_glcm<T, 11>), dim3(grid(7)), dim3(64), 0, ctx->stream, job.n, job.ps, -1, p, job.mask_rows, lut, sums);
+    // K = 0 (empty mask) belongs to the first class: k_lo = -1.  Smaller classes keep more nuclei in flight per CU
+    // (16 KB of LDS per wave for masks up to 512 pixels, 23 KB up to 1024, 37 KB up to 2048, 66 KB up to 4096).
+    hipLaunchKernelGGL((k_glcm<T, 10>), dim3(grid(10)), dim3(64), 0, ctx->stream, job.n, job.ps, -1, p, job.mask_rows, lut, sums);
+    if (P > 512) hipLaunchKernelGGL((k_glcm<T, 11>), dim3(grid(7)), dim3(64), 0, ctx->stream, job.n, job.ps, 512, p, job.mask_rows, lut, sums);
     if (P > 1024) hipLaunchKernelGGL((k_glcm<T, 12>), dim3(grid(4)), dim3(64), 0, ctx->stream, job.n, job.ps, 1024, p, job.mask_rows, lut, sums);
     if (P > 2048) hipLaunchKernelGGL((k_glcm<T, 13>), dim3(grid(2)), dim3(64), 0, ctx->stream, job.n, job.ps, 2048, p, job.mask_rows, lut, sums);
 }
