@@ -115,6 +115,24 @@ def test_config1_end_to_end_csv(nfx, tmp_path):
 
 
 @pytest.mark.gpu
+def test_two_contexts_in_one_process_match_one(nfx, tmp_path):
+    """-g 0 -g 0: two engine contexts driven from two host threads (the reference calls its feature sets from every
+    rayon worker, main.rs:146-151); shards are cut on batch boundaries, so the file equals the single-context one."""
+    synth = importlib.import_module("nuclei-feature-extraction_amd.synth")
+    n, ps, H, W = 330, 48, 512, 512
+    seed = synth.SEED_BASE + 9
+    cx, cy = synth.centres(seed, 0, n, ps, W, H)
+    off, xy = synth.polygons(seed, 0, n, ps, cx, cy)
+    write_png(tmp_path / "t.png", synth.tile(seed, H, W, off[:41], xy, ps))
+    write_geojson(tmp_path / "n.geojson", off, xy)
+    a, b = tmp_path / "one.csv", tmp_path / "two.csv"
+    common = ["-p", str(ps), "-b", "40", str(tmp_path / "n.geojson"), str(tmp_path / "t.png")]
+    assert run("-g", "0", *common, str(a), "color", "geometry").returncode == 0
+    assert run("-g", "0", "-g", "0", *common, str(b), "color", "geometry").returncode == 0
+    assert open(a).read() == open(b).read()
+
+
+@pytest.mark.gpu
 def test_geojson_requires_bbox(tmp_path):
     (tmp_path / "g.geojson").write_text('{"features":[{"geometry":{"type":"Polygon","coordinates":[[[1,1],[5,1],[5,5],[1,1]]]}}]}')
     write_png(tmp_path / "t.png", np.full((3, 16, 16), 200, np.uint8))
