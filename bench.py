@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--h2d", default="resident", choices=["resident", "stream"],
                     help="resident (default, the metric): inputs in HBM before the timed region; stream: patches start in pinned "
                          "host memory and every step streams them in, double-buffered (PCIe-inclusive rate, DESIGN.md)")
+    ap.add_argument("--gather-slices", type=int, default=4, help="N>1: slices per step whose row gather overlaps the next slice's compute")
     ap.add_argument("--chunk", type=int, default=100_000, help="nuclei per streamed chunk (--h2d stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
@@ -114,13 +115,31 @@ def main():
         h_patches.copy_(d_patches)
         torch.cuda.synchronize()
 
+    # N > 1: the shard is extracted in a few batch-aligned slices and each slice's rows start their way to rank 0
+    # (RCCL gather, asynchronous on RCCL's own stream) while the next slice is being computed
+    n_slices = max(1, min(args.gather_slices, n_local // B)) if use_dist else 1
+    bounds = [((n_local // B) * k // n_slices) * B for k in range(n_slices)] + [n_local]
+    v_bounds = [int(off[b]) for b in bounds]
+    d_off64 = d_off.to(torch.int64)
+    slice_offs = [(d_off64[bounds[k]:bounds[k + 1] + 1] - v_bounds[k]).to(torch.int32) for k in range(n_slices)]
+
     def step():
         if h_patches is not None:
             pipeline.extract_streamed(ctx, sets, off, xy, h_patches, ps, batch_size=B, chunk_nuclei=args.chunk, out=d_out)
-        else:
+            if use_dist:
+                dist.gather(d_out, gather_list, dst=0)
+            return
+        if not use_dist:
             ctx.extract(sets, d_off, d_xy, d_patches, ps, batch_size=B, out=d_out, want_centroids=False)
-        if use_dist:
-            dist.gather(d_out, gather_list, dst=0)
+            return
+        works = []
+        for k in range(n_slices):
+            b0, b1 = bounds[k], bounds[k + 1]
+            ctx.extract(sets, slice_offs[k], d_xy[v_bounds[k]:v_bounds[k + 1]], d_patches[b0:b1] if d_patches is not None else None, ps,
+                        batch_size=B, out=d_out[b0:b1], want_centroids=False)
+            works.append(dist.gather(d_out[b0:b1], [g[b0:b1] for g in gather_list] if rank == 0 else None, dst=0, async_op=True))
+        for w in works:
+            w.wait()
 
     def fence():
         if use_dist:
