@@ -22,9 +22,19 @@ struct Polygons {
     size_t size() const { return ring_offsets.size() - 1; }
 };
 
+// Everything the reference's serde structs keep of a feature (geojson.rs:8-24); filled only when the reader is
+// constructed with keep_all = true (filter-geojson needs bbox, type and every ring with every coordinate).
+struct FullFeature {
+    std::vector<float> bbox;
+    std::string type;
+    std::vector<std::vector<std::vector<float>>> coordinates;
+};
+
 class GeoJsonReader {
   public:
-    explicit GeoJsonReader(std::string_view text) : p_(text.data()), end_(text.data() + text.size()), begin_(text.data()) {}
+    explicit GeoJsonReader(std::string_view text, bool keep_all = false)
+        : p_(text.data()), end_(text.data() + text.size()), begin_(text.data()), keep_all_(keep_all) {}
+    std::vector<FullFeature> full; // keep_all only
 
     Polygons parse()
     {
@@ -51,6 +61,7 @@ class GeoJsonReader {
 
   private:
     const char *p_, *end_, *begin_;
+    bool keep_all_ = false;
 
     [[noreturn]] void fail(const std::string &msg) const
     {
@@ -168,6 +179,7 @@ class GeoJsonReader {
     void feature(Polygons &out)
     {
         bool have_bbox = false, have_geometry = false;
+        if (keep_all_) full.emplace_back();
         expect('{');
         if (!peek_is('}')) {
             do {
@@ -177,7 +189,10 @@ class GeoJsonReader {
                     have_bbox = true;
                     expect('[');
                     if (!peek_is(']')) {
-                        do { (void)number(); } while (comma());
+                        do {
+                            const double v = number();
+                            if (keep_all_) full.back().bbox.push_back((float)v);
+                        } while (comma());
                     }
                     expect(']');
                 } else if (key == "geometry") {
@@ -200,7 +215,10 @@ class GeoJsonReader {
             do {
                 std::string key = string();
                 expect(':');
-                if (key == "type") { have_type = true; skip_string(); }
+                if (key == "type") {
+                    have_type = true;
+                    if (keep_all_) full.back().type = string(); else skip_string();
+                }
                 else if (key == "coordinates") { have_coords = true; coordinates(out); }
                 else skip_value();
             } while (comma());
@@ -216,15 +234,18 @@ class GeoJsonReader {
         if (!peek_is(']')) {
             do {
                 expect('[');
+                if (keep_all_) full.back().coordinates.emplace_back();
                 if (!peek_is(']')) {
                     do {
                         expect('[');
                         int k = 0;
                         float xy[2] = {0.f, 0.f};
+                        if (keep_all_) full.back().coordinates.back().emplace_back();
                         if (!peek_is(']')) {
                             do {
                                 const double v = number();
                                 if (k < 2) xy[k] = (float)v; // f64 -> f32, as serde does for f32 fields
+                                if (keep_all_) full.back().coordinates.back().back().push_back((float)v);
                                 ++k;
                             } while (comma());
                         }
