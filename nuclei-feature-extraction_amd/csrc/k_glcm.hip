@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "nfx_internal.h"
+#include "exact_div.h"
 #include "wave_ops.h"
 
 namespace nfx {
@@ -82,19 +83,19 @@ static __device__ __forceinline__ float gray_at(const T *pp, int P, int p)
 }
 
 // ---- per-pair update -----------------------------------------------------------------------------------
-static __device__ __forceinline__ void pair_sums(unsigned a, unsigned b, unsigned rk, const GlcmLuts *__restrict__ lut,
-                                                 unsigned *hx, unsigned *hs, LevelAcc &A)
+// Everything of a pair that does not need the marginal histogram: sum histogram, the four power sums, idm, and the
+// rank terms.  The entropy term is a table look-up by rank; its index is handed back so the load can be issued one
+// loop iteration later, off the LDS dependency chain.
+static __device__ __forceinline__ unsigned pair_sums(unsigned a, unsigned b, unsigned rk, unsigned *hs, LevelAcc &A)
 {
     const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
-    atomicAdd(&hx[a], 1u);
-    atomicAdd(&hx[b], 1u);
     atomicAdd(&hs[a + b], 1u);
     const unsigned s = a + b, d = hi - lo;
     A.S1 += s; A.S2 += s * s; A.D1 += d; A.D2 += d * d;
     A.idm += __builtin_amdgcn_rcpf(1.0f + (float)(d * d)); // 1/(1+d^2), 1 ulp
     const bool diag = lo == hi;
     A.asmn += (diag ? 4u : 2u) * (2u * rk + 1u);
-    A.ents += diag ? lut->dD[rk] : lut->dO[rk];
+    return (diag ? (unsigned)GL_RANKS : 0u) + rk; // index into [dO | dD]
 }
 
 static __device__ __forceinline__ unsigned tri_index(unsigned a, unsigned b)
@@ -110,22 +111,20 @@ static __device__ __forceinline__ unsigned dense_rank(unsigned *tab, unsigned id
     return (atomicAdd(&tab[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
 }
 
-// open-addressing hash table, one word per cell: key << 16 | count (key <= 32384 < 0xFFFF = the EMPTY key)
+// open-addressing hash table, one word per cell: key << 16 | count (key <= 32384 < 0xFFFF = the EMPTY key).
+// Insert-first: a new cell costs one LDS round trip (the compare-and-swap that claims it already counts the pair),
+// an existing one two.
 template <int LOG2SLOTS>
 static __device__ __forceinline__ unsigned hash_rank(unsigned *tab, unsigned key)
 {
     constexpr unsigned MASK = (1u << LOG2SLOTS) - 1u;
     unsigned h = (key * 2654435761u) >> (32 - LOG2SLOTS);
     for (;;) {
-        const unsigned cur = tab[h];
-        if ((cur >> 16) == key) break;
-        if (cur == GL_EMPTY) {
-            const unsigned prev = atomicCAS(&tab[h], GL_EMPTY, key << 16);
-            if (prev == GL_EMPTY || (prev >> 16) == key) break;
-        }
+        const unsigned prev = atomicCAS(&tab[h], GL_EMPTY, (key << 16) | 1u);
+        if (prev == GL_EMPTY) return 0u;
+        if ((prev >> 16) == key) return atomicAdd(&tab[h], 1u) & 0xFFFFu;
         h = (h + 1u) & MASK;
     }
-    return atomicAdd(&tab[h], 1u) & 0xFFFFu;
 }
 
 static __device__ __forceinline__ void sweep(unsigned *tab, int words, unsigned value, int lane)
@@ -135,182 +134,258 @@ static __device__ __forceinline__ void sweep(unsigned *tab, int words, unsigned 
     for (int k = lane; k < words / 4; k += 64) t4[k] = v;
 }
 
-// histogram entropies (sum n ln n per level and kind), clearing the words; the NLV marginal histograms end at
-// hx_end[], the sum histograms at hs_end[].  All twelve table look-ups of a lane are issued unconditionally and
-// together (x ln x is 0 for 0 and 1), so the lane pays one L2 round trip instead of twelve dependent ones.
-template <int NLV>
-static __device__ __forceinline__ void hist_fold(unsigned *hist, const GlcmLuts *__restrict__ lut, int lane, const int (&hx_end)[NLV],
-                                                 const int (&hs_end)[NLV], double (&hxs)[NLV], double (&hss)[NLV])
+static __device__ __forceinline__ double xlnx_of(const GlcmLuts *__restrict__ lut, unsigned v, double fetched)
 {
-    constexpr int NB = GL_HIST_WORDS / 64;
-    unsigned v[NB];
-    double e[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) { v[j] = hist[lane + 64 * j]; hist[lane + 64 * j] = 0u; }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) e[j] = lut->xlnx[v[j] < (unsigned)GL_RANKS ? v[j] : 0u];
-#pragma unroll
-    for (int l = 0; l < NLV; ++l) { hxs[l] = 0.0; hss[l] = 0.0; }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int b = lane + 64 * j;
-        double ej = e[j];
-        if (v[j] >= (unsigned)GL_RANKS) ej = (double)v[j] * log((double)v[j]); // beyond the table: never for ps <= 45
-        bool done = false;
-#pragma unroll
-        for (int l = 0; l < NLV; ++l)
-            if (!done && b < hx_end[l]) { hxs[l] += ej; done = true; }
-#pragma unroll
-        for (int l = 0; l < NLV; ++l)
-            if (!done && b < hs_end[l]) { hss[l] += ej; done = true; }
-    }
+    return v < (unsigned)GL_RANKS ? fetched : (double)v * log((double)v); // beyond the table: masks above 2048 pixels
 }
+static __device__ __forceinline__ unsigned lut_slot(unsigned v) { return v < (unsigned)GL_RANKS ? v : 0u; }
 
-static __device__ __forceinline__ void publish(double *__restrict__ dst, unsigned np, const LevelAcc &A, double hxs, double hss, int lane)
+static __device__ __forceinline__ void publish(double *__restrict__ dst, unsigned np, const LevelAcc &A, double ents, double hxs, double hss, int lane)
 {
     const double v1 = (double)wave_total_u32(A.S1), v2 = (double)wave_total_u32(A.S2);
     const double v3 = (double)wave_total_u32(A.D1), v4 = (double)wave_total_u32(A.D2);
     const double v5 = (double)wave_total_f32(A.idm), v6 = (double)wave_total_u32(A.asmn);
-    const double v7 = wave_total_f64(A.ents), v8 = wave_total_f64(hxs), v9 = wave_total_f64(hss);
+    const double v7 = wave_total_f64(ents), v8 = wave_total_f64(hxs), v9 = wave_total_f64(hss);
     if (lane == 0) {
         dst[0] = (double)np; dst[1] = v1; dst[2] = v2; dst[3] = v3; dst[4] = v4;
         dst[5] = v5; dst[6] = v6; dst[7] = v7; dst[8] = v8; dst[9] = v9;
     }
 }
 
+// ---- mask-size classes ---------------------------------------------------------------------------------------
+// One list of nucleus indices per hash capacity, filled by k_glcm_classify (order inside a list is irrelevant).
+static constexpr int GL_CLASSES = 4;
+static __device__ __host__ __forceinline__ int glcm_class(int K) { return K <= 512 ? 0 : K <= 1024 ? 1 : K <= 2048 ? 2 : 3; }
+
+__global__ __launch_bounds__(256) void k_glcm_classify(int64_t n, int ps, const uint64_t *__restrict__ mask_rows, int *__restrict__ lists,
+                                                       int *__restrict__ counts)
+{
+    // sixteen lanes per nucleus
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    int K = 0;
+    if (i < n)
+        for (int r = sub; r < ps; r += 16) K += __popcll(mask_rows[i * ps + r]);
+    K += __shfl_xor(K, 1, 64); K += __shfl_xor(K, 2, 64); K += __shfl_xor(K, 4, 64); K += __shfl_xor(K, 8, 64);
+    if (i < n && sub == 0) {
+        const int c = glcm_class(K);
+        lists[(int64_t)c * n + atomicAdd(&counts[c], 1)] = (int)i;
+    }
+}
+
 // ---- the kernel -------------------------------------------------------------------------------------------
-// LOG2SLOTS: hash capacity; serves nuclei with k_lo < K <= SLOTS/2 mask pixels.
+// LOG2SLOTS: hash capacity; serves the nuclei of its class list (K <= SLOTS/2 mask pixels).
 template <typename T, int LOG2SLOTS>
-__global__ __launch_bounds__(64) void k_glcm(int64_t n, int ps, int k_lo, const T *__restrict__ patches,
-                                             const uint64_t *__restrict__ mask_rows, const GlcmLuts *__restrict__ lut,
-                                             double *__restrict__ sums)
+__global__ __launch_bounds__(64) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int ps,
+                                             const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
+                                             const GlcmLuts *__restrict__ lut, double *__restrict__ sums)
 {
     constexpr int SLOTS = 1 << LOG2SLOTS, QCAP = SLOTS / 2;
     constexpr int TAB_WORDS = GL_H128_OFF + SLOTS;
-    __shared__ __attribute__((aligned(16))) unsigned s_tab[TAB_WORDS];
-    __shared__ __attribute__((aligned(16))) unsigned s_hist[GL_HIST_WORDS];
+    constexpr int NPRE = 12; // 16-byte pieces of a u8 patch per lane (3*64*64 / 16 / 64)
+    __shared__ __attribute__((aligned(16))) unsigned s_mem[TAB_WORDS + GL_HIST_WORDS]; // tables | histograms
     __shared__ unsigned s_q[QCAP];           // four packed levels per list entry
     __shared__ unsigned short s_pos[QCAP];   // (r << 8) | c per list entry
-    __shared__ uint64_t s_rows[64];
+    __shared__ uint64_t s_rows1[66];         // mask row r at [r + 1]; zero rows either side
     __shared__ unsigned short s_rowstart[64];
+    unsigned *const s_tab = s_mem, *const s_hist = s_mem + TAB_WORDS;
 
     const int lane = threadIdx.x;
     const int P = ps * ps;
-    sweep(s_tab, GL_H128_OFF, 0u, lane);
-    sweep(s_tab + GL_H128_OFF, SLOTS, GL_EMPTY, lane);
-    sweep(s_hist, GL_HIST_WORDS, 0u, lane);
-    __syncthreads();
+    const int cnt = *count;
+    int j = blockIdx.x;
+    if (j >= cnt) return;
+    const double *__restrict__ rank_tab = lut->dO; // dD follows it
+    // u8 patches travel through registers: the next nucleus's patch and mask row are requested as soon as the
+    // current ones have been put down in LDS, so their HBM latency hides behind a whole nucleus of work
+    const int n16 = (3 * P) / 16;
+    const bool stage = sizeof(T) == 1 && ((3 * P) & 15) == 0 && 3 * P <= (int)sizeof(s_mem) && (reinterpret_cast<uintptr_t>(patches) & 15) == 0;
+    uint4 pre[NPRE];
+    uint64_t row_next;
+    int i_next = list[j];
+    auto request = [&](int64_t i) {
+        row_next = lane < ps ? mask_rows[i * ps + lane] : 0ull;
+        if (stage) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(patches + (size_t)i * 3 * P);
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k)
+                if (lane + 64 * k < n16) pre[k] = src[lane + 64 * k];
+        }
+    };
+    request(i_next);
+    if (lane < 2) s_rows1[lane ? ps + 1 : 0] = 0ull;
 
-    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
-        // ---- mask rows, row prefix, class test ------------------------------------------------------------
-        const uint64_t myrow = lane < ps ? mask_rows[i * ps + lane] : 0ull;
-        const int cnt = __popcll(myrow);
-        int inc = cnt;
+#pragma unroll 1
+    for (; j < cnt; j += gridDim.x) {
+        const int64_t i = i_next;
+        const uint64_t myrow = row_next;
+        if (stage) {
+            uint4 *dst = reinterpret_cast<uint4 *>(s_mem);
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k)
+                if (lane + 64 * k < n16) dst[lane + 64 * k] = pre[k];
+        }
+        if (j + (int)gridDim.x < cnt) {
+            i_next = list[j + gridDim.x];
+            request(i_next);
+        }
+        // ---- row prefix ---------------------------------------------------------------------------------------
+        const int rcnt = __popcll(myrow);
+        int inc = rcnt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int v = __shfl_up(inc, o, 64);
             if (lane >= o) inc += v;
         }
         const int K = __builtin_amdgcn_readlane(inc, 63);
-        if (K <= k_lo || K > QCAP) continue; // another instantiation's nucleus (wave-uniform)
-        const int excl = inc - cnt;
-        s_rows[lane] = myrow;
+        const int excl = inc - rcnt;
+        if (lane < ps) s_rows1[lane + 1] = myrow;
         s_rowstart[lane] = (unsigned short)excl;
-        const uint64_t anyrow = __ballot(myrow != 0ull);
-        const T *pp = patches + (size_t)i * 3 * P;
-        // u8 patches: the whole patch comes in with 16-byte loads (one HBM round trip) into the table memory,
-        // which is idle until the list is built; the per-row loop below then reads LDS bytes
-        const uint8_t *staged = nullptr;
-        if (sizeof(T) == 1 && 3 * P <= TAB_WORDS * 4 && ((3 * P) & 15) == 0 && (reinterpret_cast<uintptr_t>(pp) & 15) == 0) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(pp);
-            uint4 *dst = reinterpret_cast<uint4 *>(s_tab);
-            for (int k = lane; k < (3 * P) / 16; k += 64) dst[k] = src[k];
-            staged = reinterpret_cast<const uint8_t *>(s_tab);
-            __syncthreads();
-        }
-        // ---- compact list: every masked pixel is read and quantised once --------------------------------------
+        // ---- position list: stores only, no LDS round trip in the loop ---------------------------------------
+        const unsigned row_lo = (unsigned)myrow, row_hi = (unsigned)(myrow >> 32);
         for (int r = 0; r < ps; ++r) {
-            if (!((anyrow >> r) & 1ull)) continue;
-            const uint64_t w = __shfl(myrow, r, 64);
+            const unsigned wlo = __builtin_amdgcn_readlane(row_lo, r), whi = __builtin_amdgcn_readlane(row_hi, r);
+            if ((wlo | whi) == 0u) continue;
             const int base = __builtin_amdgcn_readlane(excl, r);
-            if (lane < ps && ((w >> lane) & 1ull)) {
-                const float g = staged ? gray_at<uint8_t>(staged, P, r * ps + lane) : gray_at<T>(pp, P, r * ps + lane);
-                const unsigned q4 = quant(g, 32) | (quant(g, 64) << 8) | (quant(g, 128) << 16) | (quant(g, 254) << 24); // texture.rs:19
-                const int idx = base + __popcll(w & ((1ull << lane) - 1ull));
-                s_q[idx] = q4;
-                s_pos[idx] = (unsigned short)((r << 8) | lane);
+            const uint64_t w = ((uint64_t)whi << 32) | wlo;
+            if ((w >> lane) & 1ull) s_pos[base + __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u))] = (unsigned short)((r << 8) | lane);
+        }
+        wave_lds_fence();
+        // ---- every masked pixel is read and quantised once, all lanes busy --------------------------------------
+        const T *pp = patches + (size_t)i * 3 * P;
+        for (int e = lane; e < K; e += 64) {
+            const unsigned pos = s_pos[e];
+            const int p = (int)(pos >> 8) * ps + (int)(pos & 255u);
+            float g;
+            if (stage) {
+                const uint8_t *sb = reinterpret_cast<const uint8_t *>(s_mem);
+                float gs = u8_unit(sb[p]) + u8_unit(sb[P + p]); // utils.rs:172
+                gs = gs + u8_unit(sb[2 * P + p]);
+                g = third_of_u8_sum(gs);                        // texture.rs:36
+            } else {
+                g = gray_at<T>(pp, P, p);
             }
+            s_q[e] = quant(g, 32) | (quant(g, 64) << 8) | (quant(g, 128) << 16) | (quant(g, 254) << 24); // texture.rs:19
         }
-        __syncthreads();
-        if (staged) { // hand the table memory back: dense tables zero, hash table empty
-            sweep(s_tab, GL_H128_OFF, 0u, lane);
-            sweep(s_tab + GL_H128_OFF, SLOTS, GL_EMPTY, lane);
-            __syncthreads();
-        }
+        wave_lds_fence();
+        sweep(s_hist, GL_HIST_WORDS, 0u, lane);
         double *sums_i = sums + i * 16 * GL_NACC;
 
+#pragma unroll 1
         for (int oi = 0; oi < 4; ++oi) {
             const int dy = kGlcmOffsets[oi][0], dx = kGlcmOffsets[oi][1];
+            sweep(s_tab, GL_H128_OFF, 0u, lane);               // pass A's dense tables start from zero
+            sweep(s_tab + GL_H128_OFF, SLOTS, GL_EMPTY, lane); // and its hash table from empty
+            wave_lds_fence();
             // ================= pass A: levels 32, 64, 128 ==========================================================
-            // histogram words: hx32 0..31 | hx64 32..95 | hx128 96..223 | hs32 224..286 | hs64 288..414 | hs128 416..670
+            // histogram words: hx128 0..127 | hs32 128..190 | hs64 192..318 | hs128 320..574.  The marginal histogram
+            // is filled per PIXEL (a pixel of level a that takes part in deg pairs adds deg to p_x(a)) and only at
+            // the finest of the nested levels: floor(128 g) >> 1 = floor(64 g), so hx64 and hx32 fold out of hx128.
             LevelAcc A0 = {0, 0, 0, 0, 0, 0.0f, 0.0}, A1 = A0, A2 = A0, A3 = A0;
             unsigned np = 0;
+            unsigned pend0 = 0u, pend1 = 0u, pend2 = 0u; // rank-table indices of the previous iteration (entry 0 holds 0.0)
+#pragma unroll 1
             for (int e = lane; e < K; e += 64) {
+                const double ev0 = rank_tab[pend0], ev1 = rank_tab[pend1], ev2 = rank_tab[pend2];
+                pend0 = pend1 = pend2 = 0u;
                 const unsigned pos = s_pos[e];
-                const int r2 = (int)(pos >> 8) + dy, c2 = (int)(pos & 255u) + dx;
-                if (r2 >= ps || c2 < 0 || c2 >= ps) continue;
-                const uint64_t w2 = s_rows[r2];
-                if (!((w2 >> c2) & 1ull)) continue;
                 const unsigned qa = s_q[e];
-                const unsigned qb = s_q[s_rowstart[r2] + (unsigned)__popcll(w2 & ((1ull << c2) - 1ull))];
-                np += 1u;
-                {
-                    const unsigned a = qa & 255u, b = qb & 255u;
-                    pair_sums(a, b, dense_rank(s_tab, tri_index(a, b)), lut, s_hist, s_hist + 224, A0);
+                const int r = (int)(pos >> 8), c = (int)(pos & 255u);
+                const int c2 = c + dx, cb = c - dx;
+                const uint64_t w2 = s_rows1[r + 1 + dy], wb = s_rows1[r + 1 - dy];
+                const bool fwd = (unsigned)c2 < (unsigned)ps && ((w2 >> (c2 & 63)) & 1ull);
+                const bool bwd = (unsigned)cb < (unsigned)ps && ((wb >> (cb & 63)) & 1ull);
+                const unsigned deg = (fwd ? 1u : 0u) + (bwd ? 1u : 0u);
+                if (deg) atomicAdd(&s_hist[(qa >> 16) & 255u], deg);
+                if (fwd) {
+                    const unsigned qb = s_q[s_rowstart[r + dy] + (unsigned)__popcll(w2 & ((1ull << c2) - 1ull))];
+                    np += 1u;
+                    {
+                        const unsigned a = qa & 255u, b = qb & 255u;
+                        pend0 = pair_sums(a, b, dense_rank(s_tab, tri_index(a, b)), s_hist + 128, A0);
+                    }
+                    {
+                        const unsigned a = (qa >> 8) & 255u, b = (qb >> 8) & 255u;
+                        pend1 = pair_sums(a, b, dense_rank(s_tab + GL_D64_OFF, tri_index(a, b)), s_hist + 192, A1);
+                    }
+                    {
+                        const unsigned a = (qa >> 16) & 255u, b = (qb >> 16) & 255u;
+                        pend2 = pair_sums(a, b, hash_rank<LOG2SLOTS>(s_tab + GL_H128_OFF, tri_index(a, b)), s_hist + 320, A2);
+                    }
                 }
-                {
-                    const unsigned a = (qa >> 8) & 255u, b = (qb >> 8) & 255u;
-                    pair_sums(a, b, dense_rank(s_tab + GL_D64_OFF, tri_index(a, b)), lut, s_hist + 32, s_hist + 288, A1);
-                }
-                {
-                    const unsigned a = (qa >> 16) & 255u, b = (qb >> 16) & 255u;
-                    pair_sums(a, b, hash_rank<LOG2SLOTS>(s_tab + GL_H128_OFF, tri_index(a, b)), lut, s_hist + 96, s_hist + 416, A2);
-                }
+                A0.ents += ev0; A1.ents += ev1; A2.ents += ev2;
             }
-            __syncthreads();
+            A0.ents += rank_tab[pend0]; A1.ents += rank_tab[pend1]; A2.ents += rank_tab[pend2];
+            wave_lds_fence();
             const unsigned np_w = wave_total_u32(np);
             {
-                const int hx_end[3] = {32, 96, 224}, hs_end[3] = {288, 416, GL_HIST_WORDS};
-                double hxs[3], hss[3];
-                hist_fold<3>(s_hist, lut, lane, hx_end, hs_end, hxs, hss);
+                // fold: read and clear the histogram words, request every x ln x together, and only then do the
+                // table sweep and the power-sum reductions, so the look-ups' round trip hides behind them
+                const uint2 h2 = reinterpret_cast<const uint2 *>(s_hist)[lane]; // hx128[2 lane], hx128[2 lane + 1]
+                unsigned hv[7];
+#pragma unroll
+                for (int m = 0; m < 7; ++m) hv[m] = s_hist[128 + lane + 64 * m];
+                const unsigned n64 = h2.x + h2.y;                       // hx64[lane]
+                const unsigned n32 = n64 + (unsigned)__shfl_down((int)n64, 1, 64); // hx32[lane / 2] on even lanes
+                const unsigned n32e = (lane & 1) ? 0u : n32;
+                const double f0 = lut->xlnx[lut_slot(h2.x)], f1 = lut->xlnx[lut_slot(h2.y)];
+                const double f64_ = lut->xlnx[lut_slot(n64)], f32_ = lut->xlnx[lut_slot(n32e)];
+                double fs[7];
+#pragma unroll
+                for (int m = 0; m < 7; ++m) fs[m] = lut->xlnx[lut_slot(hv[m])];
+                sweep(s_hist, 576, 0u, lane);
                 sweep(s_tab, SLOTS, GL_EMPTY, lane); // pass B's hash table lives at offset 0 (over d32, d64 and the head of h128)
-                publish(sums_i + (0 * 4 + oi) * GL_NACC, np_w, A0, hxs[0], hss[0], lane);
-                publish(sums_i + (1 * 4 + oi) * GL_NACC, np_w, A1, hxs[1], hss[1], lane);
-                publish(sums_i + (2 * 4 + oi) * GL_NACC, np_w, A2, hxs[2], hss[2], lane);
+                const double hx128 = xlnx_of(lut, h2.x, f0) + xlnx_of(lut, h2.y, f1);
+                const double hx64 = xlnx_of(lut, n64, f64_), hx32 = xlnx_of(lut, n32e, f32_);
+                double e[7];
+#pragma unroll
+                for (int m = 0; m < 7; ++m) e[m] = xlnx_of(lut, hv[m], fs[m]);
+                const double hs32 = e[0], hs64 = e[1] + e[2], hs128 = (e[3] + e[4]) + (e[5] + e[6]);
+                publish(sums_i + (0 * 4 + oi) * GL_NACC, np_w, A0, A0.ents, hx32, hs32, lane);
+                publish(sums_i + (1 * 4 + oi) * GL_NACC, np_w, A1, A1.ents, hx64, hs64, lane);
+                publish(sums_i + (2 * 4 + oi) * GL_NACC, np_w, A2, A2.ents, hx128, hs128, lane);
             }
-            __syncthreads();
+            wave_lds_fence();
             // ================= pass B: level 254 ===================================================================
             // histogram words: hx 0..253 | hs 256..762
+            unsigned pend3 = 0u;
+#pragma unroll 1
             for (int e = lane; e < K; e += 64) {
+                const double ev3 = rank_tab[pend3];
+                pend3 = 0u;
                 const unsigned pos = s_pos[e];
-                const int r2 = (int)(pos >> 8) + dy, c2 = (int)(pos & 255u) + dx;
-                if (r2 >= ps || c2 < 0 || c2 >= ps) continue;
-                const uint64_t w2 = s_rows[r2];
-                if (!((w2 >> c2) & 1ull)) continue;
                 const unsigned a = s_q[e] >> 24;
-                const unsigned b = s_q[s_rowstart[r2] + (unsigned)__popcll(w2 & ((1ull << c2) - 1ull))] >> 24;
-                pair_sums(a, b, hash_rank<LOG2SLOTS>(s_tab, tri_index(a, b)), lut, s_hist, s_hist + 256, A3);
+                const int r = (int)(pos >> 8), c = (int)(pos & 255u);
+                const int c2 = c + dx, cb = c - dx;
+                const uint64_t w2 = s_rows1[r + 1 + dy], wb = s_rows1[r + 1 - dy];
+                const bool fwd = (unsigned)c2 < (unsigned)ps && ((w2 >> (c2 & 63)) & 1ull);
+                const bool bwd = (unsigned)cb < (unsigned)ps && ((wb >> (cb & 63)) & 1ull);
+                const unsigned deg = (fwd ? 1u : 0u) + (bwd ? 1u : 0u);
+                if (deg) atomicAdd(&s_hist[a], deg);
+                if (fwd) {
+                    const unsigned b = s_q[s_rowstart[r + dy] + (unsigned)__popcll(w2 & ((1ull << c2) - 1ull))] >> 24;
+                    pend3 = pair_sums(a, b, hash_rank<LOG2SLOTS>(s_tab, tri_index(a, b)), s_hist + 256, A3);
+                }
+                A3.ents += ev3;
             }
-            __syncthreads();
+            A3.ents += rank_tab[pend3];
+            wave_lds_fence();
             {
-                const int hx_end[1] = {256}, hs_end[1] = {GL_HIST_WORDS};
-                double hxs[1], hss[1];
-                hist_fold<1>(s_hist, lut, lane, hx_end, hs_end, hxs, hss);
-                sweep(s_tab, GL_H128_OFF, 0u, lane);                 // pass A's dense tables start from zero
-                sweep(s_tab + GL_H128_OFF, SLOTS, GL_EMPTY, lane);   // and its hash table from empty
-                publish(sums_i + (3 * 4 + oi) * GL_NACC, np_w, A3, hxs[0], hss[0], lane);
+                unsigned hv[12];
+#pragma unroll
+                for (int m = 0; m < 12; ++m) hv[m] = s_hist[lane + 64 * m];
+                double fs[12];
+#pragma unroll
+                for (int m = 0; m < 12; ++m) fs[m] = lut->xlnx[lut_slot(hv[m])];
+                sweep(s_hist, GL_HIST_WORDS, 0u, lane);
+                double e[12];
+#pragma unroll
+                for (int m = 0; m < 12; ++m) e[m] = xlnx_of(lut, hv[m], fs[m]);
+                const double hx = (e[0] + e[1]) + (e[2] + e[3]);
+                const double hs = ((e[4] + e[5]) + (e[6] + e[7])) + ((e[8] + e[9]) + (e[10] + e[11]));
+                publish(sums_i + (3 * 4 + oi) * GL_NACC, np_w, A3, A3.ents, hx, hs, lane);
             }
-            __syncthreads();
+            wave_lds_fence();
         }
     }
 }
@@ -363,7 +438,12 @@ __global__ __launch_bounds__(256) void k_glcm_finish(int64_t n, const double *__
     o[13] = (float)sqrt(a2);
 }
 
-size_t glcm_scratch_bytes(const Job &job) { return sizeof(double) * 16 * GL_NACC * (size_t)(job.n > 0 ? job.n : 1); }
+static size_t glcm_sums_bytes(int64_t n) { return sizeof(double) * 16 * GL_NACC * (size_t)(n > 0 ? n : 1); }
+size_t glcm_scratch_bytes(const Job &job)
+{
+    const size_t n = (size_t)(job.n > 0 ? job.n : 1);
+    return glcm_sums_bytes(job.n) + sizeof(int) * (GL_CLASSES * n + 64);
+}
 
 static hipError_t ensure_luts(nfx_ctx *ctx)
 {
@@ -381,29 +461,36 @@ static hipError_t ensure_luts(nfx_ctx *ctx)
 }
 
 template <typename T>
-static void launch_classes(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *sums)
+static void launch_classes(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *sums, const int *lists, const int *counts)
 {
     const T *p = reinterpret_cast<const T *>(job.patches);
     const int P = job.ps * job.ps;
     auto grid = [&](int wgs_per_cu) { const int64_t m = 256ll * wgs_per_cu * 4; return (unsigned)(job.n < m ? job.n : m); };
-    // K = 0 (empty mask) belongs to the first class: k_lo = -1.  Smaller classes keep more nuclei in flight per CU
-    // (16 KB of LDS per wave for masks up to 512 pixels, 23 KB up to 1024, 37 KB up to 2048, 66 KB up to 4096).
-    hipLaunchKernelGGL((k_glcm<T, 10>), dim3(grid(10)), dim3(64), 0, ctx->stream, job.n, job.ps, -1, p, job.mask_rows, lut, sums);
-    if (P > 512) hipLaunchKernelGGL((k_glcm<T, 11>), dim3(grid(7)), dim3(64), 0, ctx->stream, job.n, job.ps, 512, p, job.mask_rows, lut, sums);
-    if (P > 1024) hipLaunchKernelGGL((k_glcm<T, 12>), dim3(grid(4)), dim3(64), 0, ctx->stream, job.n, job.ps, 1024, p, job.mask_rows, lut, sums);
-    if (P > 2048) hipLaunchKernelGGL((k_glcm<T, 13>), dim3(grid(2)), dim3(64), 0, ctx->stream, job.n, job.ps, 2048, p, job.mask_rows, lut, sums);
+    // Smaller classes keep more nuclei in flight per CU (16 KB of LDS per wave for masks up to 512 pixels, 23 KB up
+    // to 1024, 37 KB up to 2048, 66 KB up to 4096).  Blocks beyond a list's length exit at once.
+    const int64_t n = job.n;
+    hipLaunchKernelGGL((k_glcm<T, 10>), dim3(grid(10)), dim3(64), 0, ctx->stream, lists + 0 * n, counts + 0, job.ps, p, job.mask_rows, lut, sums);
+    if (P > 512) hipLaunchKernelGGL((k_glcm<T, 11>), dim3(grid(7)), dim3(64), 0, ctx->stream, lists + 1 * n, counts + 1, job.ps, p, job.mask_rows, lut, sums);
+    if (P > 1024) hipLaunchKernelGGL((k_glcm<T, 12>), dim3(grid(4)), dim3(64), 0, ctx->stream, lists + 2 * n, counts + 2, job.ps, p, job.mask_rows, lut, sums);
+    if (P > 2048) hipLaunchKernelGGL((k_glcm<T, 13>), dim3(grid(2)), dim3(64), 0, ctx->stream, lists + 3 * n, counts + 3, job.ps, p, job.mask_rows, lut, sums);
 }
 
 hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
 {
     if (job.n == 0) return hipSuccess;
+    if (job.n > 0x7FFFFFFFll) return hipErrorInvalidValue; // class lists hold 32-bit nucleus indices
     hipError_t e = ensure_luts(ctx);
     if (e != hipSuccess) return e;
     ScopedTiming t(ctx, KS_GLCM);
     double *sums = reinterpret_cast<double *>(scratch);
+    int *lists = reinterpret_cast<int *>(reinterpret_cast<char *>(scratch) + glcm_sums_bytes(job.n));
+    int *counts = lists + GL_CLASSES * job.n;
     const GlcmLuts *lut = reinterpret_cast<const GlcmLuts *>(ctx->glcm_lut);
-    if (job.patches_f32) launch_classes<float>(ctx, job, lut, sums);
-    else launch_classes<uint8_t>(ctx, job, lut, sums);
+    e = hipMemsetAsync(counts, 0, sizeof(int) * GL_CLASSES, ctx->stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_glcm_classify, dim3((unsigned)((job.n * 16 + 255) / 256)), dim3(256), 0, ctx->stream, job.n, job.ps, job.mask_rows, lists, counts);
+    if (job.patches_f32) launch_classes<float>(ctx, job, lut, sums, lists, counts);
+    else launch_classes<uint8_t>(ctx, job, lut, sums, lists, counts);
     const int64_t items = job.n * 16;
     hipLaunchKernelGGL(k_glcm_finish, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, job.n, sums, job.out, job.F, col0);
     return hipGetLastError();
