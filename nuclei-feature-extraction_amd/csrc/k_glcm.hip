@@ -98,6 +98,13 @@ static __device__ __forceinline__ unsigned pair_sums(unsigned a, unsigned b, uns
     return (diag ? (unsigned)GL_RANKS : 0u) + rk; // index into [dO | dD]
 }
 
+// hash key of the unordered cell {a, b}: at most 0xFDFD, below the dummy (0xFFFE) and empty (0xFFFF) keys
+static __device__ __forceinline__ unsigned cell_key(unsigned a, unsigned b)
+{
+    const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+    return (hi << 8) | lo;
+}
+
 static __device__ __forceinline__ unsigned tri_index(unsigned a, unsigned b)
 {
     const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
@@ -111,20 +118,98 @@ static __device__ __forceinline__ unsigned dense_rank(unsigned *tab, unsigned id
     return (atomicAdd(&tab[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
 }
 
-// open-addressing hash table, one word per cell: key << 16 | count (key <= 32384 < 0xFFFF = the EMPTY key).
-// Insert-first: a new cell costs one LDS round trip (the compare-and-swap that claims it already counts the pair),
-// an existing one two.
+// open-addressing hash tables hold one word per cell: key << 16 | count.
+
+// ---- two list entries per lane and iteration -------------------------------------------------------------------
+// The pair loops are chains of dependent LDS round trips (position -> mask rows -> partner level -> cell counter ->
+// next probe) and LDS capacity caps a CU at ~10 waves, so the latency has to be hidden inside the wave: every lane
+// walks TWO list entries per iteration through one branch-free body, giving the scheduler two independent chains.
+// "Branch-free": an entry without a partner adds 0 to valid counters and aims its compare-and-swap at the lane's
+// private dummy word (key 0xFFFE, never empty, never equal), so no exec-mask region splits the basic block.
+struct Located {
+    unsigned qa, qb; // packed levels of the pixel and of its partner
+    bool fwd;        // the partner (r+dy, c+dx) is in the mask: this entry owns a pair
+    unsigned deg;    // number of pairs the pixel takes part in (forward + backward)
+    unsigned memo;   // what pass B needs to find the same partner again: list distance (1..126, 0 = none) | bwd << 7
+};
+
+static __device__ __forceinline__ Located locate(int e, bool valid, int ps, int dy, int dx, const unsigned *s_q,
+                                                 const uint64_t *s_rows1, const unsigned short *s_rowstart)
+{
+    const int es = valid ? e : 0;
+    Located L;
+    L.qa = s_q[es];
+    const int r = (int)(L.qa >> 24), c = (int)((L.qa >> 16) & 255u);
+    const int c2 = c + dx, cb = c - dx;
+    const uint64_t w2 = s_rows1[r + 1 + dy], wb = s_rows1[r + 1 - dy];
+    const unsigned rs = s_rowstart[r + dy];
+    L.fwd = valid && (unsigned)c2 < (unsigned)ps && ((w2 >> (c2 & 63)) & 1ull);
+    const bool bwd = valid && (unsigned)cb < (unsigned)ps && ((wb >> (cb & 63)) & 1ull);
+    L.deg = (L.fwd ? 1u : 0u) + (bwd ? 1u : 0u);
+    // without a partner this is still a list index (<= K): the value read is masked into range and adds 0 everywhere
+    const unsigned pidx = rs + (unsigned)__popcll(w2 & ((1ull << (c2 & 63)) - 1ull));
+    L.qb = s_q[pidx];
+    L.memo = (L.fwd ? pidx - (unsigned)es : 0u) | (bwd ? 128u : 0u); // the partner sits in this or the next row: < 2 ps entries on
+    return L;
+}
+
+// pass B: the same pixel and partner through the memo pass A left behind (no mask arithmetic)
+static __device__ __forceinline__ Located relocate(int e, bool valid, const unsigned *s_q, const unsigned char *s_memo)
+{
+    const int es = valid ? e : 0;
+    const unsigned m = valid ? s_memo[es] : 0u;
+    Located L;
+    L.qa = s_q[es];
+    const unsigned delta = m & 127u;
+    L.fwd = delta != 0u;
+    L.deg = (L.fwd ? 1u : 0u) + (m >> 7);
+    L.qb = s_q[es + (int)delta];
+    L.memo = m;
+    return L;
+}
+
+// branch-free accumulation of one pair at one level; returns the rank-table index for the deferred look-up
+static __device__ __forceinline__ unsigned pair_acc(bool fwd, unsigned a, unsigned b, unsigned rk, LevelAcc &A)
+{
+    const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+    const unsigned d = fwd ? hi - lo : 0u; // the sums over s = a + b come out of the sum histogram when it is folded
+    A.D1 += d; A.D2 += d * d;
+    A.idm += fwd ? __builtin_amdgcn_rcpf(1.0f + (float)(d * d)) : 0.0f; // 1/(1+d^2), 1 ulp
+    const bool diag = lo == hi;
+    A.asmn += fwd ? (diag ? 4u : 2u) * (2u * rk + 1u) : 0u;
+    return fwd ? (diag ? (unsigned)GL_RANKS : 0u) + rk : 0u;
+}
+
+static __device__ __forceinline__ unsigned dense_rank_if(unsigned *tab, unsigned idx, bool fwd)
+{
+    const unsigned sh = (idx & 1u) * 16u;
+    return (atomicAdd(&tab[idx >> 1], fwd ? 1u << sh : 0u) >> sh) & 0xFFFFu;
+}
+
+static constexpr unsigned GL_DUMMY = 0xFFFE0000u;
+
+// ranks of two keys in the open-addressing table; both probes of a round are issued back to back
 template <int LOG2SLOTS>
-static __device__ __forceinline__ unsigned hash_rank(unsigned *tab, unsigned key)
+static __device__ __forceinline__ void hash_rank2(unsigned *tab, unsigned *dummy, unsigned key0, bool act0, unsigned key1, bool act1,
+                                                  unsigned &rk0, unsigned &rk1)
 {
     constexpr unsigned MASK = (1u << LOG2SLOTS) - 1u;
-    unsigned h = (key * 2654435761u) >> (32 - LOG2SLOTS);
-    for (;;) {
-        const unsigned prev = atomicCAS(&tab[h], GL_EMPTY, (key << 16) | 1u);
-        if (prev == GL_EMPTY) return 0u;
-        if ((prev >> 16) == key) return atomicAdd(&tab[h], 1u) & 0xFFFFu;
-        h = (h + 1u) & MASK;
-    }
+    unsigned h0 = __umul24(key0, 0x9E3779u) >> (32 - LOG2SLOTS), h1 = __umul24(key1, 0x9E3779u) >> (32 - LOG2SLOTS);
+    rk0 = 0u; rk1 = 0u;
+    do {
+        unsigned *const slot0 = act0 ? tab + h0 : dummy, *const slot1 = act1 ? tab + h1 : dummy;
+        const unsigned prev0 = atomicCAS(slot0, GL_EMPTY, (key0 << 16) | 1u);
+        const unsigned prev1 = atomicCAS(slot1, GL_EMPTY, (key1 << 16) | 1u);
+        const bool same0 = act0 && (prev0 >> 16) == key0, same1 = act1 && (prev1 >> 16) == key1;
+        const unsigned r0 = atomicAdd(same0 ? slot0 : dummy, same0 ? 1u : 0u);
+        const unsigned r1 = atomicAdd(same1 ? slot1 : dummy, same1 ? 1u : 0u);
+        if (same0) rk0 = r0 & 0xFFFFu;
+        if (same1) rk1 = r1 & 0xFFFFu;
+        act0 = act0 && prev0 != GL_EMPTY && !same0;
+        act1 = act1 && prev1 != GL_EMPTY && !same1;
+        h0 = (h0 + 1u) & MASK;
+        h1 = (h1 + 1u) & MASK;
+    } while (act0 || act1);
 }
 
 static __device__ __forceinline__ void sweep(unsigned *tab, int words, unsigned value, int lane)
@@ -184,10 +269,12 @@ __global__ __launch_bounds__(64) void k_glcm(const int *__restrict__ list, const
     constexpr int TAB_WORDS = GL_H128_OFF + SLOTS;
     constexpr int NPRE = 12; // 16-byte pieces of a u8 patch per lane (3*64*64 / 16 / 64)
     __shared__ __attribute__((aligned(16))) unsigned s_mem[TAB_WORDS + GL_HIST_WORDS]; // tables | histograms
-    __shared__ unsigned s_q[QCAP];           // four packed levels per list entry
-    __shared__ unsigned short s_pos[QCAP];   // (r << 8) | c per list entry
+    __shared__ unsigned s_q[QCAP + 1];         // list entry: r << 24 | c << 16 | level128 << 8 | level254 (levels 64 and 32
+                                             // are level128 >> 1 and >> 2: floor(128 g) >> 1 == floor(64 g))
     __shared__ uint64_t s_rows1[66];         // mask row r at [r + 1]; zero rows either side
-    __shared__ unsigned short s_rowstart[64];
+    __shared__ unsigned short s_rowstart[66];
+    __shared__ unsigned s_dummy[64];
+    __shared__ unsigned char s_memo[QCAP + 64];
     unsigned *const s_tab = s_mem, *const s_hist = s_mem + TAB_WORDS;
 
     const int lane = threadIdx.x;
@@ -214,6 +301,7 @@ __global__ __launch_bounds__(64) void k_glcm(const int *__restrict__ list, const
     };
     request(i_next);
     if (lane < 2) s_rows1[lane ? ps + 1 : 0] = 0ull;
+    if (lane < 2) s_rowstart[64 + lane] = 0;
 
 #pragma unroll 1
     for (; j < cnt; j += gridDim.x) {
@@ -248,14 +336,14 @@ __global__ __launch_bounds__(64) void k_glcm(const int *__restrict__ list, const
             if ((wlo | whi) == 0u) continue;
             const int base = __builtin_amdgcn_readlane(excl, r);
             const uint64_t w = ((uint64_t)whi << 32) | wlo;
-            if ((w >> lane) & 1ull) s_pos[base + __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u))] = (unsigned short)((r << 8) | lane);
+            if ((w >> lane) & 1ull) s_q[base + __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u))] = ((unsigned)r << 24) | ((unsigned)lane << 16);
         }
         wave_lds_fence();
         // ---- every masked pixel is read and quantised once, all lanes busy --------------------------------------
         const T *pp = patches + (size_t)i * 3 * P;
         for (int e = lane; e < K; e += 64) {
-            const unsigned pos = s_pos[e];
-            const int p = (int)(pos >> 8) * ps + (int)(pos & 255u);
+            const unsigned pos = s_q[e];
+            const int p = (int)(pos >> 24) * ps + (int)((pos >> 16) & 255u);
             float g;
             if (stage) {
                 const uint8_t *sb = reinterpret_cast<const uint8_t *>(s_mem);
@@ -265,10 +353,11 @@ __global__ __launch_bounds__(64) void k_glcm(const int *__restrict__ list, const
             } else {
                 g = gray_at<T>(pp, P, p);
             }
-            s_q[e] = quant(g, 32) | (quant(g, 64) << 8) | (quant(g, 128) << 16) | (quant(g, 254) << 24); // texture.rs:19
+            s_q[e] = pos | (quant(g, 128) << 8) | quant(g, 254); // texture.rs:19
         }
         wave_lds_fence();
         sweep(s_hist, GL_HIST_WORDS, 0u, lane);
+        s_dummy[lane] = GL_DUMMY;
         double *sums_i = sums + i * 16 * GL_NACC;
 
 #pragma unroll 1
@@ -283,39 +372,47 @@ __global__ __launch_bounds__(64) void k_glcm(const int *__restrict__ list, const
             // the finest of the nested levels: floor(128 g) >> 1 = floor(64 g), so hx64 and hx32 fold out of hx128.
             LevelAcc A0 = {0, 0, 0, 0, 0, 0.0f, 0.0}, A1 = A0, A2 = A0, A3 = A0;
             unsigned np = 0;
-            unsigned pend0 = 0u, pend1 = 0u, pend2 = 0u; // rank-table indices of the previous iteration (entry 0 holds 0.0)
+            unsigned pend[2][3] = {{0u, 0u, 0u}, {0u, 0u, 0u}}; // rank-table indices of the previous iteration (entry 0 holds 0.0)
 #pragma unroll 1
-            for (int e = lane; e < K; e += 64) {
-                const double ev0 = rank_tab[pend0], ev1 = rank_tab[pend1], ev2 = rank_tab[pend2];
-                pend0 = pend1 = pend2 = 0u;
-                const unsigned pos = s_pos[e];
-                const unsigned qa = s_q[e];
-                const int r = (int)(pos >> 8), c = (int)(pos & 255u);
-                const int c2 = c + dx, cb = c - dx;
-                const uint64_t w2 = s_rows1[r + 1 + dy], wb = s_rows1[r + 1 - dy];
-                const bool fwd = (unsigned)c2 < (unsigned)ps && ((w2 >> (c2 & 63)) & 1ull);
-                const bool bwd = (unsigned)cb < (unsigned)ps && ((wb >> (cb & 63)) & 1ull);
-                const unsigned deg = (fwd ? 1u : 0u) + (bwd ? 1u : 0u);
-                if (deg) atomicAdd(&s_hist[(qa >> 16) & 255u], deg);
-                if (fwd) {
-                    const unsigned qb = s_q[s_rowstart[r + dy] + (unsigned)__popcll(w2 & ((1ull << c2) - 1ull))];
-                    np += 1u;
-                    {
-                        const unsigned a = qa & 255u, b = qb & 255u;
-                        pend0 = pair_sums(a, b, dense_rank(s_tab, tri_index(a, b)), s_hist + 128, A0);
-                    }
-                    {
-                        const unsigned a = (qa >> 8) & 255u, b = (qb >> 8) & 255u;
-                        pend1 = pair_sums(a, b, dense_rank(s_tab + GL_D64_OFF, tri_index(a, b)), s_hist + 192, A1);
-                    }
-                    {
-                        const unsigned a = (qa >> 16) & 255u, b = (qb >> 16) & 255u;
-                        pend2 = pair_sums(a, b, hash_rank<LOG2SLOTS>(s_tab + GL_H128_OFF, tri_index(a, b)), s_hist + 320, A2);
-                    }
-                }
-                A0.ents += ev0; A1.ents += ev1; A2.ents += ev2;
+            for (int e = lane; e < K; e += 128) {
+                double ev[2][3];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int l = 0; l < 3; ++l) ev[u][l] = rank_tab[pend[u][l]];
+                const Located X = locate(e, true, ps, dy, dx, s_q, s_rows1, s_rowstart);
+                const Located Y = locate(e + 64, e + 64 < K, ps, dy, dx, s_q, s_rows1, s_rowstart);
+                const unsigned xa2 = (X.qa >> 8) & 127u, xb2 = (X.qb >> 8) & 127u, ya2 = (Y.qa >> 8) & 127u, yb2 = (Y.qb >> 8) & 127u;
+                const unsigned xa1 = xa2 >> 1, xb1 = xb2 >> 1, ya1 = ya2 >> 1, yb1 = yb2 >> 1;
+                const unsigned xa0 = xa2 >> 2, xb0 = xb2 >> 2, ya0 = ya2 >> 2, yb0 = yb2 >> 2;
+                s_memo[e] = (unsigned char)X.memo;
+                s_memo[e + 64] = (unsigned char)Y.memo;
+                atomicAdd(&s_hist[xa2], X.deg);
+                atomicAdd(&s_hist[ya2], Y.deg);
+                np += (X.fwd ? 1u : 0u) + (Y.fwd ? 1u : 0u);
+                const unsigned rx0 = dense_rank_if(s_tab, tri_index(xa0, xb0), X.fwd);
+                const unsigned ry0 = dense_rank_if(s_tab, tri_index(ya0, yb0), Y.fwd);
+                const unsigned rx1 = dense_rank_if(s_tab + GL_D64_OFF, tri_index(xa1, xb1), X.fwd);
+                const unsigned ry1 = dense_rank_if(s_tab + GL_D64_OFF, tri_index(ya1, yb1), Y.fwd);
+                atomicAdd(&s_hist[128 + xa0 + xb0], X.fwd ? 1u : 0u);
+                atomicAdd(&s_hist[128 + ya0 + yb0], Y.fwd ? 1u : 0u);
+                atomicAdd(&s_hist[192 + xa1 + xb1], X.fwd ? 1u : 0u);
+                atomicAdd(&s_hist[192 + ya1 + yb1], Y.fwd ? 1u : 0u);
+                atomicAdd(&s_hist[320 + xa2 + xb2], X.fwd ? 1u : 0u);
+                atomicAdd(&s_hist[320 + ya2 + yb2], Y.fwd ? 1u : 0u);
+                unsigned rx2, ry2;
+                hash_rank2<LOG2SLOTS>(s_tab + GL_H128_OFF, s_dummy + lane, cell_key(xa2, xb2), X.fwd, cell_key(ya2, yb2), Y.fwd, rx2, ry2);
+                pend[0][0] = pair_acc(X.fwd, xa0, xb0, rx0, A0);
+                pend[1][0] = pair_acc(Y.fwd, ya0, yb0, ry0, A0);
+                pend[0][1] = pair_acc(X.fwd, xa1, xb1, rx1, A1);
+                pend[1][1] = pair_acc(Y.fwd, ya1, yb1, ry1, A1);
+                pend[0][2] = pair_acc(X.fwd, xa2, xb2, rx2, A2);
+                pend[1][2] = pair_acc(Y.fwd, ya2, yb2, ry2, A2);
+                A0.ents += ev[0][0] + ev[1][0]; A1.ents += ev[0][1] + ev[1][1]; A2.ents += ev[0][2] + ev[1][2];
             }
-            A0.ents += rank_tab[pend0]; A1.ents += rank_tab[pend1]; A2.ents += rank_tab[pend2];
+            A0.ents += rank_tab[pend[0][0]] + rank_tab[pend[1][0]];
+            A1.ents += rank_tab[pend[0][1]] + rank_tab[pend[1][1]];
+            A2.ents += rank_tab[pend[0][2]] + rank_tab[pend[1][2]];
             wave_lds_fence();
             const unsigned np_w = wave_total_u32(np);
             {
@@ -341,6 +438,13 @@ __global__ __launch_bounds__(64) void k_glcm(const int *__restrict__ list, const
 #pragma unroll
                 for (int m = 0; m < 7; ++m) e[m] = xlnx_of(lut, hv[m], fs[m]);
                 const double hs32 = e[0], hs64 = e[1] + e[2], hs128 = (e[3] + e[4]) + (e[5] + e[6]);
+                {   // sum s n_s and sum s^2 n_s: word 128 + lane + 64 m holds n_s of s = lane (level 32), lane + 64 (m - 1), lane + 64 (m - 3)
+                    const unsigned s0 = (unsigned)lane, s1 = s0 + 64u, s2 = s0 + 128u, s3 = s0 + 192u;
+                    A0.S1 = s0 * hv[0];                A0.S2 = s0 * s0 * hv[0];
+                    A1.S1 = s0 * hv[1] + s1 * hv[2];   A1.S2 = s0 * s0 * hv[1] + s1 * s1 * hv[2];
+                    A2.S1 = (s0 * hv[3] + s1 * hv[4]) + (s2 * hv[5] + s3 * hv[6]);
+                    A2.S2 = (s0 * s0 * hv[3] + s1 * s1 * hv[4]) + (s2 * s2 * hv[5] + s3 * s3 * hv[6]);
+                }
                 publish(sums_i + (0 * 4 + oi) * GL_NACC, np_w, A0, A0.ents, hx32, hs32, lane);
                 publish(sums_i + (1 * 4 + oi) * GL_NACC, np_w, A1, A1.ents, hx64, hs64, lane);
                 publish(sums_i + (2 * 4 + oi) * GL_NACC, np_w, A2, A2.ents, hx128, hs128, lane);
@@ -348,27 +452,24 @@ __global__ __launch_bounds__(64) void k_glcm(const int *__restrict__ list, const
             wave_lds_fence();
             // ================= pass B: level 254 ===================================================================
             // histogram words: hx 0..253 | hs 256..762
-            unsigned pend3 = 0u;
+            unsigned pend3[2] = {0u, 0u};
 #pragma unroll 1
-            for (int e = lane; e < K; e += 64) {
-                const double ev3 = rank_tab[pend3];
-                pend3 = 0u;
-                const unsigned pos = s_pos[e];
-                const unsigned a = s_q[e] >> 24;
-                const int r = (int)(pos >> 8), c = (int)(pos & 255u);
-                const int c2 = c + dx, cb = c - dx;
-                const uint64_t w2 = s_rows1[r + 1 + dy], wb = s_rows1[r + 1 - dy];
-                const bool fwd = (unsigned)c2 < (unsigned)ps && ((w2 >> (c2 & 63)) & 1ull);
-                const bool bwd = (unsigned)cb < (unsigned)ps && ((wb >> (cb & 63)) & 1ull);
-                const unsigned deg = (fwd ? 1u : 0u) + (bwd ? 1u : 0u);
-                if (deg) atomicAdd(&s_hist[a], deg);
-                if (fwd) {
-                    const unsigned b = s_q[s_rowstart[r + dy] + (unsigned)__popcll(w2 & ((1ull << c2) - 1ull))] >> 24;
-                    pend3 = pair_sums(a, b, hash_rank<LOG2SLOTS>(s_tab, tri_index(a, b)), s_hist + 256, A3);
-                }
-                A3.ents += ev3;
+            for (int e = lane; e < K; e += 128) {
+                const double ev30 = rank_tab[pend3[0]], ev31 = rank_tab[pend3[1]];
+                const Located X = relocate(e, true, s_q, s_memo);
+                const Located Y = relocate(e + 64, e + 64 < K, s_q, s_memo);
+                const unsigned xa = X.qa & 255u, xb = X.qb & 255u, ya = Y.qa & 255u, yb = Y.qb & 255u;
+                atomicAdd(&s_hist[xa], X.deg);
+                atomicAdd(&s_hist[ya], Y.deg);
+                atomicAdd(&s_hist[256 + xa + xb], X.fwd ? 1u : 0u);
+                atomicAdd(&s_hist[256 + ya + yb], Y.fwd ? 1u : 0u);
+                unsigned rx, ry;
+                hash_rank2<LOG2SLOTS>(s_tab, s_dummy + lane, cell_key(xa, xb), X.fwd, cell_key(ya, yb), Y.fwd, rx, ry);
+                pend3[0] = pair_acc(X.fwd, xa, xb, rx, A3);
+                pend3[1] = pair_acc(Y.fwd, ya, yb, ry, A3);
+                A3.ents += ev30 + ev31;
             }
-            A3.ents += rank_tab[pend3];
+            A3.ents += rank_tab[pend3[0]] + rank_tab[pend3[1]];
             wave_lds_fence();
             {
                 unsigned hv[12];
@@ -381,6 +482,9 @@ __global__ __launch_bounds__(64) void k_glcm(const int *__restrict__ list, const
                 double e[12];
 #pragma unroll
                 for (int m = 0; m < 12; ++m) e[m] = xlnx_of(lut, hv[m], fs[m]);
+                A3.S1 = 0u; A3.S2 = 0u;
+#pragma unroll
+                for (int m = 4; m < 12; ++m) { const unsigned sv = (unsigned)lane + 64u * (unsigned)(m - 4); A3.S1 += sv * hv[m]; A3.S2 += sv * sv * hv[m]; }
                 const double hx = (e[0] + e[1]) + (e[2] + e[3]);
                 const double hs = ((e[4] + e[5]) + (e[6] + e[7])) + ((e[8] + e[9]) + (e[10] + e[11]));
                 publish(sums_i + (3 * 4 + oi) * GL_NACC, np_w, A3, A3.ents, hx, hs, lane);
