@@ -11,6 +11,7 @@
 #include <math.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define NFX_HD __host__ __device__ __forceinline__
 #else
 #define NFX_HD inline

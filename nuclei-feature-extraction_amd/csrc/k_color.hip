@@ -18,6 +18,7 @@
 //                second pass over the pixels).
 //   Blocks of one reference batch share blockIdx % 8, i.e. one XCD, so the batch's S/C images are
 //   served by that XCD's L2 to all of its nuclei.
+#include "exact_div.h"
 #include "nfx_internal.h"
 #include "wave_ops.h"
 
@@ -25,7 +26,7 @@ namespace nfx {
 
 template <typename T> struct Px;
 template <> struct Px<uint8_t> {
-    static __device__ __forceinline__ float ld(const uint8_t *p, size_t i) { return (float)p[i] / 255.0f; } // utils.rs:172
+    static __device__ __forceinline__ float ld(const uint8_t *p, size_t i) { return u8_unit(p[i]); } // utils.rs:172 (exact_div.h)
 };
 template <> struct Px<float> {
     static __device__ __forceinline__ float ld(const float *p, size_t i) { return p[i]; }
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void k_hue_batch(int64_t n, int ps, int batch_
                          b4 = *reinterpret_cast<const uchar4 *>(pb + 2 * P + px);
             const uint8_t rr[4] = {r4.x, r4.y, r4.z, r4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) { r[q] = (float)rr[q] / 255.0f; g[q] = (float)gg[q] / 255.0f; bl[q] = (float)bb[q] / 255.0f; }
+            for (int q = 0; q < VEC; ++q) { r[q] = u8_unit(rr[q]); g[q] = u8_unit(gg[q]); bl[q] = u8_unit(bb[q]); }
         } else {
 #pragma unroll
             for (int q = 0; q < VEC; ++q) { r[q] = Px<T>::ld(p, px + q); g[q] = Px<T>::ld(p, P + px + q); bl[q] = Px<T>::ld(p, 2 * P + px + q); }
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
             unsigned b0 = 0, b1 = 0, b2 = 0;
             if (sizeof(T) == 1) {
                 b0 = sp[p]; b1 = sp[P + p]; b2 = sp[2 * P + p];
-                x[0] = (float)b0 / 255.0f; x[1] = (float)b1 / 255.0f; x[2] = (float)b2 / 255.0f; // utils.rs:172
+                x[0] = u8_unit(b0); x[1] = u8_unit(b1); x[2] = u8_unit(b2); // utils.rs:172
             } else {
                 x[0] = Px<T>::ld(pp, p);
                 x[1] = Px<T>::ld(pp, P + p);

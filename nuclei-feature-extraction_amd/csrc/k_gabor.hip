@@ -25,6 +25,7 @@
 #include <cstring>
 #include <vector>
 
+#include "exact_div.h"
 #include "nfx_internal.h"
 #include "wave_ops.h"
 
@@ -59,7 +60,7 @@ struct GaborTables {
 
 template <typename T> struct BPx;
 template <> struct BPx<uint8_t> {
-    static __device__ __forceinline__ float ld(const uint8_t *p, size_t i) { return (float)p[i] / 255.0f; }
+    static __device__ __forceinline__ float ld(const uint8_t *p, size_t i) { return u8_unit(p[i]); }
 };
 template <> struct BPx<float> {
     static __device__ __forceinline__ float ld(const float *p, size_t i) { return p[i]; }
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
             for (int p = t; p < P; p += GB_THREADS) {
                 float gs = BPx<T>::ld(pp, p) + BPx<T>::ld(pp, P + p);
                 gs = gs + BPx<T>::ld(pp, 2 * P + p);
-                gs = gs / 3.0f; // texture.rs:332
+                gs = sizeof(T) == 1 ? third_of_u8_sum(gs) : gs / 3.0f; // texture.rs:332
                 s_g[r * gw + c + GB_PAD] = gs;
                 if ((s_rows[r] >> c) & 1ull) gsum += gs;
                 c += dc; r += dr;

@@ -18,6 +18,7 @@
 // The 17 features are weighted sums over the bins: with bin = lane + 64k a lane always sees the same run
 // length l = lane % 16 and six fixed gray levels, so every weight is a register computed once per kernel;
 // row/column sums for the non-uniformity features are 16-lane / 4-lane butterfly reductions.
+#include "exact_div.h"
 #include "nfx_internal.h"
 #include "wave_ops.h"
 
@@ -28,7 +29,7 @@ __constant__ int kRlDirs[4][2] = {{1, 0}, {1, 1}, {0, 1}, {-1, 1}};             
 
 template <typename T> struct RPx;
 template <> struct RPx<uint8_t> {
-    static __device__ __forceinline__ float ld(const uint8_t *p, size_t i) { return (float)p[i] / 255.0f; }
+    static __device__ __forceinline__ float ld(const uint8_t *p, size_t i) { return u8_unit(p[i]); }
 };
 template <> struct RPx<float> {
     static __device__ __forceinline__ float ld(const float *p, size_t i) { return p[i]; }
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
                     const int p = r * ps + lane;
                     float gs = RPx<T>::ld(pp, p) + RPx<T>::ld(pp, P + p);
                     gs = gs + RPx<T>::ld(pp, 2 * P + p);
-                    gs = gs / 3.0f;
+                    gs = sizeof(T) == 1 ? third_of_u8_sum(gs) : gs / 3.0f;
                     int qi = (int)floorf(gs * (float)RL_LEVELS);
                     qi = qi < 0 ? 0 : (qi > RL_LEVELS - 1 ? RL_LEVELS - 1 : qi);
                     q = (unsigned)qi;
