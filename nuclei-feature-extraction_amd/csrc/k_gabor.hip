@@ -47,13 +47,15 @@ static constexpr int GB_MAX_GROUPS = 16, GB_MAX_FILTERS = 24, GB_MAX_PASSES = 3;
 static constexpr int GB_WSLOT = 64;                            // one pass: 30 weight pairs padded to 32 float2
 static constexpr int GB_WBUF = GB_WSLOT * (1 + GB_MAX_PASSES); // row pass + up to three column passes
 
+static constexpr int GB_META = 60;                             // spare floats 60..63 of a slot hold the group's / pass's metadata
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct GaborGroup {
     int n_pass, pad0, pad1, pad2;
     int combine[4];            // per column pass: 0 -> responses (accA, accB); 1 -> (accA - accB, accA + accB)
     int filt[4][2];            // per column pass: the two filter slots its responses belong to (-1: none)
-    float image[GB_WBUF];      // the group's taps exactly as they sit in LDS: [row (ra,rb) x 32 | pass0 (ca,cb) x 32 | pass1 | pass2]
+    float image[GB_WBUF];      // the group exactly as it sits in LDS: [row (ra,rb) x 30, n_pass | pass0 (ca,cb) x 30, dc0, dc1, meta | pass1 | pass2]
 };
 struct GaborFilter {
     int ch0, ch1;
@@ -97,9 +99,9 @@ static __device__ __forceinline__ double bsum(double v)
 // (every lane reads the same address: a broadcast).  Tap-major order, pinned: the TS packed FMAs of one tap hit TS
 // different accumulators (independent, back-to-back issue); left alone, the scheduler serialises all 30 taps of
 // one accumulator into a dependent chain.
-// The pairs are fetched six taps at a time, one block ahead of their use, so only two blocks (24 registers, not 64)
+// The pairs are fetched two taps (one 16-byte read) at a time, one block ahead of their use, so only two blocks (8 registers, not 64)
 // are live and the LDS latency of the next block hides behind the current block's FMAs.
-static constexpr int GB_TBLK = 6, GB_NBLK = GB_SIZE / GB_TBLK;
+static constexpr int GB_TBLK = 2, GB_NBLK = GB_SIZE / GB_TBLK;
 
 static __device__ __forceinline__ void load_tap_block(const float *w, int blk, f2 (&wr)[GB_TBLK])
 {
@@ -115,12 +117,12 @@ static __device__ __forceinline__ void load_tap_block(const float *w, int blk, f
 // PAIRWIN = false: row pass, one gray window, two kernels: (a, b)[o] = sum_j (ra, rb)[j] * x[o + j]
 // PAIRWIN = true:  column pass, a window of plane pairs:   (accA, accB)[o] = sum_j (ca, cb)[j] * (a, b)[o + j]
 template <int TS, typename X>
-static __device__ __forceinline__ void taps2(const X (&x)[TS + GB_SIZE - 1], const float *w, f2 (&acc)[TS])
+static __device__ __forceinline__ void taps2(const X (&x)[TS + GB_SIZE - 1], const float *w, f2 init, f2 (&acc)[TS])
 {
     f2 wr[2][GB_TBLK];
     load_tap_block(w, 0, wr[0]);
 #pragma unroll
-    for (int o = 0; o < TS; ++o) acc[o] = (f2){0.0f, 0.0f};
+    for (int o = 0; o < TS; ++o) acc[o] = init;
 #pragma unroll
     for (int blk = 0; blk < GB_NBLK; ++blk) {
         if (blk + 1 < GB_NBLK) load_tap_block(w, blk + 1, wr[(blk + 1) & 1]);
@@ -146,78 +148,116 @@ struct GaborShared {
     const uint64_t *rows;
 };
 
-// One group (one row pass + its column passes) with strip size TS: wave w owns column strip w of the row pass
-// and row strip w of the column passes, so each pass is exactly one round for every wave.
+// All groups of one nucleus with strip size TS: wave w owns column strip w of every row pass and row strip w of
+// every column pass, so each pass is exactly one round for every wave.  No lane-divergent branches: lanes outside the
+// bounding box duplicate their neighbour's work (row pass: same values to the same address) or carry an all-zero
+// mask (column pass), which keeps every FMA block in one basic block.  Everything that does not depend on the group
+// (window addresses, the strip's mask bits) is set up once; everything that does (taps, DC gains, filter slots,
+// number of passes) sits in the group's LDS image, so the loop issues no scalar loads.
 template <int TS>
-static __device__ __forceinline__ void gabor_group(const GaborShared &S, const GaborTables *__restrict__ tab, int g, int ps,
-                                                   int gw, int rlo, int nrow_rp, int rmin, int rmax, int cmin, int cmax,
-                                                   float mu_gray, int lane, int wv, float (&s1)[6], float (&s2)[6], int dbg)
+static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const GaborTables *__restrict__ tab, int n_groups, int ps,
+                                                     int gw, int rlo, int nrow_rp, int rmin, int rmax, int cmin, int cmax,
+                                                     float mu_gray, uint64_t wrow, int t, float (*s_wt)[GB_WBUF], int &buf,
+                                                     double (*s_part)[GB_MAX_FILTERS][2], int dbg)
 {
     constexpr int WIN = TS + GB_SIZE - 1;
-    const GaborGroup &G = tab->groups[g];
-    // ---- row pass: lanes run along rows (LDS stride gw, odd), the wave's strip along columns ----------------
+    const int lane = t & 63, wv = t >> 6;
+    // row pass geometry: lanes run along rows (LDS stride gw, odd), the wave's strip along columns
+    const int c0 = cmin + wv * TS;
+    const bool rstrip = c0 <= cmax && !(dbg & 1); // wave-uniform
+    const int rr = rlo + (lane < nrow_rp ? lane : nrow_rp - 1);
+    int c0c = c0 < ps - TS ? c0 : ps - TS; // keep the window inside the apron row
+    c0c = c0c > 0 ? c0c : 0;
+    const float *src = &S.g[rr * gw + c0c]; // gray column c-15 sits at apron index c
+    f2 *du = &S.UW[(rr + GB_PAD) * GB_UW + c0c];
+    // column pass geometry: lanes run along columns, the wave's strip along rows
+    const int r0 = rmin + wv * TS;
+    const bool cstrip = r0 <= rmax && !(dbg & 2); // wave-uniform
+    const int c = cmin + lane <= cmax ? cmin + lane : cmax;
+    int r0c = r0 < ps - TS ? r0 : ps - TS; // clamped strips overlap: rows below r0 are masked out
+    r0c = r0c > 0 ? r0c : 0;
+    const f2 *su = &S.UW[r0c * GB_UW + c]; // row (r0c - 15) + 15
+    unsigned mbits = 0; // bit q: pixel (r0c + q, c) is in the mask and belongs to this strip
     {
-        const int c0 = cmin + wv * TS;
-        if (c0 <= cmax && lane < nrow_rp && !(dbg & 1)) {
-            const int r = rlo + lane;
-            int c0c = c0 < ps - TS ? c0 : ps - TS; // keep the window inside the apron row
-            c0c = c0c > 0 ? c0c : 0;
-            const float *src = &S.g[r * gw + c0c]; // gray column c-15 sits at apron index c
+        const unsigned wlo = (unsigned)wrow, whi = (unsigned)(wrow >> 32); // lane l holds mask row l
+#pragma unroll
+        for (int q = 0; q < TS; ++q) {
+            const int R = (r0c + q) & 63;
+            const uint64_t row = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)whi, R) << 32) | (unsigned)__builtin_amdgcn_readlane((int)wlo, R);
+            if (r0c + q >= r0) mbits |= (unsigned)((row >> c) & 1ull) << q;
+        }
+        if (cmin + lane > cmax) mbits = 0u;
+    }
+
+    for (int g = 0; g < ((dbg & 4) ? 0 : n_groups); ++g) {
+        __syncthreads(); // taps (and, for g = 0, gray) visible; every wave has left the previous group's column passes
+        const float *wt = s_wt[buf];
+        // the taps are the same for every nucleus: group g+1's image is fetched into registers while group g runs and
+        // put down in the other buffer afterwards, wrapping around to group 0 for the next nucleus
+        const int gn = g + 1 < n_groups ? g + 1 : 0;
+        float4 wnext = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (t < GB_WBUF / 4) wnext = reinterpret_cast<const float4 *>(tab->groups[gn].image)[t];
+        // ---- row pass ---------------------------------------------------------------------------------------------
+        if (rstrip) {
             float x[WIN];
             f2 acc[TS];
 #pragma unroll
             for (int j = 0; j < WIN; ++j) x[j] = src[j];
-            taps2<TS, float>(x, S.wt, acc);
-            f2 *du = &S.UW[(r + GB_PAD) * GB_UW + c0c];
-            // unconditional stores (c0c <= ps - TS keeps them inside the row; for ps < TS they land in the row's unused
-            // tail): a guarded store makes the compiler sink each output's 30 FMAs into its own branch -- one
-            // dependent chain per output instead of TS independent ones
+            taps2<TS, float>(x, wt, (f2){0.0f, 0.0f}, acc);
+            // unconditional stores (c0c <= ps - TS keeps them inside the row; for ps < TS they land in the row's unused tail)
 #pragma unroll
             for (int q = 0; q < TS; ++q) du[q] = acc[q];
         }
-    }
-    __syncthreads();
-    // ---- column passes: lanes run along columns, the wave's strip along rows -----------------------------------
-    {
-        const int r0 = rmin + wv * TS;
-        const int c = cmin + lane;
-        if (r0 <= rmax && c <= cmax && !(dbg & 2)) {
-            int r0c = r0 < ps - TS ? r0 : ps - TS; // clamped strips overlap: rows below r0 are masked out
-            r0c = r0c > 0 ? r0c : 0;
-            unsigned mbits = 0;
+        __syncthreads();
+        // ---- column passes ------------------------------------------------------------------------------------------
+        const int n_pass = __float_as_int(wt[GB_META]);
+        f2 x[WIN];
+        if (cstrip) {
 #pragma unroll
-            for (int q = 0; q < TS; ++q)
-                if (r0c + q >= r0) mbits |= (unsigned)((S.rows[r0c + q] >> c) & 1ull) << q;
-            if (mbits != 0u) {
-                f2 x[WIN];
-                const f2 *su = &S.UW[r0c * GB_UW + c]; // row (r0c - 15) + 15
+            for (int j = 0; j < WIN; ++j) x[j] = su[j * GB_UW];
+        }
+#pragma unroll 1
+        for (int p = 0; p < n_pass; ++p) {
+            const float *wp = wt + (1 + p) * GB_WSLOT;
+            const int meta = __float_as_int(wp[GB_META + 2]); // combine | slot0 << 8 | slot1 << 16 (255: none)
+            f2 a = {0.0f, 0.0f}, b = {0.0f, 0.0f};
+            if (cstrip) {
+                f2 acc[TS];
+                const float sh0 = wp[GB_META] * mu_gray, sh1 = wp[GB_META + 1] * mu_gray; // DC gain x mean masked gray
+                // the accumulators start at minus the shift (for the mixed pair: A - B starts at -sh0, A + B at -sh1), so
+                // the responses come out already shifted; masked partial sums of the strip's TS responses follow (f32
+                // inside the strip and the wave, f64 across waves)
+                if (meta & 1) {
+                    taps2<TS, f2>(x, wp, (f2){-0.5f * (sh0 + sh1), 0.5f * (sh0 - sh1)}, acc);
 #pragma unroll
-                for (int j = 0; j < WIN; ++j) x[j] = su[j * GB_UW];
+                    for (int q = 0; q < TS; ++q) {
+                        const float mq = ((mbits >> q) & 1u) ? 1.0f : 0.0f; // the mask as a 0/1 factor: packed multiply
+                        const f2 d = (f2){acc[q].x - acc[q].y, acc[q].x + acc[q].y} * (f2){mq, mq};
+                        a += d;
+                        b = __builtin_elementwise_fma(d, d, b);
+                    }
+                } else {
+                    taps2<TS, f2>(x, wp, (f2){-sh0, -sh1}, acc);
 #pragma unroll
-                for (int p = 0; p < GB_MAX_PASSES; ++p) {
-                    if (p < G.n_pass) {
-                        f2 acc[TS];
-                        taps2<TS, f2>(x, S.wt + (1 + p) * GB_WSLOT, acc);
-                        const int f0 = G.filt[p][0], f1 = G.filt[p][1];
-                        const f2 shift = {f0 >= 0 ? tab->filters[f0].dc * mu_gray : 0.0f, f1 >= 0 ? tab->filters[f1].dc * mu_gray : 0.0f};
-                        const bool mix = G.combine[p] != 0;
-                        // masked, shifted partial sums of the strip's TS responses (f32 inside the strip and the wave, f64 across waves)
-                        f2 a = {0.0f, 0.0f}, b = {0.0f, 0.0f};
-#pragma unroll
-                        for (int q = 0; q < TS; ++q) {
-                            const f2 v = mix ? (f2){acc[q].x - acc[q].y, acc[q].x + acc[q].y} : acc[q];
-                            const float mq = ((mbits >> q) & 1u) ? 1.0f : 0.0f; // the mask as a 0/1 factor: packed multiply
-                            const f2 d = (v - shift) * (f2){mq, mq};
-                            a += d;
-                            b = __builtin_elementwise_fma(d, d, b);
-                        }
-                        // every wave runs exactly one strip per pass: the strip's sums ARE the lane's sums
-                        s1[2 * p] = a.x; s2[2 * p] = b.x;
-                        s1[2 * p + 1] = a.y; s2[2 * p + 1] = b.y;
+                    for (int q = 0; q < TS; ++q) {
+                        const float mq = ((mbits >> q) & 1u) ? 1.0f : 0.0f;
+                        const f2 d = acc[q] * (f2){mq, mq};
+                        a += d;
+                        b = __builtin_elementwise_fma(d, d, b);
                     }
                 }
             }
+            // every wave runs exactly one strip per pass; each lane holds shifted sums (small numbers), so an f32 wave
+            // reduction is exact enough
+            const float a0 = wave_total_f32(a.x), b0 = wave_total_f32(b.x), a1 = wave_total_f32(a.y), b1 = wave_total_f32(b.y);
+            if (lane == 0) {
+                const int f0 = (meta >> 8) & 255, f1 = (meta >> 16) & 255;
+                if (f0 != 255) { s_part[wv][f0][0] = (double)a0; s_part[wv][f0][1] = (double)b0; }
+                if (f1 != 255) { s_part[wv][f1][0] = (double)a1; s_part[wv][f1][1] = (double)b1; }
+            }
         }
+        buf ^= 1; // the other buffer was last read by group g-1, which every wave left before this iteration's first barrier
+        if (t < GB_WBUF / 4) reinterpret_cast<float4 *>(s_wt[buf])[t] = wnext;
     }
 }
 
@@ -231,7 +271,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
     __shared__ float s_g[NFX_MAX_PATCH_SIZE * GB_GW + 16];
     __shared__ f2 s_UW[GB_UH * GB_UW]; // plane pair; row r lives at index r + GB_PAD; aprons stay zero
     __shared__ uint64_t s_rows[64 + 16];
-    __shared__ double s_part[4][24][2];
+    __shared__ double s_part[4][GB_MAX_FILTERS][2];
     __shared__ float s_gsum[4];
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -239,19 +279,40 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
     const int gw = ps + GB_SIZE - 1;
     for (int k = t; k < NFX_MAX_PATCH_SIZE * GB_GW + 16; k += GB_THREADS) s_g[k] = 0.0f; // apron stays zero
     for (int k = t; k < GB_UH * GB_UW; k += GB_THREADS) s_UW[k] = (f2){0.0f, 0.0f};
-    for (int k = t; k < 2 * GB_WBUF; k += GB_THREADS) (&s_wt[0][0])[k] = 0.0f;
     if (t < 64 + 16) s_rows[t] = 0ull;
-    __syncthreads();
     const int n_groups = tab->n_groups, n_filters = tab->n_filters;
+    int buf = 0;
+    if (t < GB_WBUF / 4) reinterpret_cast<float4 *>(s_wt[0])[t] = reinterpret_cast<const float4 *>(tab->groups[0].image)[t];
+    __syncthreads();
     GaborShared S;
     S.g = s_g; S.UW = s_UW; S.rows = s_rows;
+    // u8 patches whose rows are whole 16-byte pieces come in with one 16-byte load per channel and thread
+    const bool vec = sizeof(T) == 1 && (ps & 15) == 0 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0;
 
     for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
         if (t < 64) s_rows[t] = t < ps ? mask_rows[i * ps + t] : 0ull;
         __syncthreads();
         const T *pp = patches + (size_t)i * 3 * P;
         float gsum = 0.0f; // masked gray sum -> the shift that keeps the f32 partial sums well conditioned
-        {
+        if (vec) {
+            for (int k = t; k < P / 16; k += GB_THREADS) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(pp) + k;
+                const uint4 r4 = src[0], g4 = src[P / 16], b4 = src[2 * (P / 16)];
+                const unsigned rr[4] = {r4.x, r4.y, r4.z, r4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                const int p0 = 16 * k, r = p0 / ps, c0 = p0 - r * ps;
+                const unsigned mrow = (unsigned)(s_rows[r] >> c0) & 0xFFFFu;
+                float *dst = &s_g[r * gw + c0 + GB_PAD];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int sh = 8 * (q & 3);
+                    float gs = u8_unit((rr[q >> 2] >> sh) & 255u) + u8_unit((gg[q >> 2] >> sh) & 255u); // utils.rs:172
+                    gs = gs + u8_unit((bb[q >> 2] >> sh) & 255u);
+                    gs = third_of_u8_sum(gs); // texture.rs:332
+                    dst[q] = gs;
+                    gsum += ((mrow >> q) & 1u) ? gs : 0.0f;
+                }
+            }
+        } else {
             int r = t / ps, c = t - r * ps;
             const int dr = GB_THREADS / ps, dc = GB_THREADS - dr * ps;
             for (int p = t; p < P; p += GB_THREADS) {
@@ -264,8 +325,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
                 if (c >= ps) { c -= ps; r += 1; }
             }
         }
-        gsum = (float)bsum((double)gsum);
-        if (lane == 0) s_gsum[wv] = gsum;
+        gsum = wave_total_f32(gsum);
         // mask bounding box and area: lane r looks at row r, the wave votes
         const uint64_t wrow = s_rows[lane];
         const uint64_t rowsany = __ballot(wrow != 0ull);
@@ -287,31 +347,18 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
         const int rhi = rmax + (GB_SIZE - 1 - GB_PAD) < ps - 1 ? rmax + (GB_SIZE - 1 - GB_PAD) : ps - 1;
         const int nrow_rp = rhi - rlo + 1;
         const int span = ncol > nrow ? ncol : nrow;   // both passes use the same strip size
-        // group 0's taps -> buffer 0 (the barrier inside the first gabor_group call is too late for the row pass,
-        // so this load is followed by its own barrier, which also publishes s_g and s_gsum)
-        for (int g = 0; g < ((dbg & 4) ? 0 : n_groups); ++g) {
-            const GaborGroup &G = tab->groups[g];
-            float *wt = s_wt[g & 1];
-            if (t < GB_WBUF / 4) reinterpret_cast<float4 *>(wt)[t] = reinterpret_cast<const float4 *>(G.image)[t];
-            __syncthreads(); // taps visible; every wave has left the previous group's column pass (U/W reusable)
-            const float mu_gray = (s_gsum[0] + s_gsum[1] + s_gsum[2] + s_gsum[3]) / (float)area;
-            S.wt = wt;
-            float s1[6], s2[6];
-#pragma unroll
-            for (int f = 0; f < 6; ++f) { s1[f] = 0.0f; s2[f] = 0.0f; }
-            if (span <= 32) gabor_group<8>(S, tab, g, ps, gw, rlo, nrow_rp, rmin, rmax, cmin, cmax, mu_gray, lane, wv, s1, s2, dbg);
-            else if (span <= 48) gabor_group<12>(S, tab, g, ps, gw, rlo, nrow_rp, rmin, rmax, cmin, cmax, mu_gray, lane, wv, s1, s2, dbg);
-            else gabor_group<16>(S, tab, g, ps, gw, rlo, nrow_rp, rmin, rmax, cmin, cmax, mu_gray, lane, wv, s1, s2, dbg);
-#pragma unroll
-            for (int f = 0; f < 6; ++f) {
-                const int slot = (f >> 1) < G.n_pass ? G.filt[f >> 1][f & 1] : -1;
-                if (slot >= 0) {
-                    // each lane holds one strip's shifted sums (small numbers): an f32 wave reduction is exact enough
-                    const float a = wave_total_f32(s1[f]), b = wave_total_f32(s2[f]);
-                    if (lane == 0) { s_part[wv][slot][0] = (double)a; s_part[wv][slot][1] = (double)b; }
-                }
-            }
-        }
+        if (lane == 0) s_gsum[wv] = gsum;
+        __syncthreads();
+        const float mu_gray = (s_gsum[0] + s_gsum[1] + s_gsum[2] + s_gsum[3]) / (float)area;
+#define NFX_GB_CALL(TS) gabor_nucleus<TS>(S, tab, n_groups, ps, gw, rlo, nrow_rp, rmin, rmax, cmin, cmax, mu_gray, wrow, t, s_wt, buf, s_part, dbg)
+        // four strips of the smallest even size that covers the bounding box: every wave has work in every pass
+        if (span <= 24) NFX_GB_CALL(6);
+        else if (span <= 32) NFX_GB_CALL(8);
+        else if (span <= 40) NFX_GB_CALL(10);
+        else if (span <= 48) NFX_GB_CALL(12);
+        else if (span <= 56) NFX_GB_CALL(14);
+        else NFX_GB_CALL(16);
+#undef NFX_GB_CALL
         __syncthreads();
         // ---- mean / variance (texture.rs:339-344) from the shifted sums: mean = c + s1/K, var = s2/K - (s1/K)^2 -----
         if (t < n_filters) {
@@ -436,6 +483,18 @@ static void build_tables(GaborTables &T)
         }
     }
     for (auto &u : uniq) ok = ok && u.placed;
+    for (int g = 0; g < ng; ++g) { // metadata the kernel reads from the LDS image
+        GaborGroup &G = T.groups[g];
+        memcpy(&G.image[GB_META], &G.n_pass, sizeof(int));
+        for (int p = 0; p < G.n_pass; ++p) {
+            float *slot = &G.image[(1 + p) * GB_WSLOT + GB_META];
+            const int f0 = G.filt[p][0], f1 = G.filt[p][1];
+            slot[0] = f0 >= 0 ? T.filters[f0].dc : 0.0f;
+            slot[1] = f1 >= 0 ? T.filters[f1].dc : 0.0f;
+            const int meta = (G.combine[p] ? 1 : 0) | ((f0 >= 0 ? f0 : 255) << 8) | ((f1 >= 0 ? f1 : 255) << 16);
+            memcpy(&slot[2], &meta, sizeof(int));
+        }
+    }
     T.n_groups = ok ? ng : GB_MAX_GROUPS + 1;
 }
 
