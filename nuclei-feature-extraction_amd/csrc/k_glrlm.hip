@@ -7,9 +7,12 @@
 //
 // ONE WAVEFRONT PER NUCLEUS (persistent, grid-stride; four independent waves per workgroup, each with a
 // private LDS slice and no s_barrier -- a wave's LDS ops execute in order).  Runs are found BIT-PARALLEL:
-//   * staging (lane = column, coalesced): the 24-level value of every masked pixel goes to an LDS byte map,
-//     and for each of the four directions a ballot builds the row's "continues its predecessor" word
-//     C_d[r] (pixel and predecessor in the mask with equal level), filed under lane r;
+//   * staging: u8 patches arrive as 16-byte pieces (lane L owns the 16 pixels of piece L + 64k in all three
+//     channels; the NEXT nucleus's pieces are requested before the current ones are used, so HBM latency hides
+//     behind a whole nucleus), are quantised to 24 levels in registers and written to an LDS byte map with 0xFF
+//     outside the mask; then (lane = column) for each of the four directions a ballot builds the row's
+//     "continues its predecessor" word C_d[r] (pixel and predecessor in the mask with equal level), filed
+//     under lane r;
 //   * per direction (lane = row): run starts are S = M & ~C.  Step k ANDs in the C word of the row k steps
 //     ahead (a one-lane shuffle), shifted by k*dx bits: what survives are the starts whose run is longer
 //     than k.  A 4-bit bit-sliced counter accumulates the survivors, so after <=15 steps every start
@@ -45,10 +48,31 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
     constexpr int QS = 68; // byte-map row stride: lane = row reads of one column spread over the banks
     __shared__ uint8_t s_q_all[4][NFX_MAX_PATCH_SIZE * QS];
     __shared__ unsigned s_R_all[4][RL_BINS];
+    __shared__ uint64_t s_rows_all[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint8_t *s_q = s_q_all[wv];
     unsigned *s_R = s_R_all[wv];
+    uint64_t *s_rows = s_rows_all[wv];
     const int P = ps * ps;
+    // vector staging: rows are whole 16-byte pieces, every patch starts on a 16-byte boundary
+    constexpr int NPC = NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE / 16 / 64; // pieces per lane and channel (4)
+    const bool vec = sizeof(T) == 1 && (ps & 15) == 0 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0;
+    const int npieces = P / 16;
+    uint4 pre[3][NPC];
+    uint64_t row_next = 0ull;
+    auto request = [&](int64_t i) {
+        row_next = lane < ps ? mask_rows[i * ps + lane] : 0ull;
+        if (vec) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(patches + (size_t)i * 3 * P);
+#pragma unroll
+            for (int k = 0; k < NPC; ++k)
+                if (lane + 64 * k < npieces) {
+                    pre[0][k] = src[lane + 64 * k];
+                    pre[1][k] = src[npieces + lane + 64 * k];
+                    pre[2][k] = src[2 * npieces + lane + 64 * k];
+                }
+        }
+    };
 
     // per-lane constant weights: l = lane%16 + 1, g_k = lane/16 + 4k + 1
     const double l = (double)((lane & 15) + 1);
@@ -68,9 +92,49 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
     for (int k = 0; k < 6; ++k) s_R[lane + 64 * k] = 0u;
     wave_lds_fence();
 
-    for (int64_t i = (int64_t)blockIdx.x * 4 + wv; i < n; i += (int64_t)gridDim.x * 4) {
-        const uint64_t myrow = lane < ps ? mask_rows[i * ps + lane] : 0ull;
+    const int64_t istep = (int64_t)gridDim.x * 4;
+    if ((int64_t)blockIdx.x * 4 + wv < n) request((int64_t)blockIdx.x * 4 + wv);
+#pragma unroll 1
+    for (int64_t i = (int64_t)blockIdx.x * 4 + wv; i < n; i += istep) {
+        const uint64_t myrow = row_next;
         const uint64_t anyrow = __ballot(myrow != 0ull);
+        if (vec) {
+            // quantise this lane's pieces and put the levels down (0xFF outside the mask), then ask for the next nucleus
+            s_rows[lane] = myrow;
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < NPC; ++k) {
+                const int piece = lane + 64 * k;
+                if (piece < npieces) {
+                    const int p0 = 16 * piece, r = p0 / ps, c0 = p0 - r * ps;
+                    const unsigned mrow = (unsigned)(s_rows[r] >> c0) & 0xFFFFu;
+                    const unsigned rr[4] = {pre[0][k].x, pre[0][k].y, pre[0][k].z, pre[0][k].w};
+                    const unsigned gg[4] = {pre[1][k].x, pre[1][k].y, pre[1][k].z, pre[1][k].w};
+                    const unsigned bb[4] = {pre[2][k].x, pre[2][k].y, pre[2][k].z, pre[2][k].w};
+                    unsigned packed[4];
+#pragma unroll
+                    for (int w4 = 0; w4 < 4; ++w4) {
+                        unsigned word = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const int sh = 8 * b;
+                            float gs = u8_unit((rr[w4] >> sh) & 255u) + u8_unit((gg[w4] >> sh) & 255u); // utils.rs:172
+                            gs = gs + u8_unit((bb[w4] >> sh) & 255u);
+                            gs = third_of_u8_sum(gs); // texture.rs:189
+                            int qi = (int)floorf(gs * (float)RL_LEVELS);
+                            qi = qi < 0 ? 0 : (qi > RL_LEVELS - 1 ? RL_LEVELS - 1 : qi);
+                            const unsigned lvl = ((mrow >> (4 * w4 + b)) & 1u) ? (unsigned)qi : 0xFFu;
+                            word |= lvl << sh;
+                        }
+                        packed[w4] = word;
+                    }
+                    unsigned *dst = reinterpret_cast<unsigned *>(s_q + r * QS + c0); // QS and c0 are multiples of 4
+                    dst[0] = packed[0]; dst[1] = packed[1]; dst[2] = packed[2]; dst[3] = packed[3];
+                }
+            }
+            wave_lds_fence();
+        }
+        if (i + istep < n) request(i + istep);
         const double Np = (double)wave_total_i32(__popcll(myrow)); // pixel_count, texture.rs:196
         const T *pp = patches + (size_t)i * 3 * P;
 
@@ -82,7 +146,9 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
             unsigned q = 0xFFu;
             if (rowhas) {
                 const uint64_t w = __shfl(myrow, r, 64);
-                if (lane < ps && ((w >> lane) & 1ull)) {
+                if (vec) {
+                    if (lane < ps) q = s_q[r * QS + lane];
+                } else if (lane < ps && ((w >> lane) & 1ull)) {
                     const int p = r * ps + lane;
                     float gs = RPx<T>::ld(pp, p) + RPx<T>::ld(pp, P + p);
                     gs = gs + RPx<T>::ld(pp, 2 * P + p);
