@@ -10,12 +10,14 @@
 //   k_hue_batch  one lane per (reference batch, pixel): S = sum_j sin(hue_j), C = sum_j cos(hue_j)
 //                over every patch j of the batch.  This is the cheap form of the reference's
 //                [N,N,ps,ps] broadcast: nucleus i's circular mean is atan2(mask_i . S, mask_i . C).
-//   k_color      one wavefront per nucleus, lanes = columns of a mask row, only rows that hold mask
-//                pixels are visited.  Pass A dots the mask with S and C (-> mean_h); pass B streams
-//                the patch once, converts RGB->HSV/HED in registers and accumulates sum x and
-//                sum x^2 of nine channels in f64; the variance about the f32-rounded mean is then
-//                sum x^2 - 2 mu sum x + K mu^2 (the two-pass result of color.rs:123-128 without a
-//                second pass over the pixels).
+//   k_color      one wavefront per nucleus.  Pass A (lanes = columns of a mask row, four rows' loads in flight)
+//                dots the mask with S and C (-> mean_h) and, for u8 patches, COMPACTS the masked pixels'
+//                RGB bytes into a per-wave LDS list; pass B then walks the list with every lane busy
+//                (a mask row fills well under half a wave), converts RGB->HSV/HED in registers and
+//                accumulates sum x and sum x^2 of nine channels in f64; the variance about the
+//                f32-rounded mean is then sum x^2 - 2 mu sum x + K mu^2 (the two-pass result of
+//                color.rs:123-128 without a second pass over the pixels).  f32 patches (trait entry)
+//                are read in place, row by row.
 //   Blocks of one reference batch share blockIdx % 8, i.e. one XCD, so the batch's S/C images are
 //   served by that XCD's L2 to all of its nuclei.
 #include "exact_div.h"
@@ -23,6 +25,8 @@
 #include "wave_ops.h"
 
 namespace nfx {
+
+static constexpr int COLOR_LIST_CAP = 2048; // list entries per wave
 
 template <typename T> struct Px;
 template <> struct Px<uint8_t> {
@@ -123,6 +127,24 @@ __global__ __launch_bounds__(256) void k_hue_batch(int64_t n, int ps, int batch_
     }
 }
 
+// nine channels of one pixel: r g b h' s v he eo da (color.rs:45-53)
+template <typename T>
+static __device__ __forceinline__ void pixel_channels(float r, float g, float b, unsigned b0, unsigned b1, unsigned b2, float mh,
+                                                      const float *s_od, float (&x)[9])
+{
+    x[0] = r; x[1] = g; x[2] = b;
+    float h;
+    hsv_from_rgb(r, g, b, h, x[4], x[5]);
+    x[3] = h - mh; // color.rs:52
+    float o0, o1, o2;
+    if (sizeof(T) == 1) {
+        o0 = s_od[b0]; o1 = s_od[b1]; o2 = s_od[b2];
+    } else {
+        o0 = od_f32(r); o1 = od_f32(g); o2 = od_f32(b);
+    }
+    hed_from_od(o0, o1, o2, &x[6]);
+}
+
 // ---- k_color ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size, int64_t n_batches, int blocks_per_batch,
@@ -131,9 +153,7 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
                                                float *__restrict__ out, int F, int col0)
 {
     __shared__ float s_od[256];
-    // u8 patches are staged per wave into LDS with 16-byte coalesced loads: one HBM round trip per nucleus
-    // instead of one per mask row and pass (f32 patches -- the trait entry -- are read in place)
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_patch_all[]; // 4 x round16(3*ps*ps) bytes (u8 only)
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_patch_all[]; // 4 waves x ps*ps list words (u8 only)
     if (sizeof(T) == 1) {
         s_od[threadIdx.x] = od_lut[threadIdx.x];
         __syncthreads();
@@ -151,20 +171,10 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
 
     const int P = ps * ps;
     const T *pp = patches + (size_t)i * 3 * P;
-    const uint8_t *sp = nullptr; // the wave's staged copy (u8 only)
-    if (sizeof(T) == 1) {
-        uint8_t *dst = s_patch_all + (threadIdx.x >> 6) * ((3 * P + 15) & ~15);
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(pp);
-        const int nbytes = 3 * P;
-        if ((nbytes & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-            for (int k = lane; k < nbytes / 16; k += 64)
-                reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(src)[k];
-        } else {
-            for (int k = lane; k < nbytes; k += 64) dst[k] = src[k];
-        }
-        sp = dst;
-        wave_lds_fence();
-    }
+    // u8 only: r | g << 8 | b << 16 per masked pixel; masks beyond the list's capacity (only the largest nuclei of a
+    // 64x64 patch) leave their last pixels to a row-wise tail pass, so the LDS footprint stays at four waves x 8 KB
+    const int cap = P < COLOR_LIST_CAP ? P : COLOR_LIST_CAP;
+    unsigned *s_list = reinterpret_cast<unsigned *>(s_patch_all) + (threadIdx.x >> 6) * cap;
     const uint64_t myrow = lane < ps ? mask_rows[i * ps + lane] : 0ull;
     const int rpi = ps <= 32 ? 2 : 1;          // rows per wave iteration
     const int cw = ps <= 32 ? 32 : 64;         // lanes per row
@@ -174,18 +184,49 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
     const double *S = SC + (size_t)batch * 2 * P;
     const double *Cc = S + P;
 
-    // pass A: K and the circular sums (color.rs:148-152)
+    // pass A: K and the circular sums (color.rs:148-152), and the list of masked pixels.  Four row steps per
+    // iteration, every load issued before the first use: the S/C images come from L2 and the pixel bytes from HBM,
+    // a dependent load per row would cost its latency per row.
     int kcnt = 0;
     double ss = 0.0, cc = 0.0;
-    for (int r0 = 0; r0 < ps; r0 += rpi) {
-        if (((anyrow >> r0) & (rpi == 2 ? 3ull : 1ull)) == 0ull) continue;
-        const int r = r0 + rsub;
-        const uint64_t w = __shfl(myrow, r & 63, 64);
-        if (r < ps && c < ps && ((w >> c) & 1ull)) {
-            const int p = r * ps + c;
-            kcnt += 1;
-            ss += S[p];
-            cc += Cc[p];
+    const int rcnt = __popcll(myrow);
+    int incl = rcnt; // list position of the first pixel of this lane's row = exclusive prefix over the rows
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    const int rowstart = incl - rcnt;
+    {
+        constexpr int U = 4;
+        const int rfirst = anyrow ? (__ffsll((long long)anyrow) - 1) & ~(rpi - 1) : ps;
+        const int rlast = anyrow ? 63 - __clzll((long long)anyrow) : -1;
+        for (int r0 = rfirst; r0 <= rlast; r0 += U * rpi) {
+            double sv[U], cv[U];
+            unsigned px[U];
+            int at[U];
+            bool act[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * rpi + rsub;
+                const uint64_t w = __shfl(myrow, r & 63, 64);
+                act[u] = r < ps && c < ps && ((w >> c) & 1ull);
+                const int pa = act[u] ? r * ps + c : 0;
+                sv[u] = S[pa];
+                cv[u] = Cc[pa];
+                if (sizeof(T) == 1) {
+                    const uint8_t *pb = reinterpret_cast<const uint8_t *>(pp);
+                    px[u] = (unsigned)pb[pa] | ((unsigned)pb[P + pa] << 8) | ((unsigned)pb[2 * P + pa] << 16);
+                    at[u] = __shfl(rowstart, r & 63, 64) + __popcll(w & ((1ull << c) - 1ull));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                kcnt += act[u] ? 1 : 0;
+                ss += act[u] ? sv[u] : 0.0;
+                cc += act[u] ? cv[u] : 0.0;
+                if (sizeof(T) == 1 && act[u] && at[u] < cap) s_list[at[u]] = px[u];
+            }
         }
     }
     const int K = wave_total_i32(kcnt);
@@ -203,37 +244,56 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
     double s1[9], s2[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
-    for (int r0 = 0; r0 < ps; r0 += rpi) {
-        if (((anyrow >> r0) & (rpi == 2 ? 3ull : 1ull)) == 0ull) continue;
-        const int r = r0 + rsub;
-        const uint64_t w = __shfl(myrow, r & 63, 64);
-        if (r < ps && c < ps && ((w >> c) & 1ull)) {
-            const int p = r * ps + c;
+    if (sizeof(T) == 1) {
+        wave_lds_fence();
+        const int Kl = K < cap ? K : cap;
+        if (K > cap) { // tail: pixels that found no room in the list, straight from memory
+            const uint8_t *pb = reinterpret_cast<const uint8_t *>(pp);
+            for (int r0 = 0; r0 < ps; r0 += rpi) {
+                const int r = r0 + rsub;
+                const uint64_t w = __shfl(myrow, r & 63, 64);
+                const int at = __shfl(rowstart, r & 63, 64) + __popcll(w & ((1ull << c) - 1ull));
+                if (r < ps && c < ps && ((w >> c) & 1ull) && at >= cap) {
+                    const int p = r * ps + c;
+                    const unsigned b0 = pb[p], b1 = pb[P + p], b2 = pb[2 * P + p];
+                    float x[9];
+                    pixel_channels<T>(u8_unit(b0), u8_unit(b1), u8_unit(b2), b0, b1, b2, mh, s_od, x);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const double xd = (double)x[k];
+                        s1[k] += xd;
+                        s2[k] += xd * xd;
+                    }
+                }
+            }
+        }
+        for (int e = lane; e < Kl; e += 64) {
+            const unsigned v = s_list[e];
+            const unsigned b0 = v & 255u, b1 = (v >> 8) & 255u, b2 = v >> 16;
             float x[9];
-            unsigned b0 = 0, b1 = 0, b2 = 0;
-            if (sizeof(T) == 1) {
-                b0 = sp[p]; b1 = sp[P + p]; b2 = sp[2 * P + p];
-                x[0] = u8_unit(b0); x[1] = u8_unit(b1); x[2] = u8_unit(b2); // utils.rs:172
-            } else {
-                x[0] = Px<T>::ld(pp, p);
-                x[1] = Px<T>::ld(pp, P + p);
-                x[2] = Px<T>::ld(pp, 2 * P + p);
-            }
-            float h;
-            hsv_from_rgb(x[0], x[1], x[2], h, x[4], x[5]);
-            x[3] = h - mh; // color.rs:52
-            float o0, o1, o2;
-            if (sizeof(T) == 1) {
-                o0 = s_od[b0]; o1 = s_od[b1]; o2 = s_od[b2];
-            } else {
-                o0 = od_f32(x[0]); o1 = od_f32(x[1]); o2 = od_f32(x[2]);
-            }
-            hed_from_od(o0, o1, o2, &x[6]);
+            pixel_channels<T>(u8_unit(b0), u8_unit(b1), u8_unit(b2), b0, b1, b2, mh, s_od, x); // utils.rs:172
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 const double xd = (double)x[k];
                 s1[k] += xd;
                 s2[k] += xd * xd;
+            }
+        }
+    } else {
+        for (int r0 = 0; r0 < ps; r0 += rpi) {
+            if (((anyrow >> r0) & (rpi == 2 ? 3ull : 1ull)) == 0ull) continue;
+            const int r = r0 + rsub;
+            const uint64_t w = __shfl(myrow, r & 63, 64);
+            if (r < ps && c < ps && ((w >> c) & 1ull)) {
+                const int p = r * ps + c;
+                float x[9];
+                pixel_channels<T>(Px<T>::ld(pp, p), Px<T>::ld(pp, P + p), Px<T>::ld(pp, 2 * P + p), 0u, 0u, 0u, mh, s_od, x);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    const double xd = (double)x[k];
+                    s1[k] += xd;
+                    s2[k] += xd * xd;
+                }
             }
         }
     }
@@ -321,7 +381,7 @@ hipError_t launch_color(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
             hipLaunchKernelGGL(k_color<float>, dim3((unsigned)blocks), dim3(256), 16, ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
                                reinterpret_cast<const float *>(job.patches), job.mask_rows, SC, ctx->od_lut, job.out, job.F, col0);
         else
-            hipLaunchKernelGGL(k_color<uint8_t>, dim3((unsigned)blocks), dim3(256), 4 * ((3 * P + 15) & ~15), ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
+            hipLaunchKernelGGL(k_color<uint8_t>, dim3((unsigned)blocks), dim3(256), 4 * (size_t)(P < COLOR_LIST_CAP ? P : COLOR_LIST_CAP) * sizeof(unsigned), ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
                                reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, SC, ctx->od_lut, job.out, job.F, col0);
         e = hipGetLastError();
     }
