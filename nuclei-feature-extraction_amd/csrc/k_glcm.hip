@@ -245,16 +245,31 @@ static __device__ __host__ __forceinline__ int glcm_class(int K) { return K <= 5
 __global__ __launch_bounds__(256) void k_glcm_classify(int64_t n, int ps, const uint64_t *__restrict__ mask_rows, int *__restrict__ lists,
                                                        int *__restrict__ counts)
 {
-    // sixteen lanes per nucleus
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
-    const int sub = threadIdx.x & 15;
-    int K = 0;
-    if (i < n)
-        for (int r = sub; r < ps; r += 16) K += __popcll(mask_rows[i * ps + r]);
-    K += __shfl_xor(K, 1, 64); K += __shfl_xor(K, 2, 64); K += __shfl_xor(K, 4, 64); K += __shfl_xor(K, 8, 64);
-    if (i < n && sub == 0) {
-        const int c = glcm_class(K);
-        lists[(int64_t)c * n + atomicAdd(&counts[c], 1)] = (int)i;
+    // sixteen lanes per nucleus, four nuclei per lane group: 64 nuclei per block.  List slots are handed out inside the
+    // block (LDS), so the four global counters see one atomic per block and class, not one per nucleus.
+    constexpr int PER_GROUP = 4;
+    __shared__ int s_cnt[GL_CLASSES], s_base[GL_CLASSES];
+    if (threadIdx.x < GL_CLASSES) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int group = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    int cls[PER_GROUP], rank[PER_GROUP];
+#pragma unroll
+    for (int u = 0; u < PER_GROUP; ++u) {
+        const int64_t i = ((int64_t)blockIdx.x * 16 + group) * PER_GROUP + u;
+        int K = 0;
+        if (i < n)
+            for (int r = sub; r < ps; r += 16) K += __popcll(mask_rows[i * ps + r]);
+        K += __shfl_xor(K, 1, 64); K += __shfl_xor(K, 2, 64); K += __shfl_xor(K, 4, 64); K += __shfl_xor(K, 8, 64);
+        cls[u] = glcm_class(K);
+        rank[u] = (i < n && sub == 0) ? atomicAdd(&s_cnt[cls[u]], 1) : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < GL_CLASSES) s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]) : 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PER_GROUP; ++u) {
+        const int64_t i = ((int64_t)blockIdx.x * 16 + group) * PER_GROUP + u;
+        if (i < n && sub == 0) lists[(int64_t)cls[u] * n + s_base[cls[u]] + rank[u]] = (int)i;
     }
 }
 
@@ -592,7 +607,7 @@ hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
     const GlcmLuts *lut = reinterpret_cast<const GlcmLuts *>(ctx->glcm_lut);
     e = hipMemsetAsync(counts, 0, sizeof(int) * GL_CLASSES, ctx->stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_glcm_classify, dim3((unsigned)((job.n * 16 + 255) / 256)), dim3(256), 0, ctx->stream, job.n, job.ps, job.mask_rows, lists, counts);
+    hipLaunchKernelGGL(k_glcm_classify, dim3((unsigned)((job.n + 63) / 64)), dim3(256), 0, ctx->stream, job.n, job.ps, job.mask_rows, lists, counts);
     if (job.patches_f32) launch_classes<float>(ctx, job, lut, sums, lists, counts);
     else launch_classes<uint8_t>(ctx, job, lut, sums, lists, counts);
     const int64_t items = job.n * 16;
