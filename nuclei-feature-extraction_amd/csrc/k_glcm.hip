@@ -8,26 +8,34 @@
 // L=254 -- and reduces it fourteen times.  A nucleus has at most ps*(ps-1) co-occurring pairs (a few
 // thousand), so the matrix is >90 % zeros.  Here nothing dense is ever built or reduced:
 //
-//   * ONE WAVEFRONT PER NUCLEUS (single-wave workgroups, persistent): no cross-wave barrier or reduction,
-//     lanes stay busy to within K mod 64.  The mask's pixels are compacted into an LDS list of
-//     (position, four packed levels); the u8 patch is fetched with 16-byte coalesced loads into LDS (one HBM round
-//     trip per nucleus) and every masked pixel is quantised exactly once;
+//   * ONE WAVEFRONT PER NUCLEUS (single-wave workgroups, persistent): no cross-wave barrier or reduction.
+//     k_glcm_classify sorts the nuclei into four lists by mask size (= hash capacity); each list has its own
+//     instantiation, so a wave knows its next nucleus and requests that nucleus's whole u8 patch (16-byte pieces,
+//     in registers) and mask row while it works on the current one: no HBM latency on the critical path;
+//   * the mask's pixels are compacted into an LDS list, one word per pixel: r << 24 | c << 16 | level128 << 8 |
+//     level254.  Levels 64 and 32 are level128 >> 1 and >> 2 (floor(128 g) >> 1 == floor(64 g) exactly), and the
+//     patch is quantised with exact 3-instruction divisions by 255 and 3 (exact_div.h);
 //   * co-occurrence cells are counted with RETURNING LDS atomics.  The value the atomic returns is the
 //     pair's rank k inside its cell, and
 //         sum_cells G^2     = sum_pairs 2(2k+1)            (4(2k+1) on the diagonal)
 //         sum_cells G ln G  = sum_pairs 2[h(k+1)-h(k)],  h(x) = x ln x   (diag: H(x) = 2x ln 2x)
 //     telescope over the ranks (difference tables for every possible rank live in global memory, L1/L2
-//     resident), so the multiplicities are never read back and no cell needs an owner;
+//     resident; the look-up for a pair is issued one loop iteration after its rank is known), so the
+//     multiplicities are never read back and no cell needs an owner;
 //   * L=32 and L=64 use dense triangular tables of packed 16-bit counters (5 KB); L=128 and L=254 use
-//     open-addressing HASH tables sized 2x the pair capacity (8 KB for masks up to 1024 pixels) instead
-//     of 16.5 / 64.8 KB dense ones: a wave's whole state is 21 KB, seven nuclei in flight per CU.  Tables
-//     are reset by sweeping them with 16-byte stores (a handful of instructions per wave);
-//   * levels 32/64/128 share one pass over the pairs of an offset, level 254 takes a second pass in
-//     the same table memory;
-//   * every other feature is a closed form of four exact integer power sums over the pairs
-//     (sum s, s^2, d, d^2 with s=a+b, d=|a-b|) plus the two 1-D histogram entropies.
-// One instantiation per mask-size class (hash capacity).  The ten sums of every (level, offset) combination go
-// to a scratch array; k_glcm_finish evaluates the 14 features with one lane per combination.
+//     open-addressing HASH tables sized 2x the pair capacity (4 KB for masks up to 512 pixels) instead
+//     of 16.5 / 64.8 KB dense ones, keyed by hi << 8 | lo and filled insert-first (a new cell costs one LDS
+//     round trip): a wave's whole state is 16 KB, ten nuclei in flight per CU.  Tables are reset by sweeping
+//     them with 16-byte stores;
+//   * levels 32/64/128 share one pass over the pairs of an offset and leave a one-byte memo per pixel (list
+//     distance to the partner, backward-neighbour flag); the level-254 pass in the same table memory re-finds
+//     its pairs from the memo without touching the mask;
+//   * every lane walks TWO list entries per iteration through a branch-free body (two independent LDS chains);
+//   * the marginal histogram p_x is filled per PIXEL (degree = number of pairs the pixel is in) and only at the
+//     finest nested level; sum s n_s and sum s^2 n_s come out of the sum histogram when it is folded; the
+//     remaining power sums (d, d^2 with d=|a-b|), 1/(1+d^2) and the rank terms are per pair.
+// The ten sums of every (level, offset) combination go to a scratch array; k_glcm_finish evaluates the 14
+// features with one lane per combination.
 #include <cmath>
 #include <cstdlib>
 #include <vector>
