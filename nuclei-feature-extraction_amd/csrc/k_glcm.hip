@@ -233,7 +233,7 @@ static __device__ __forceinline__ double xlnx_of(const GlcmLuts *__restrict__ lu
 }
 static __device__ __forceinline__ unsigned lut_slot(unsigned v) { return v < (unsigned)GL_RANKS ? v : 0u; }
 
-static __device__ __forceinline__ void publish(double *__restrict__ dst, unsigned np, const LevelAcc &A, double ents, double hxs, double hss, int lane)
+static __device__ __forceinline__ void publish(double *dst, unsigned np, const LevelAcc &A, double ents, double hxs, double hss, int lane)
 {
     const double v1 = (double)wave_total_u32(A.S1), v2 = (double)wave_total_u32(A.S2);
     const double v3 = (double)wave_total_u32(A.D1), v4 = (double)wave_total_u32(A.D2);
@@ -297,6 +297,7 @@ __global__ __launch_bounds__(64) void k_glcm(const int *__restrict__ list, const
     __shared__ uint64_t s_rows1[66];         // mask row r at [r + 1]; zero rows either side
     __shared__ unsigned short s_rowstart[66];
     __shared__ unsigned s_dummy[64];
+    __shared__ __attribute__((aligned(16))) double s_sums[4 * GL_NACC]; // one offset's sums (four levels), stored as one 320-byte piece
     __shared__ unsigned char s_memo[QCAP + 64];
     unsigned *const s_tab = s_mem, *const s_hist = s_mem + TAB_WORDS;
 
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(64) void k_glcm(const int *__restrict__ list, const
         wave_lds_fence();
         sweep(s_hist, GL_HIST_WORDS, 0u, lane);
         s_dummy[lane] = GL_DUMMY;
-        double *sums_i = sums + i * 16 * GL_NACC;
+        double *sums_i = sums + i * 16 * GL_NACC; // [offset][level][GL_NACC]
 
 #pragma unroll 1
         for (int oi = 0; oi < 4; ++oi) {
@@ -468,9 +469,9 @@ __global__ __launch_bounds__(64) void k_glcm(const int *__restrict__ list, const
                     A2.S1 = (s0 * hv[3] + s1 * hv[4]) + (s2 * hv[5] + s3 * hv[6]);
                     A2.S2 = (s0 * s0 * hv[3] + s1 * s1 * hv[4]) + (s2 * s2 * hv[5] + s3 * s3 * hv[6]);
                 }
-                publish(sums_i + (0 * 4 + oi) * GL_NACC, np_w, A0, A0.ents, hx32, hs32, lane);
-                publish(sums_i + (1 * 4 + oi) * GL_NACC, np_w, A1, A1.ents, hx64, hs64, lane);
-                publish(sums_i + (2 * 4 + oi) * GL_NACC, np_w, A2, A2.ents, hx128, hs128, lane);
+                publish(s_sums + 0 * GL_NACC, np_w, A0, A0.ents, hx32, hs32, lane);
+                publish(s_sums + 1 * GL_NACC, np_w, A1, A1.ents, hx64, hs64, lane);
+                publish(s_sums + 2 * GL_NACC, np_w, A2, A2.ents, hx128, hs128, lane);
             }
             wave_lds_fence();
             // ================= pass B: level 254 ===================================================================
@@ -510,9 +511,11 @@ __global__ __launch_bounds__(64) void k_glcm(const int *__restrict__ list, const
                 for (int m = 4; m < 12; ++m) { const unsigned sv = (unsigned)lane + 64u * (unsigned)(m - 4); A3.S1 += sv * hv[m]; A3.S2 += sv * sv * hv[m]; }
                 const double hx = (e[0] + e[1]) + (e[2] + e[3]);
                 const double hs = ((e[4] + e[5]) + (e[6] + e[7])) + ((e[8] + e[9]) + (e[10] + e[11]));
-                publish(sums_i + (3 * 4 + oi) * GL_NACC, np_w, A3, A3.ents, hx, hs, lane);
+                publish(s_sums + 3 * GL_NACC, np_w, A3, A3.ents, hx, hs, lane);
             }
             wave_lds_fence();
+            // lane-0 stores straight to memory would touch five partial lines per combination
+            if (lane < 4 * GL_NACC) sums_i[oi * 4 * GL_NACC + lane] = s_sums[lane];
         }
     }
 }
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(256) void k_glcm_finish(int64_t n, const double *__
     if (g >= n * 16) return;
     const int64_t i = g >> 4;
     const int comb_idx = (int)(g & 15);
-    const double *a = sums + g * GL_NACC;
+    const double *a = sums + (i * 16 + (comb_idx & 3) * 4 + (comb_idx >> 2)) * GL_NACC; // stored [offset][level]
     const double N = a[0], S1 = a[1], S2 = a[2], D1 = a[3], D2 = a[4], IDM = a[5], ASMN = a[6], ENTS = a[7], HXS = a[8], HSS = a[9];
     float *o = out + i * (int64_t)F + col0 + comb_idx * 14;
     if (N == 0.0) {
