@@ -17,6 +17,7 @@
 // that must match the CPU oracle bit for bit, so the f64/f32 expression trees below are
 // evaluated exactly as written.
 #include "nfx_internal.h"
+#include "wave_ops.h"
 
 namespace nfx {
 
@@ -35,38 +36,101 @@ static __device__ __forceinline__ float readlane_f(float v, int l)
 // ---- scanline XOR rasteriser: returns this lane's row word ------------------------------------
 // pixel (r,c) sits at (c - ps/2, r - ps/2); edge (x1,y1)->(x2,y2) toggles it iff
 // (y1 > py) != (y2 > py) && px < (x2-x1)*(py-y1)/(y2-y1) + x1   (all f64).
+// An edge crosses only the few rows between its end points, so "every row tests every edge" would keep about
+// three lanes in 64 busy.  Instead lane e takes edge e, counts the rows it crosses (py in [ymin, ymax): an exact
+// integer range), a wave scan lays the (edge, row) crossings out as a work list in LDS, and the lanes then share
+// the crossings evenly -- one f64 division per crossing, not per (edge, row) -- XORing "all pixels left of the
+// crossing" into the row words with LDS atomics.  Lists longer than RS_CAP (zig-zag polygons) fall back to the
+// every-row-tests-every-edge loop.
+static constexpr int RS_CAP = 512;
+struct RasterLds {
+    unsigned short items[RS_CAP]; // edge << 8 | row
+    unsigned lo[64], hi[64];      // row words under construction
+    float ex[4][64];              // x1, y1, x2, y2 of the chunk's edges
+};
+
+// number of leading pixels of row py left of the crossing of edge (x1,y1)-(x2,y2); the caller knows the edge crosses
+static __device__ __forceinline__ int crossing_count(double x1, double y1, double x2, double y2, double py, double half, int ps)
+{
+    const double xint = (x2 - x1) * (py - y1) / (y2 - y1) + x1;
+    // k = #{c in [0,ps) : (double)c - half < xint}; estimate by ceil, then make it exact
+    const double kf = ceil(xint + half);
+    int k = !(kf > 0.0) ? 0 : (kf >= (double)ps ? ps : (int)kf);
+    if (k > 0 && !((double)(k - 1) - half < xint)) --k;
+    if (k < ps && ((double)k - half < xint)) ++k;
+    return k;
+}
+
 static __device__ __forceinline__ uint64_t raster_row(const uint32_t *__restrict__ poly_off,
-                                                      const float *__restrict__ poly_xy, int64_t i, int ps, int lane)
+                                                      const float *__restrict__ poly_xy, int64_t i, int ps, int lane, RasterLds &L)
 {
     const uint32_t v0 = poly_off[i];
     const int V = (int)(poly_off[i + 1] - v0);
     const double half = (double)ps / 2.0;
-    const double py = (double)lane - half;
-    uint64_t row = 0;
+    uint64_t row = 0; // fallback path only
+    L.lo[lane] = 0u;
+    L.hi[lane] = 0u;
     for (int base = 0; base < V; base += 64) {
         const int cnt = (V - base) < 64 ? (V - base) : 64;
         float fx1 = 0.f, fy1 = 0.f, fx2 = 0.f, fy2 = 0.f;
+        int ra = 0, nrows = 0;
         if (lane < cnt) {
             const int a = base + lane;
             const int b = (a + 1 == V) ? 0 : a + 1;
             const float2 p1 = reinterpret_cast<const float2 *>(poly_xy)[v0 + a];
             const float2 p2 = reinterpret_cast<const float2 *>(poly_xy)[v0 + b];
             fx1 = p1.x; fy1 = p1.y; fx2 = p2.x; fy2 = p2.y;
+            // rows with ymin <= r - half < ymax, i.e. (y1 > py) != (y2 > py): r in [ceil(ymin + half), ceil(ymax + half))
+            const double y1 = (double)fy1, y2 = (double)fy2;
+            const double ylo = y1 < y2 ? y1 : y2, yhi = y1 < y2 ? y2 : y1; // a NaN leaves an empty range below
+            double da = ceil(ylo + half), db = ceil(yhi + half);
+            da = da > 0.0 ? da : 0.0; db = db > 0.0 ? db : 0.0;
+            da = da < (double)ps ? da : (double)ps; db = db < (double)ps ? db : (double)ps;
+            ra = (int)da;
+            nrows = (int)db - ra;
+            nrows = (nrows > 0 && ylo < yhi) ? nrows : 0;
         }
-        for (int e = 0; e < cnt; ++e) {
-            const double x1 = (double)readlane_f(fx1, e), y1 = (double)readlane_f(fy1, e);
-            const double x2 = (double)readlane_f(fx2, e), y2 = (double)readlane_f(fy2, e);
-            if ((y1 > py) != (y2 > py)) {
-                const double xint = (x2 - x1) * (py - y1) / (y2 - y1) + x1;
-                // k = #{c in [0,ps) : (double)c - half < xint}; estimate by ceil, then make it exact
-                const double kf = ceil(xint + half);
-                int k = !(kf > 0.0) ? 0 : (kf >= (double)ps ? ps : (int)kf);
-                if (k > 0 && !((double)(k - 1) - half < xint)) --k;
-                if (k < ps && ((double)k - half < xint)) ++k;
-                row ^= (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+        int incl = nrows;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total > RS_CAP) {
+            const double py = (double)lane - half;
+            for (int e = 0; e < cnt; ++e) {
+                const double x1 = (double)readlane_f(fx1, e), y1 = (double)readlane_f(fy1, e);
+                const double x2 = (double)readlane_f(fx2, e), y2 = (double)readlane_f(fy2, e);
+                if ((y1 > py) != (y2 > py)) {
+                    const int k = crossing_count(x1, y1, x2, y2, py, half, ps);
+                    row ^= (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+                }
             }
+            continue;
         }
+        L.ex[0][lane] = fx1; L.ex[1][lane] = fy1; L.ex[2][lane] = fx2; L.ex[3][lane] = fy2;
+        {
+            const int first = incl - nrows;
+            int longest = nrows;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(longest, o, 64); longest = v > longest ? v : longest; }
+            for (int j = 0; j < longest; ++j)
+                if (j < nrows) L.items[first + j] = (unsigned short)((lane << 8) | (ra + j));
+        }
+        wave_lds_fence();
+        for (int w = lane; w < total; w += 64) {
+            const unsigned it = L.items[w];
+            const int e = (int)(it >> 8), r = (int)(it & 255u);
+            const int k = crossing_count((double)L.ex[0][e], (double)L.ex[1][e], (double)L.ex[2][e], (double)L.ex[3][e], (double)r - half, half, ps);
+            const uint64_t span = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+            atomicXor(&L.lo[r], (unsigned)span);
+            atomicXor(&L.hi[r], (unsigned)(span >> 32));
+        }
+        wave_lds_fence();
     }
+    wave_lds_fence();
+    row ^= ((uint64_t)L.hi[lane] << 32) | (uint64_t)L.lo[lane];
     return lane < ps ? row : 0ull;
 }
 
@@ -277,10 +341,11 @@ __global__ __launch_bounds__(256) void k_raster_shape(int64_t n, const uint32_t 
                                                       uint64_t *__restrict__ rows_out, float *__restrict__ out, int F,
                                                       int col0)
 {
+    __shared__ RasterLds s_raster[4];
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return; // wave-uniform
-    const uint64_t row = raster_row(poly_off, poly_xy, i, ps, lane);
+    const uint64_t row = raster_row(poly_off, poly_xy, i, ps, lane, s_raster[threadIdx.x >> 6]);
     if (rows_out && lane < ps) rows_out[i * ps + lane] = row;
     if (SHAPE) shape_from_row(row, ps, lane, out + i * (int64_t)F + col0);
 }
