@@ -67,7 +67,8 @@ def assert_rows_close(got, want, scales, exact_cols=(), rtol=RTOL, what=""):
 
 def edge_case_rings(ps):
     """Rings the reference's loaders can meet: empty, point, line, triangle, > 64 vertices, far larger
-    than the patch, self-intersecting bow-tie, unclosed ring, off-centre sliver."""
+    than the patch, self-intersecting bow-tie, unclosed ring, off-centre sliver, one pixel, and a 64-tooth comb
+    whose edges cross every row (thousands of scanline crossings: the rasteriser's long-list path)."""
     c = 500.0
     rings = []
     rings.append(np.zeros((0, 2), np.float32))                                    # no vertices
@@ -82,6 +83,9 @@ def edge_case_rings(ps):
     rings.append(np.array([[c - 6, c - 6], [c + 6, c - 6], [c + 6, c + 6], [c - 6, c + 6]], np.float32))  # unclosed square
     rings.append(np.array([[c, c], [c + 0.4 * ps, c + 0.2], [c + 0.4 * ps, c + 0.9], [c, c]], np.float32))  # sliver
     rings.append(np.array([[c - 0.5, c - 0.5], [c + 0.5, c - 0.5], [c + 0.5, c + 0.5], [c - 0.5, c + 0.5], [c - 0.5, c - 0.5]], np.float32))  # one pixel
+    k = np.arange(64)
+    comb = np.stack([c - 0.42 * ps + 0.84 * ps * k / 63.0, c + np.where(k % 2 == 0, -0.43, 0.41) * ps], 1)
+    rings.append(np.concatenate([comb, comb[:1]]).astype(np.float32))              # zig-zag comb
     off = np.zeros(len(rings) + 1, np.uint32)
     np.cumsum([len(r) for r in rings], out=off[1:])
     return off, np.concatenate(rings).astype(np.float32)
