@@ -46,6 +46,8 @@
 
 namespace nfx {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 static constexpr int GL_NACC = 10;
 static constexpr int GL_RANKS = 4096;      // rank / count range of the global difference tables
 static constexpr int GL_HIST_WORDS = 768;
@@ -283,14 +285,14 @@ __global__ __launch_bounds__(256) void k_glcm_classify(int64_t n, int ps, const 
 
 // ---- the kernel -------------------------------------------------------------------------------------------
 // LOG2SLOTS: hash capacity; serves the nuclei of its class list (K <= SLOTS/2 mask pixels).
-template <typename T, int LOG2SLOTS>
-__global__ __launch_bounds__(64) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int ps,
+// NPRE: 16-byte pieces of a u8 patch per lane (3 ps^2 / 1024 rounded up: 3, 7 or 12 for ps <= 32, 48, 64)
+template <typename T, int LOG2SLOTS, int NPRE>
+__global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int ps,
                                              const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
                                              const GlcmLuts *__restrict__ lut, double *__restrict__ sums)
 {
     constexpr int SLOTS = 1 << LOG2SLOTS, QCAP = SLOTS / 2;
     constexpr int TAB_WORDS = GL_H128_OFF + SLOTS;
-    constexpr int NPRE = 12; // 16-byte pieces of a u8 patch per lane (3*64*64 / 16 / 64)
     __shared__ __attribute__((aligned(16))) unsigned s_mem[TAB_WORDS + GL_HIST_WORDS]; // tables | histograms
     __shared__ unsigned s_q[QCAP + 1];         // list entry: r << 24 | c << 16 | level128 << 8 | level254 (levels 64 and 32
                                              // are level128 >> 1 and >> 2: floor(128 g) >> 1 == floor(64 g))
@@ -310,20 +312,23 @@ __global__ __launch_bounds__(64) void k_glcm(const int *__restrict__ list, const
     // u8 patches travel through registers: the next nucleus's patch and mask row are requested as soon as the
     // current ones have been put down in LDS, so their HBM latency hides behind a whole nucleus of work
     const int n16 = (3 * P) / 16;
-    const bool stage = sizeof(T) == 1 && ((3 * P) & 15) == 0 && 3 * P <= (int)sizeof(s_mem) && (reinterpret_cast<uintptr_t>(patches) & 15) == 0;
-    uint4 pre[NPRE];
+    const bool stage = sizeof(T) == 1 && ((3 * P) & 15) == 0 && 3 * P <= (int)sizeof(s_mem) && 3 * P <= NPRE * 1024 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0;
+    u32x4 pre[NPRE]; // a native vector type: HIP's uint4 struct is copied with memcpy, which keeps the array in scratch memory
     uint64_t row_next;
     int i_next = list[j];
-    auto request = [&](int64_t i) {
-        row_next = lane < ps ? mask_rows[i * ps + lane] : 0ull;
-        if (stage) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(patches + (size_t)i * 3 * P);
-#pragma unroll
-            for (int k = 0; k < NPRE; ++k)
-                if (lane + 64 * k < n16) pre[k] = src[lane + 64 * k];
-        }
-    };
-    request(i_next);
+#define NFX_GLCM_REQUEST(I)                                                                                       \
+    do {                                                                                                          \
+        const int64_t i_ = (I);                                                                                   \
+        row_next = lane < ps ? mask_rows[i_ * ps + lane] : 0ull;                                                  \
+        if (stage) {                                                                                              \
+            const u32x4 *src_ = reinterpret_cast<const u32x4 *>(patches + (size_t)i_ * 3 * P);                    \
+            _Pragma("unroll") for (int k_ = 0; k_ < NPRE; ++k_) pre[k_] = src_[lane + 64 * k_ < n16 ? lane + 64 * k_ : 0]; \
+        }                                                                                                         \
+    } while (0)
+    // no branches inside: all NPRE pieces are always requested (indices past the patch clamp to piece 0, one shared
+    // cache line), so the pieces stay plain register values -- a conditionally written array is demoted to scratch
+    // memory, and every load then waits for its own scratch store
+    NFX_GLCM_REQUEST(i_next);
     if (lane < 2) s_rows1[lane ? ps + 1 : 0] = 0ull;
     if (lane < 2) s_rowstart[64 + lane] = 0;
 
@@ -332,14 +337,13 @@ __global__ __launch_bounds__(64) void k_glcm(const int *__restrict__ list, const
         const int64_t i = i_next;
         const uint64_t myrow = row_next;
         if (stage) {
-            uint4 *dst = reinterpret_cast<uint4 *>(s_mem);
+            u32x4 *dst = reinterpret_cast<u32x4 *>(s_mem);
 #pragma unroll
-            for (int k = 0; k < NPRE; ++k)
-                if (lane + 64 * k < n16) dst[lane + 64 * k] = pre[k];
+            for (int k = 0; k < NPRE; ++k) dst[lane + 64 * k] = pre[k]; // s_mem holds NPRE KiB: pieces past the patch land in table memory that is swept below
         }
         if (j + (int)gridDim.x < cnt) {
             i_next = list[j + gridDim.x];
-            request(i_next);
+            NFX_GLCM_REQUEST(i_next);
         }
         // ---- row prefix ---------------------------------------------------------------------------------------
         const int rcnt = __popcll(myrow);
@@ -590,19 +594,19 @@ static hipError_t ensure_luts(nfx_ctx *ctx)
     return hipMemcpy(ctx->glcm_lut, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
 }
 
-template <typename T>
+template <typename T, int NPRE>
 static void launch_classes(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *sums, const int *lists, const int *counts)
 {
     const T *p = reinterpret_cast<const T *>(job.patches);
     const int P = job.ps * job.ps;
     auto grid = [&](int wgs_per_cu) { const int64_t m = 256ll * wgs_per_cu * 4; return (unsigned)(job.n < m ? job.n : m); };
     // Smaller classes keep more nuclei in flight per CU (16 KB of LDS per wave for masks up to 512 pixels, 23 KB up
-    // to 1024, 37 KB up to 2048, 66 KB up to 4096).  Blocks beyond a list's length exit at once.
+    // to 1024, 36 KB up to 2048, 62 KB up to 4096).  Blocks beyond a list's length exit at once.
     const int64_t n = job.n;
-    hipLaunchKernelGGL((k_glcm<T, 10>), dim3(grid(10)), dim3(64), 0, ctx->stream, lists + 0 * n, counts + 0, job.ps, p, job.mask_rows, lut, sums);
-    if (P > 512) hipLaunchKernelGGL((k_glcm<T, 11>), dim3(grid(7)), dim3(64), 0, ctx->stream, lists + 1 * n, counts + 1, job.ps, p, job.mask_rows, lut, sums);
-    if (P > 1024) hipLaunchKernelGGL((k_glcm<T, 12>), dim3(grid(4)), dim3(64), 0, ctx->stream, lists + 2 * n, counts + 2, job.ps, p, job.mask_rows, lut, sums);
-    if (P > 2048) hipLaunchKernelGGL((k_glcm<T, 13>), dim3(grid(2)), dim3(64), 0, ctx->stream, lists + 3 * n, counts + 3, job.ps, p, job.mask_rows, lut, sums);
+    hipLaunchKernelGGL((k_glcm<T, 10, NPRE>), dim3(grid(10)), dim3(64), 0, ctx->stream, lists + 0 * n, counts + 0, job.ps, p, job.mask_rows, lut, sums);
+    if (P > 512) hipLaunchKernelGGL((k_glcm<T, 11, NPRE>), dim3(grid(7)), dim3(64), 0, ctx->stream, lists + 1 * n, counts + 1, job.ps, p, job.mask_rows, lut, sums);
+    if (P > 1024) hipLaunchKernelGGL((k_glcm<T, 12, NPRE>), dim3(grid(4)), dim3(64), 0, ctx->stream, lists + 2 * n, counts + 2, job.ps, p, job.mask_rows, lut, sums);
+    if (P > 2048) hipLaunchKernelGGL((k_glcm<T, 13, NPRE>), dim3(grid(2)), dim3(64), 0, ctx->stream, lists + 3 * n, counts + 3, job.ps, p, job.mask_rows, lut, sums);
 }
 
 hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
@@ -619,8 +623,10 @@ hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
     e = hipMemsetAsync(counts, 0, sizeof(int) * GL_CLASSES, ctx->stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_glcm_classify, dim3((unsigned)((job.n + 63) / 64)), dim3(256), 0, ctx->stream, job.n, job.ps, job.mask_rows, lists, counts);
-    if (job.patches_f32) launch_classes<float>(ctx, job, lut, sums, lists, counts);
-    else launch_classes<uint8_t>(ctx, job, lut, sums, lists, counts);
+    if (job.patches_f32) launch_classes<float, 1>(ctx, job, lut, sums, lists, counts);
+    else if (job.ps <= 32) launch_classes<uint8_t, 3>(ctx, job, lut, sums, lists, counts);
+    else if (job.ps <= 48) launch_classes<uint8_t, 7>(ctx, job, lut, sums, lists, counts);
+    else launch_classes<uint8_t, 12>(ctx, job, lut, sums, lists, counts);
     const int64_t items = job.n * 16;
     hipLaunchKernelGGL(k_glcm_finish, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, job.n, sums, job.out, job.F, col0);
     return hipGetLastError();
