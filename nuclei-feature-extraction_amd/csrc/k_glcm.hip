@@ -199,13 +199,17 @@ static __device__ __forceinline__ unsigned dense_rank_if(unsigned *tab, unsigned
 static constexpr unsigned GL_DUMMY = 0xFFFE0000u;
 
 // ranks of two keys in the open-addressing table; both probes of a round are issued back to back
-template <int LOG2SLOTS>
+// SLOTS need not be a power of two: the LOG2SLOTS hash bits are scaled by 11/16 when the table is 11/16 of 2^LOG2SLOTS
+template <int LOG2SLOTS, int SLOTS>
 static __device__ __forceinline__ void hash_rank2(unsigned *tab, unsigned *dummy, unsigned key0, bool act0, unsigned key1, bool act1,
                                                   unsigned &rk0, unsigned &rk1)
 {
-    constexpr unsigned MASK = (1u << LOG2SLOTS) - 1u;
-    unsigned h0 = __umul24(key0, 0x9E3779u) >> (32 - LOG2SLOTS), h1 = __umul24(key1, 0x9E3779u) >> (32 - LOG2SLOTS);
+    static_assert(SLOTS == (1 << LOG2SLOTS) || SLOTS == 11 * (1 << LOG2SLOTS) / 16, "table size");
+    // HIP's __umul24 returns int: shift the product as unsigned, or half of the keys start at a negative slot
+    unsigned h0 = (unsigned)__umul24(key0, 0x9E3779u) >> (32 - LOG2SLOTS), h1 = (unsigned)__umul24(key1, 0x9E3779u) >> (32 - LOG2SLOTS);
+    if (SLOTS != (1 << LOG2SLOTS)) { h0 = (11u * h0) >> 4; h1 = (11u * h1) >> 4; }
     rk0 = 0u; rk1 = 0u;
+    int rounds = 0; // a full sweep of the table always ends the search; the bound only guards against a corrupted table
     do {
         unsigned *const slot0 = act0 ? tab + h0 : dummy, *const slot1 = act1 ? tab + h1 : dummy;
         const unsigned prev0 = atomicCAS(slot0, GL_EMPTY, (key0 << 16) | 1u);
@@ -217,9 +221,9 @@ static __device__ __forceinline__ void hash_rank2(unsigned *tab, unsigned *dummy
         if (same1) rk1 = r1 & 0xFFFFu;
         act0 = act0 && prev0 != GL_EMPTY && !same0;
         act1 = act1 && prev1 != GL_EMPTY && !same1;
-        h0 = (h0 + 1u) & MASK;
-        h1 = (h1 + 1u) & MASK;
-    } while (act0 || act1);
+        h0 = h0 + 1u == (unsigned)SLOTS ? 0u : h0 + 1u;
+        h1 = h1 + 1u == (unsigned)SLOTS ? 0u : h1 + 1u;
+    } while ((act0 || act1) && ++rounds <= SLOTS);
 }
 
 static __device__ __forceinline__ void sweep(unsigned *tab, int words, unsigned value, int lane)
@@ -284,14 +288,16 @@ __global__ __launch_bounds__(256) void k_glcm_classify(int64_t n, int ps, const 
 }
 
 // ---- the kernel -------------------------------------------------------------------------------------------
-// LOG2SLOTS: hash capacity; serves the nuclei of its class list (K <= SLOTS/2 mask pixels).
+// LOG2SLOTS: size class; serves the nuclei of its class list (K <= 2^LOG2SLOTS / 2 mask pixels).
 // NPRE: 16-byte pieces of a u8 patch per lane (3 ps^2 / 1024 rounded up: 3, 7 or 12 for ps <= 32, 48, 64)
 template <typename T, int LOG2SLOTS, int NPRE>
 __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int ps,
                                              const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
                                              const GlcmLuts *__restrict__ lut, double *__restrict__ sums)
 {
-    constexpr int SLOTS = 1 << LOG2SLOTS, QCAP = SLOTS / 2;
+    // hash slots per list entry: 2 in the first class (its table doubles as the staging area of a 64x64 patch), 11/8
+    // in the larger ones, where the 2.5-10 KB of LDS buy another wave per CU (8, 5 and 3 instead of 7, 4 and 2)
+    constexpr int QCAP = (1 << LOG2SLOTS) / 2, SLOTS = LOG2SLOTS == 10 ? 2 * QCAP : 11 * QCAP / 8;
     constexpr int TAB_WORDS = GL_H128_OFF + SLOTS;
     __shared__ __attribute__((aligned(16))) unsigned s_mem[TAB_WORDS + GL_HIST_WORDS]; // tables | histograms
     __shared__ unsigned s_q[QCAP + 1];         // list entry: r << 24 | c << 16 | level128 << 8 | level254 (levels 64 and 32
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void 
                 atomicAdd(&s_hist[320 + xa2 + xb2], X.fwd ? 1u : 0u);
                 atomicAdd(&s_hist[320 + ya2 + yb2], Y.fwd ? 1u : 0u);
                 unsigned rx2, ry2;
-                hash_rank2<LOG2SLOTS>(s_tab + GL_H128_OFF, s_dummy + lane, cell_key(xa2, xb2), X.fwd, cell_key(ya2, yb2), Y.fwd, rx2, ry2);
+                hash_rank2<LOG2SLOTS, SLOTS>(s_tab + GL_H128_OFF, s_dummy + lane, cell_key(xa2, xb2), X.fwd, cell_key(ya2, yb2), Y.fwd, rx2, ry2);
                 pend[0][0] = pair_acc(X.fwd, xa0, xb0, rx0, A0);
                 pend[1][0] = pair_acc(Y.fwd, ya0, yb0, ry0, A0);
                 pend[0][1] = pair_acc(X.fwd, xa1, xb1, rx1, A1);
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void 
                 atomicAdd(&s_hist[256 + xa + xb], X.fwd ? 1u : 0u);
                 atomicAdd(&s_hist[256 + ya + yb], Y.fwd ? 1u : 0u);
                 unsigned rx, ry;
-                hash_rank2<LOG2SLOTS>(s_tab, s_dummy + lane, cell_key(xa, xb), X.fwd, cell_key(ya, yb), Y.fwd, rx, ry);
+                hash_rank2<LOG2SLOTS, SLOTS>(s_tab, s_dummy + lane, cell_key(xa, xb), X.fwd, cell_key(ya, yb), Y.fwd, rx, ry);
                 pend3[0] = pair_acc(X.fwd, xa, xb, rx, A3);
                 pend3[1] = pair_acc(Y.fwd, ya, yb, ry, A3);
                 A3.ents += ev30 + ev31;
@@ -604,9 +610,9 @@ static void launch_classes(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, do
     // to 1024, 36 KB up to 2048, 62 KB up to 4096).  Blocks beyond a list's length exit at once.
     const int64_t n = job.n;
     hipLaunchKernelGGL((k_glcm<T, 10, NPRE>), dim3(grid(10)), dim3(64), 0, ctx->stream, lists + 0 * n, counts + 0, job.ps, p, job.mask_rows, lut, sums);
-    if (P > 512) hipLaunchKernelGGL((k_glcm<T, 11, NPRE>), dim3(grid(7)), dim3(64), 0, ctx->stream, lists + 1 * n, counts + 1, job.ps, p, job.mask_rows, lut, sums);
-    if (P > 1024) hipLaunchKernelGGL((k_glcm<T, 12, NPRE>), dim3(grid(4)), dim3(64), 0, ctx->stream, lists + 2 * n, counts + 2, job.ps, p, job.mask_rows, lut, sums);
-    if (P > 2048) hipLaunchKernelGGL((k_glcm<T, 13, NPRE>), dim3(grid(2)), dim3(64), 0, ctx->stream, lists + 3 * n, counts + 3, job.ps, p, job.mask_rows, lut, sums);
+    if (P > 512) hipLaunchKernelGGL((k_glcm<T, 11, NPRE>), dim3(grid(8)), dim3(64), 0, ctx->stream, lists + 1 * n, counts + 1, job.ps, p, job.mask_rows, lut, sums);
+    if (P > 1024) hipLaunchKernelGGL((k_glcm<T, 12, NPRE>), dim3(grid(5)), dim3(64), 0, ctx->stream, lists + 2 * n, counts + 2, job.ps, p, job.mask_rows, lut, sums);
+    if (P > 2048) hipLaunchKernelGGL((k_glcm<T, 13, NPRE>), dim3(grid(3)), dim3(64), 0, ctx->stream, lists + 3 * n, counts + 3, job.ps, p, job.mask_rows, lut, sums);
 }
 
 hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
