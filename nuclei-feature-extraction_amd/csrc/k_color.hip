@@ -38,7 +38,11 @@ template <> struct Px<float> {
 
 static __device__ __forceinline__ double wave_sum_f64(double v) { return wave_total_f64(v); }
 
-// Smith hexcone, H in degrees (DESIGN.md "colour transforms")
+// Smith hexcone, H in degrees (DESIGN.md "colour transforms").  The two quotients use the hardware reciprocal (1 ulp)
+// instead of the eleven-instruction IEEE division: hue and saturation are float statistics compared at 1e-5, and
+// the conversion is a build decision of this repository (tch-utils' own arithmetic is not vendored), not a pinned one.
+static __device__ __forceinline__ float quot(float x, float y) { return x * __builtin_amdgcn_rcpf(y); }
+
 static __device__ __forceinline__ void hsv_from_rgb(float r, float g, float b, float &h, float &s, float &v)
 {
     const float mx = fmaxf(r, fmaxf(g, b));
@@ -46,11 +50,11 @@ static __device__ __forceinline__ void hsv_from_rgb(float r, float g, float b, f
     const float d = mx - mn;
     float hh;
     if (d == 0.0f) hh = 0.0f;
-    else if (mx == r) { hh = (g - b) / d; if (hh < 0.0f) hh += 6.0f; } // |hh| <= 1: fmod(hh, 6) is the identity
-    else if (mx == g) hh = (b - r) / d + 2.0f;
-    else hh = (r - g) / d + 4.0f;
+    else if (mx == r) { hh = quot(g - b, d); if (hh < 0.0f) hh += 6.0f; } // |hh| <= 1: fmod(hh, 6) is the identity
+    else if (mx == g) hh = quot(b - r, d) + 2.0f;
+    else hh = quot(r - g, d) + 4.0f;
     h = hh * 60.0f;
-    s = (mx == 0.0f) ? 0.0f : d / mx;
+    s = (mx == 0.0f) ? 0.0f : quot(d, mx);
     v = mx;
 }
 
