@@ -17,6 +17,7 @@ There is NO CPU fallback: if libnfx.so is missing or no GPU is present the calls
 from __future__ import annotations
 
 import ctypes as C
+import sys
 import os
 from typing import Dict, List, Optional, Sequence
 
@@ -163,6 +164,11 @@ class Context:
     ``torch.cuda.current_stream().cuda_stream``; device-memory calls are enqueued on it."""
 
     def __init__(self, device: int = 0, stream: Optional[int] = None):
+        # A process that also uses torch holds two HIP runtimes (torch ships its own): torch's has to come up first, the
+        # other order leaves torch with "No HIP GPUs are available".  Only when the caller has imported torch already.
+        torch = sys.modules.get("torch")
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.init()
         h = C.c_void_p()
         st = lib().nfx_ctx_create(device, C.byref(h))
         if st != 0:

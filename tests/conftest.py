@@ -19,6 +19,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def nfx():
     """The product package (host mirror of the reference's FeatureSet interface over the C ABI)."""
+    # torch carries its own HIP runtime: when both live in one process torch's has to come up first (the other order
+    # leaves torch with "No HIP GPUs are available"), so bring it up before libnfx makes its first HIP call
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     return importlib.import_module(PKG_NAME)
 
 

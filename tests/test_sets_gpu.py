@@ -38,6 +38,18 @@ def test_pipeline_entry_matches_oracle(nfx, ctx, set_id, ps, n, batch):
     par.assert_rows_close(got, want, par.column_scales(nfx, [set_id], ps), what=f"{nfx.feature_set_cli_name(set_id)} ps={ps}")
 
 
+@pytest.mark.parametrize("ps,n,batch", [(20, 37, 7), (33, 41, 100), (50, 35, 9), (63, 30, 16)])
+def test_unaligned_patch_sizes_take_the_scalar_loaders(nfx, ctx, ps, n, batch):
+    """Patch sizes whose rows are not whole 16-byte pieces (and whose patches do not start on 16-byte boundaries) leave
+    the vector staging / prefetch paths of every kernel; ragged last batches ride along.  All five sets at once."""
+    off, xy, pu8 = _inputs(ps, n, seed=70 + ps)
+    sets = list(SETS_READY)
+    want, wcen = orc.extract(sets, off, xy, pu8, ps, batch_size=batch)
+    got, gcen = ctx.extract(sets, off, xy, pu8, ps, batch_size=batch)
+    assert np.array_equal(gcen, wcen, equal_nan=True)
+    par.assert_rows_close(got, want, par.column_scales(nfx, sets, ps), what=f"all sets ps={ps}")
+
+
 @pytest.mark.parametrize("set_id", [s for s in SETS_READY if s != 0])
 def test_trait_entry_f32_matches_oracle(nfx, ctx, set_id):
     ps, n = 48, 40
