@@ -161,3 +161,38 @@ def test_filter_geojson_reproduces_the_reference_utility(tmp_path):
     assert f["geometry"]["coordinates"][0] == [[10.0, 20.0], [30.0, 20.0], [20.5, 40.0], [10.0, 20.0]]
     assert f["geometry"]["coordinates"][1] == [[1.0, 2.0], [3.0, 4.0], [5.0, 6.0]]   # inner rings are not shifted (filter_geojson.rs:54)
     assert subprocess.run([FILTER, "a", "b"], capture_output=True).returncode == 2
+
+
+RUNNER = os.path.join(ROOT, "nuclei-feature-extraction_amd", "bin", "run.sh")
+
+
+def test_folder_driver_usage_and_empty_folder(tmp_path):
+    """run.sh:5-38: three folders are required; a folder without .geojson files is not an error."""
+    r = subprocess.run([RUNNER], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage:" in r.stdout and "<geojson_folder>" in r.stdout
+    (tmp_path / "g").mkdir(); (tmp_path / "s").mkdir()
+    r = subprocess.run([RUNNER, str(tmp_path / "g"), str(tmp_path / "s"), str(tmp_path / "out" / "deep")], capture_output=True, text=True)
+    assert r.returncode == 0 and (tmp_path / "out" / "deep").is_dir()          # mkdir -p (run.sh:41)
+
+
+@pytest.mark.gpu
+def test_folder_driver_processes_every_geojson(nfx, tmp_path):
+    """run.sh:43-55: <name>.geojson pairs with the slide of the same name, output <name>.<ext>; EXTRACTION_ARGS before the
+    positionals, EXTRACTION_FEATURES after; a failing file is reported and the loop goes on."""
+    synth = importlib.import_module("nuclei-feature-extraction_amd.synth")
+    ps, H, W = 32, 256, 256
+    (tmp_path / "g").mkdir(); (tmp_path / "s").mkdir()
+    for k, name in enumerate(["a", "b"]):
+        seed = synth.SEED_BASE + 40 + k
+        cx, cy = synth.centres(seed, 0, 30, ps, W, H)
+        off, xy = synth.polygons(seed, 0, 30, ps, cx, cy)
+        write_png(tmp_path / "s" / f"{name}.png", synth.tile(seed, H, W, off, xy, ps))
+        write_geojson(tmp_path / "g" / f"{name}.geojson", off, xy)
+    (tmp_path / "g" / "c.geojson").write_text("{\"type\": \"FeatureCollection\", \"features\": []}")   # no slide c.*: fails
+    env = dict(os.environ, EXTRACTION_ARGS="-p 32 -b 10 -g 0", EXTRACTION_FEATURES="geometry color")
+    r = subprocess.run([RUNNER, str(tmp_path / "g"), str(tmp_path / "s"), str(tmp_path / "out"), "json"], capture_output=True, text=True, env=env)
+    assert r.returncode == 1, r.stdout + r.stderr
+    assert r.stdout.count("Done processing") == 2 and r.stdout.count("Error processing") == 1
+    for name in ("a", "b"):
+        lines = (tmp_path / "out" / f"{name}.json").read_text().strip().splitlines()
+        assert len(lines) == 30 and set(json.loads(lines[0]).keys()) == set(nfx.all_column_names([0, 1]))
