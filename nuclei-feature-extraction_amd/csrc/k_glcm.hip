@@ -199,15 +199,16 @@ static __device__ __forceinline__ unsigned dense_rank_if(unsigned *tab, unsigned
 static constexpr unsigned GL_DUMMY = 0xFFFE0000u;
 
 // ranks of two keys in the open-addressing table; both probes of a round are issued back to back
-// SLOTS need not be a power of two: the LOG2SLOTS hash bits are scaled by 11/16 when the table is 11/16 of 2^LOG2SLOTS
-template <int LOG2SLOTS, int SLOTS>
+// SLOTS is any table size up to 2^16: sixteen hash bits are scaled into [0, SLOTS)
+template <int SLOTS>
 static __device__ __forceinline__ void hash_rank2(unsigned *tab, unsigned *dummy, unsigned key0, bool act0, unsigned key1, bool act1,
                                                   unsigned &rk0, unsigned &rk1)
 {
-    static_assert(SLOTS == (1 << LOG2SLOTS) || SLOTS == 11 * (1 << LOG2SLOTS) / 16, "table size");
+    static_assert(SLOTS > 0 && SLOTS <= 65536, "table size");
     // HIP's __umul24 returns int: shift the product as unsigned, or half of the keys start at a negative slot
-    unsigned h0 = (unsigned)__umul24(key0, 0x9E3779u) >> (32 - LOG2SLOTS), h1 = (unsigned)__umul24(key1, 0x9E3779u) >> (32 - LOG2SLOTS);
-    if (SLOTS != (1 << LOG2SLOTS)) { h0 = (11u * h0) >> 4; h1 = (11u * h1) >> 4; }
+    unsigned h0 = (unsigned)__umul24(key0, 0x9E3779u) >> 16, h1 = (unsigned)__umul24(key1, 0x9E3779u) >> 16;
+    h0 = (unsigned)__umul24(h0, (unsigned)SLOTS) >> 16;
+    h1 = (unsigned)__umul24(h1, (unsigned)SLOTS) >> 16;
     rk0 = 0u; rk1 = 0u;
     int rounds = 0; // a full sweep of the table always ends the search; the bound only guards against a corrupted table
     do {
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void 
                 atomicAdd(&s_hist[320 + xa2 + xb2], X.fwd ? 1u : 0u);
                 atomicAdd(&s_hist[320 + ya2 + yb2], Y.fwd ? 1u : 0u);
                 unsigned rx2, ry2;
-                hash_rank2<LOG2SLOTS, SLOTS>(s_tab + GL_H128_OFF, s_dummy + lane, cell_key(xa2, xb2), X.fwd, cell_key(ya2, yb2), Y.fwd, rx2, ry2);
+                hash_rank2<SLOTS>(s_tab + GL_H128_OFF, s_dummy + lane, cell_key(xa2, xb2), X.fwd, cell_key(ya2, yb2), Y.fwd, rx2, ry2);
                 pend[0][0] = pair_acc(X.fwd, xa0, xb0, rx0, A0);
                 pend[1][0] = pair_acc(Y.fwd, ya0, yb0, ry0, A0);
                 pend[0][1] = pair_acc(X.fwd, xa1, xb1, rx1, A1);
@@ -465,7 +466,9 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void 
 #pragma unroll
                 for (int m = 0; m < 7; ++m) fs[m] = lut->xlnx[lut_slot(hv[m])];
                 sweep(s_hist, 576, 0u, lane);
-                sweep(s_tab, SLOTS, GL_EMPTY, lane); // pass B's hash table lives at offset 0 (over d32, d64 and the head of h128)
+                sweep(s_tab, TAB_WORDS, GL_EMPTY, lane); // pass B's hash table is the WHOLE table memory (d32, d64 and h128 are
+                                                          // done): 2.3-2.7 slots per entry, so fewer searches need a second probe
+                                                          // and the wave's iteration -- as slow as its unluckiest key -- ends sooner
                 const double hx128 = xlnx_of(lut, h2.x, f0) + xlnx_of(lut, h2.y, f1);
                 const double hx64 = xlnx_of(lut, n64, f64_), hx32 = xlnx_of(lut, n32e, f32_);
                 double e[7];
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void 
                 atomicAdd(&s_hist[256 + xa + xb], X.fwd ? 1u : 0u);
                 atomicAdd(&s_hist[256 + ya + yb], Y.fwd ? 1u : 0u);
                 unsigned rx, ry;
-                hash_rank2<LOG2SLOTS, SLOTS>(s_tab, s_dummy + lane, cell_key(xa, xb), X.fwd, cell_key(ya, yb), Y.fwd, rx, ry);
+                hash_rank2<TAB_WORDS>(s_tab, s_dummy + lane, cell_key(xa, xb), X.fwd, cell_key(ya, yb), Y.fwd, rx, ry);
                 pend3[0] = pair_acc(X.fwd, xa, xb, rx, A3);
                 pend3[1] = pair_acc(Y.fwd, ya, yb, ry, A3);
                 A3.ents += ev30 + ev31;
