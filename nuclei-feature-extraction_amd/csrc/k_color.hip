@@ -10,14 +10,14 @@
 //   k_hue_batch  one lane per (reference batch, pixel): S = sum_j sin(hue_j), C = sum_j cos(hue_j)
 //                over every patch j of the batch.  This is the cheap form of the reference's
 //                [N,N,ps,ps] broadcast: nucleus i's circular mean is atan2(mask_i . S, mask_i . C).
-//   k_color      one wavefront per nucleus.  Pass A (lanes = columns of a mask row, four rows' loads in flight)
-//                dots the mask with S and C (-> mean_h) and, for u8 patches, COMPACTS the masked pixels'
-//                RGB bytes into a per-wave LDS list; pass B then walks the list with every lane busy
-//                (a mask row fills well under half a wave), converts RGB->HSV/HED in registers and
-//                accumulates sum x and sum x^2 of nine channels in f64; the variance about the
-//                f32-rounded mean is then sum x^2 - 2 mu sum x + K mu^2 (the two-pass result of
-//                color.rs:123-128 without a second pass over the pixels).  f32 patches (trait entry)
-//                are read in place, row by row.
+//   k_color      one wavefront per nucleus.  The masked pixels' positions are compacted into a per-wave LDS list
+//                (a mask row fills well under half a wave), then ONE pass walks the list with every lane busy,
+//                two pixels per lane in flight: it dots the mask with S and C (-> mean_h), converts
+//                RGB->HSV/HED in registers and accumulates sum x and sum x^2 of nine channels in f64; the
+//                variance about the f32-rounded mean is then sum x^2 - 2 mu sum x + K mu^2 (the two-pass
+//                result of color.rs:123-128 without a second pass over the pixels).  The hue statistics are
+//                taken on h itself: the shift by mean_h (color.rs:52) only reaches the standard deviation,
+//                which is shift-invariant, so mean_h is not needed before the pixels are read.
 //   Blocks of one reference batch share blockIdx % 8, i.e. one XCD, so the batch's S/C images are
 //   served by that XCD's L2 to all of its nuclei.
 #include "exact_div.h"
@@ -185,11 +185,9 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
                                                float *__restrict__ out, int F, int col0)
 {
     __shared__ float s_od[256];
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_patch_all[]; // 4 waves x ps*ps list words (u8 only)
-    if (sizeof(T) == 1) {
-        s_od[threadIdx.x] = od_lut[threadIdx.x];
-        __syncthreads();
-    }
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_patch_all[]; // 4 waves x min(ps*ps, COLOR_LIST_CAP) list entries
+    s_od[threadIdx.x] = od_lut[threadIdx.x];
+    __syncthreads();
     // XCD-aware block -> (batch, slot) map: every block of a batch has the same blockIdx % 8
     const int64_t v = blockIdx.x;
     const int64_t xcd = v & 7, slot = v >> 3;
@@ -203,24 +201,15 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
 
     const int P = ps * ps;
     const T *pp = patches + (size_t)i * 3 * P;
-    // u8 only: r | g << 8 | b << 16 per masked pixel; masks beyond the list's capacity (only the largest nuclei of a
-    // 64x64 patch) leave their last pixels to a row-wise tail pass, so the LDS footprint stays at four waves x 8 KB
+    // the masked pixels' positions, compacted: masks beyond the list's capacity (only the largest nuclei of a 64x64
+    // patch) leave their last pixels to a row-wise tail, so the LDS footprint stays at four waves x 4 KB
     const int cap = P < COLOR_LIST_CAP ? P : COLOR_LIST_CAP;
-    unsigned *s_list = reinterpret_cast<unsigned *>(s_patch_all) + (threadIdx.x >> 6) * cap;
+    unsigned short *s_list = reinterpret_cast<unsigned short *>(s_patch_all) + (threadIdx.x >> 6) * cap;
     const uint64_t myrow = lane < ps ? mask_rows[i * ps + lane] : 0ull;
-    const int rpi = ps <= 32 ? 2 : 1;          // rows per wave iteration
-    const int cw = ps <= 32 ? 32 : 64;         // lanes per row
-    const int c = lane & (cw - 1);
-    const int rsub = rpi == 2 ? (lane >> 5) : 0;
     const uint64_t anyrow = __ballot(myrow != 0ull); // rows that hold mask pixels
     const double *S = SC + (size_t)batch * 2 * P;
     const double *Cc = S + P;
 
-    // pass A: K and the circular sums (color.rs:148-152), and the list of masked pixels.  Four row steps per
-    // iteration, every load issued before the first use: the S/C images come from L2 and the pixel bytes from HBM,
-    // a dependent load per row would cost its latency per row.
-    int kcnt = 0;
-    double ss = 0.0, cc = 0.0;
     const int rcnt = __popcll(myrow);
     int incl = rcnt; // list position of the first pixel of this lane's row = exclusive prefix over the rows
 #pragma unroll
@@ -228,40 +217,79 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
         const int up = __shfl_up(incl, o, 64);
         if (lane >= o) incl += up;
     }
+    const int K = __builtin_amdgcn_readlane(incl, 63);
     const int rowstart = incl - rcnt;
-    {
-        constexpr int U = 4;
-        const int rfirst = anyrow ? (__ffsll((long long)anyrow) - 1) & ~(rpi - 1) : ps;
-        const int rlast = anyrow ? 63 - __clzll((long long)anyrow) : -1;
-        for (int r0 = rfirst; r0 <= rlast; r0 += U * rpi) {
-            double sv[U], cv[U];
-            unsigned px[U];
-            int at[U];
-            bool act[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int r = r0 + u * rpi + rsub;
-                const uint64_t w = __shfl(myrow, r & 63, 64);
-                act[u] = r < ps && c < ps && ((w >> c) & 1ull);
-                const int pa = act[u] ? r * ps + c : 0;
-                sv[u] = S[pa];
-                cv[u] = Cc[pa];
-                if (sizeof(T) == 1) {
-                    const uint8_t *pb = reinterpret_cast<const uint8_t *>(pp);
-                    px[u] = (unsigned)pb[pa] | ((unsigned)pb[P + pa] << 8) | ((unsigned)pb[2 * P + pa] << 16);
-                    at[u] = __shfl(rowstart, r & 63, 64) + __popcll(w & ((1ull << c) - 1ull));
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                kcnt += act[u] ? 1 : 0;
-                ss += act[u] ? sv[u] : 0.0;
-                cc += act[u] ? cv[u] : 0.0;
-                if (sizeof(T) == 1 && act[u] && at[u] < cap) s_list[at[u]] = px[u];
-            }
+    {   // position list: lane = column, stores only (no round trip in the loop)
+        const unsigned rlo = (unsigned)myrow, rhi = (unsigned)(myrow >> 32);
+        uint64_t rows_left = anyrow;
+        while (rows_left) {
+            const int r = __ffsll((long long)rows_left) - 1;
+            rows_left &= rows_left - 1ull;
+            const unsigned wlo = __builtin_amdgcn_readlane(rlo, r), whi = __builtin_amdgcn_readlane(rhi, r);
+            const int base = __builtin_amdgcn_readlane(rowstart, r);
+            const uint64_t w = ((uint64_t)whi << 32) | wlo;
+            const int at = base + (int)__builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
+            if (((w >> lane) & 1ull) && at < cap) s_list[at] = (unsigned short)(r * ps + lane);
         }
     }
-    const int K = wave_total_i32(kcnt);
+    wave_lds_fence();
+
+    // ONE pass over the list, every lane busy: the circular sums (color.rs:148-152) and sum x, sum x^2 of
+    // r g b h s v he eo da.  The hue statistics are taken on h itself: the reference shifts h by mean_h first
+    // (color.rs:52), which only the standard deviation sees -- and that is shift-invariant -- so mean_h is not needed
+    // before the pixels are read, and one pass replaces two.
+    double ss = 0.0, cc = 0.0;
+    double s1[9], s2[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
+    auto pixel = [&](int p, bool on, unsigned b0, unsigned b1, unsigned b2, float f0, float f1, float f2, double sv, double cv) {
+        float x[9];
+        if (sizeof(T) == 1) pixel_channels<T>(u8_unit(b0), u8_unit(b1), u8_unit(b2), b0, b1, b2, 0.0f, s_od, x); // utils.rs:172
+        else pixel_channels<T>(f0, f1, f2, 0u, 0u, 0u, 0.0f, s_od, x);
+        ss += on ? sv : 0.0;
+        cc += on ? cv : 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const double xd = on ? (double)x[k] : 0.0;
+            s1[k] += xd;
+            s2[k] += xd * xd;
+        }
+    };
+    const int Kl = K < cap ? K : cap;
+    for (int e = lane; e < Kl; e += 128) { // two entries per lane: ten loads in flight before the first use
+        const bool on1 = e + 64 < Kl;
+        const int p0 = s_list[e], p1 = on1 ? s_list[e + 64] : p0;
+        unsigned a0 = 0, a1 = 0, a2 = 0, c0 = 0, c1 = 0, c2 = 0;
+        float fa0 = 0, fa1 = 0, fa2 = 0, fc0 = 0, fc1 = 0, fc2 = 0;
+        if (sizeof(T) == 1) {
+            const uint8_t *pb = reinterpret_cast<const uint8_t *>(pp);
+            a0 = pb[p0]; a1 = pb[P + p0]; a2 = pb[2 * P + p0];
+            c0 = pb[p1]; c1 = pb[P + p1]; c2 = pb[2 * P + p1];
+        } else {
+            fa0 = Px<T>::ld(pp, p0); fa1 = Px<T>::ld(pp, P + p0); fa2 = Px<T>::ld(pp, 2 * P + p0);
+            fc0 = Px<T>::ld(pp, p1); fc1 = Px<T>::ld(pp, P + p1); fc2 = Px<T>::ld(pp, 2 * P + p1);
+        }
+        const double sv0 = S[p0], cv0 = Cc[p0], sv1 = S[p1], cv1 = Cc[p1];
+        pixel(p0, true, a0, a1, a2, fa0, fa1, fa2, sv0, cv0);
+        pixel(p1, on1, c0, c1, c2, fc0, fc1, fc2, sv1, cv1);
+    }
+    if (K > cap) { // tail: pixels that found no room in the list, row by row
+        for (int r = 0; r < ps; ++r) {
+            const uint64_t w = __shfl(myrow, r, 64);
+            const int at = __shfl(rowstart, r, 64) + __popcll(w & ((1ull << lane) - 1ull));
+            const bool on = lane < ps && ((w >> lane) & 1ull) && at >= cap;
+            const int p = on ? r * ps + lane : 0;
+            unsigned a0 = 0, a1 = 0, a2 = 0;
+            float fa0 = 0, fa1 = 0, fa2 = 0;
+            if (sizeof(T) == 1) {
+                const uint8_t *pb = reinterpret_cast<const uint8_t *>(pp);
+                a0 = pb[p]; a1 = pb[P + p]; a2 = pb[2 * P + p];
+            } else {
+                fa0 = Px<T>::ld(pp, p); fa1 = Px<T>::ld(pp, P + p); fa2 = Px<T>::ld(pp, 2 * P + p);
+            }
+            pixel(p, on, a0, a1, a2, fa0, fa1, fa2, S[p], Cc[p]);
+        }
+    }
     ss = wave_sum_f64(ss);
     cc = wave_sum_f64(cc);
     const float area = (float)K;
@@ -272,63 +300,6 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
     mh = mh + 360.0f;
     mh = fmodf(mh, 360.0f); // color.rs:154
 
-    // pass B: sum x, sum x^2 of r g b h' s v he eo da
-    double s1[9], s2[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
-    if (sizeof(T) == 1) {
-        wave_lds_fence();
-        const int Kl = K < cap ? K : cap;
-        if (K > cap) { // tail: pixels that found no room in the list, straight from memory
-            const uint8_t *pb = reinterpret_cast<const uint8_t *>(pp);
-            for (int r0 = 0; r0 < ps; r0 += rpi) {
-                const int r = r0 + rsub;
-                const uint64_t w = __shfl(myrow, r & 63, 64);
-                const int at = __shfl(rowstart, r & 63, 64) + __popcll(w & ((1ull << c) - 1ull));
-                if (r < ps && c < ps && ((w >> c) & 1ull) && at >= cap) {
-                    const int p = r * ps + c;
-                    const unsigned b0 = pb[p], b1 = pb[P + p], b2 = pb[2 * P + p];
-                    float x[9];
-                    pixel_channels<T>(u8_unit(b0), u8_unit(b1), u8_unit(b2), b0, b1, b2, mh, s_od, x);
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) {
-                        const double xd = (double)x[k];
-                        s1[k] += xd;
-                        s2[k] += xd * xd;
-                    }
-                }
-            }
-        }
-        for (int e = lane; e < Kl; e += 64) {
-            const unsigned v = s_list[e];
-            const unsigned b0 = v & 255u, b1 = (v >> 8) & 255u, b2 = v >> 16;
-            float x[9];
-            pixel_channels<T>(u8_unit(b0), u8_unit(b1), u8_unit(b2), b0, b1, b2, mh, s_od, x); // utils.rs:172
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const double xd = (double)x[k];
-                s1[k] += xd;
-                s2[k] += xd * xd;
-            }
-        }
-    } else {
-        for (int r0 = 0; r0 < ps; r0 += rpi) {
-            if (((anyrow >> r0) & (rpi == 2 ? 3ull : 1ull)) == 0ull) continue;
-            const int r = r0 + rsub;
-            const uint64_t w = __shfl(myrow, r & 63, 64);
-            if (r < ps && c < ps && ((w >> c) & 1ull)) {
-                const int p = r * ps + c;
-                float x[9];
-                pixel_channels<T>(Px<T>::ld(pp, p), Px<T>::ld(pp, P + p), Px<T>::ld(pp, 2 * P + p), 0u, 0u, 0u, mh, s_od, x);
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    const double xd = (double)x[k];
-                    s1[k] += xd;
-                    s2[k] += xd * xd;
-                }
-            }
-        }
-    }
     float mean[9], sd[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -410,10 +381,10 @@ hipError_t launch_color(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
         const int64_t blocks = nb8 * bpb;
         if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
         if (job.patches_f32)
-            hipLaunchKernelGGL(k_color<float>, dim3((unsigned)blocks), dim3(256), 16, ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
+            hipLaunchKernelGGL(k_color<float>, dim3((unsigned)blocks), dim3(256), 4 * (size_t)(P < COLOR_LIST_CAP ? P : COLOR_LIST_CAP) * sizeof(unsigned short), ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
                                reinterpret_cast<const float *>(job.patches), job.mask_rows, SC, ctx->od_lut, job.out, job.F, col0);
         else
-            hipLaunchKernelGGL(k_color<uint8_t>, dim3((unsigned)blocks), dim3(256), 4 * (size_t)(P < COLOR_LIST_CAP ? P : COLOR_LIST_CAP) * sizeof(unsigned), ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
+            hipLaunchKernelGGL(k_color<uint8_t>, dim3((unsigned)blocks), dim3(256), 4 * (size_t)(P < COLOR_LIST_CAP ? P : COLOR_LIST_CAP) * sizeof(unsigned short), ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
                                reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, SC, ctx->od_lut, job.out, job.F, col0);
         e = hipGetLastError();
     }
