@@ -240,18 +240,6 @@ static __device__ __forceinline__ double xlnx_of(const GlcmLuts *__restrict__ lu
 }
 static __device__ __forceinline__ unsigned lut_slot(unsigned v) { return v < (unsigned)GL_RANKS ? v : 0u; }
 
-static __device__ __forceinline__ void publish(double *dst, unsigned np, const LevelAcc &A, double ents, double hxs, double hss, int lane)
-{
-    const double v1 = (double)wave_total_u32(A.S1), v2 = (double)wave_total_u32(A.S2);
-    const double v3 = (double)wave_total_u32(A.D1), v4 = (double)wave_total_u32(A.D2);
-    const double v5 = (double)wave_total_f32(A.idm), v6 = (double)wave_total_u32(A.asmn);
-    const double v7 = wave_total_f64(ents), v8 = wave_total_f64(hxs), v9 = wave_total_f64(hss);
-    if (lane == 0) {
-        dst[0] = (double)np; dst[1] = v1; dst[2] = v2; dst[3] = v3; dst[4] = v4;
-        dst[5] = v5; dst[6] = v6; dst[7] = v7; dst[8] = v8; dst[9] = v9;
-    }
-}
-
 // ---- mask-size classes ---------------------------------------------------------------------------------------
 // One list of nucleus indices per hash capacity, filled by k_glcm_classify (order inside a list is irrelevant).
 static constexpr int GL_CLASSES = 4;
@@ -449,7 +437,7 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void 
             A1.ents += rank_tab[pend[0][1]] + rank_tab[pend[1][1]];
             A2.ents += rank_tab[pend[0][2]] + rank_tab[pend[1][2]];
             wave_lds_fence();
-            const unsigned np_w = wave_total_u32(np);
+            unsigned np_w;
             {
                 // fold: read and clear the histogram words, request every x ln x together, and only then do the
                 // table sweep and the power-sum reductions, so the look-ups' round trip hides behind them
@@ -482,9 +470,30 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void 
                     A2.S1 = (s0 * hv[3] + s1 * hv[4]) + (s2 * hv[5] + s3 * hv[6]);
                     A2.S2 = (s0 * s0 * hv[3] + s1 * s1 * hv[4]) + (s2 * s2 * hv[5] + s3 * s3 * hv[6]);
                 }
-                publish(s_sums + 0 * GL_NACC, np_w, A0, A0.ents, hx32, hs32, lane);
-                publish(s_sums + 1 * GL_NACC, np_w, A1, A1.ents, hx64, hs64, lane);
-                publish(s_sums + 2 * GL_NACC, np_w, A2, A2.ents, hx128, hs128, lane);
+                // 28 wave totals at once (wave_ops.h: reduce-scatter butterflies): lane 48 + j ends up with one of them
+                unsigned U[16] = {A0.S1, A0.S2, A0.D1, A0.D2, A0.asmn, A1.S1, A1.S2, A1.D1, A1.D2, A1.asmn,
+                                  A2.S1, A2.S2, A2.D1, A2.D2, A2.asmn, np};
+                double Dv[8] = {A0.ents, hx32, hs32, A1.ents, hx64, hs64, A2.ents, hx128};
+                float Fv[4] = {A0.idm, A1.idm, A2.idm, 0.0f};
+                const unsigned ut = wave_reduce_scatter(U, lane);
+                const double dt = wave_reduce_scatter(Dv, lane);
+                const float ft = wave_reduce_scatter(Fv, lane);
+                const double hs128t = wave_total_f64(hs128);
+                np_w = (unsigned)__builtin_amdgcn_readlane((int)ut, 63); // scatter_index<16>(15) == 15
+                if (lane >= 48) {
+                    const int j = lane - 48;
+                    const int iu = scatter_index<16>(j), id = scatter_index<8>(j & 7), ifl = scatter_index<4>(j & 3);
+                    if (iu < 15) { // level * 5 + {S1, S2, D1, D2, asmn} -> slots 1, 2, 3, 4, 6
+                        const int lvl = iu / 5, f = iu - 5 * lvl;
+                        s_sums[lvl * GL_NACC + (f < 4 ? 1 + f : 6)] = (double)ut;
+                    }
+                    s_sums[(id / 3) * GL_NACC + 7 + id % 3] = dt;                 // level * 3 + {ents, hxs, hss} (hss of level 128 below)
+                    if (ifl < 3) s_sums[ifl * GL_NACC + 5] = (double)ft;         // idm
+                }
+                if (lane == 0) {
+                    s_sums[0 * GL_NACC] = s_sums[1 * GL_NACC] = s_sums[2 * GL_NACC] = (double)np_w;
+                    s_sums[2 * GL_NACC + 9] = hs128t;
+                }
             }
             wave_lds_fence();
             // ================= pass B: level 254 ===================================================================
@@ -524,7 +533,18 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void 
                 for (int m = 4; m < 12; ++m) { const unsigned sv = (unsigned)lane + 64u * (unsigned)(m - 4); A3.S1 += sv * hv[m]; A3.S2 += sv * sv * hv[m]; }
                 const double hx = (e[0] + e[1]) + (e[2] + e[3]);
                 const double hs = ((e[4] + e[5]) + (e[6] + e[7])) + ((e[8] + e[9]) + (e[10] + e[11]));
-                publish(s_sums + 3 * GL_NACC, np_w, A3, A3.ents, hx, hs, lane);
+                unsigned U[8] = {A3.S1, A3.S2, A3.D1, A3.D2, A3.asmn, 0u, 0u, 0u};
+                double Dv[4] = {A3.ents, hx, hs, 0.0};
+                const unsigned ut = wave_reduce_scatter(U, lane);
+                const double dt = wave_reduce_scatter(Dv, lane);
+                const float idm = wave_total_f32(A3.idm);
+                if (lane >= 48) {
+                    const int j = lane - 48;
+                    const int iu = scatter_index<8>(j & 7), id = scatter_index<4>(j & 3);
+                    if (iu < 5) s_sums[3 * GL_NACC + (iu < 4 ? 1 + iu : 6)] = (double)ut;
+                    if (id < 3) s_sums[3 * GL_NACC + 7 + id] = dt;
+                }
+                if (lane == 0) { s_sums[3 * GL_NACC] = (double)np_w; s_sums[3 * GL_NACC + 5] = (double)idm; }
             }
             wave_lds_fence();
             // lane-0 stores straight to memory would touch five partial lines per combination
