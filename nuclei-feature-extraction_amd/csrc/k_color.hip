@@ -290,8 +290,16 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
             pixel(p, on, a0, a1, a2, fa0, fa1, fa2, S[p], Cc[p]);
         }
     }
-    ss = wave_sum_f64(ss);
-    cc = wave_sum_f64(cc);
+    // twenty totals in two reduce-scatter butterflies (wave_ops.h): lane l ends up with sum x and sum x^2 of channel
+    // scatter_index<16>(l & 15) (slots 9 and 10 of the first carry the circular sums), and nine lanes finish the nine
+    // channels side by side
+    double T1[16] = {s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7], s1[8], ss, cc, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double T2[16] = {s2[0], s2[1], s2[2], s2[3], s2[4], s2[5], s2[6], s2[7], s2[8], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const double a = wave_reduce_scatter(T1, lane);
+    const double b = wave_reduce_scatter(T2, lane);
+    // scatter_index<16> reverses the four bits: slot 9 (1001b) sits in lane 9, slot 10 (1010b) in lane 5
+    ss = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 9), __builtin_amdgcn_readlane(__double2loint(a), 9));
+    cc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 5), __builtin_amdgcn_readlane(__double2loint(a), 5));
     const float area = (float)K;
     const float rad2deg = (float)(180.0 / 3.14159265358979323846);
     const float sinm = (float)ss / area, cosm = (float)cc / area;
@@ -300,26 +308,16 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
     mh = mh + 360.0f;
     mh = fmodf(mh, 360.0f); // color.rs:154
 
-    float mean[9], sd[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const double a = wave_sum_f64(s1[k]);
-        const double b = wave_sum_f64(s2[k]);
+    const int k = scatter_index<16>(lane & 15);
+    if (lane < 16 && k < 9) {
         const float mu = (float)a / area;
         const double mud = (double)mu;
         double D = b - 2.0 * mud * a + (double)K * mud * mud; // sum (x-mu)^2 about the f32 mean
         D = D > 0.0 ? D : (D == D ? 0.0 : D);                 // rounding can leave -1e-17; keep NaN
-        mean[k] = mu;
-        sd[k] = sqrtf((float)D / area);
-    }
-    if (lane == 0) {
-        float *o = out + i * (int64_t)F + col0; // column order color.rs:80-99
-        o[0] = mean[0]; o[1] = mean[1]; o[2] = mean[2];
-        o[3] = sd[0];   o[4] = sd[1];   o[5] = sd[2];
-        o[6] = mh;      o[7] = mean[4]; o[8] = mean[5];
-        o[9] = sd[3];   o[10] = sd[4];  o[11] = sd[5];
-        o[12] = mean[6]; o[13] = mean[7]; o[14] = mean[8];
-        o[15] = sd[6];  o[16] = sd[7];  o[17] = sd[8];
+        const float sd = sqrtf((float)D / area);
+        float *o = out + i * (int64_t)F + col0; // column order color.rs:80-99: mean rgb, std rgb, mean hsv, std hsv, mean hed, std hed
+        o[k < 3 ? k : (k < 6 ? 3 + k : 6 + k)] = k == 3 ? mh : mu; // mean_h is the circular mean
+        o[k < 3 ? 3 + k : (k < 6 ? 6 + k : 9 + k)] = sd;
     }
 }
 

@@ -233,24 +233,21 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
             // column sum of run length l over the 4 lanes that share lane%16
             colsum += __shfl_xor(colsum, 16, 64);
             colsum += __shfl_xor(colsum, 32, 64);
-            double rln = lane < 16 ? colsum * colsum : 0.0;
-            nr = rsum(nr); sre = rsum(sre); lre = rsum(lre); lgre = rsum(lgre); hgre = rsum(hgre);
-            srlge = rsum(srlge); srhge = rsum(srhge); lrlge = rsum(lrlge); lrhge = rsum(lrhge);
-            srmge = rsum(srmge); lrmge = rsum(lrmge); srege = rsum(srege); lrege = rsum(lrege);
-            rlm = rsum(rlm); gln = rsum(gln); rln = rsum(rln);
-            if (lane == 0) {
-                float *o = out + i * (int64_t)F + col0 + 17 * d; // column order texture.rs:244-301
-                const double mean = rlm / nr;
-                o[0] = (float)(sre / nr);    o[1] = (float)(lre / nr);
-                o[2] = (float)(gln / nr);    o[3] = (float)(rln / nr);
-                o[4] = (float)(lgre / nr);   o[5] = (float)(hgre / nr);
-                o[6] = (float)(srlge / nr);  o[7] = (float)(srhge / nr);
-                o[8] = (float)(lrlge / nr);  o[9] = (float)(lrhge / nr);
-                o[10] = (float)(srmge / nr); o[11] = (float)(lrmge / nr);
-                o[12] = (float)(srege / nr); o[13] = (float)(lrege / nr);
-                o[14] = (float)(nr / Np);
-                o[15] = (float)mean;
-                o[16] = (float)(lre / nr - mean * mean); // sum R (l-mean)^2 / Nr
+            const double rln = lane < 16 ? colsum * colsum : 0.0;
+            // sixteen totals at once (wave_ops.h: reduce-scatter butterfly), in column order (texture.rs:244-301): lane l then
+            // holds the total of V[scatter_index<16>(l & 15)], and sixteen lanes do the sixteen divisions side by side
+            double V[16] = {sre, lre, gln, rln, lgre, hgre, srlge, srhge, lrlge, lrhge, srmge, lrmge, srege, lrege, nr, rlm};
+            const double tot = wave_reduce_scatter(V, lane);
+            // scatter_index<16> reverses the four bits: V[14] (nr) sits in lanes 7 + 16k, V[15] (rlm) in lanes 15 + 16k
+            const double nr_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 7), __builtin_amdgcn_readlane(__double2loint(tot), 7));
+            const double rlm_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 15), __builtin_amdgcn_readlane(__double2loint(tot), 15));
+            if (lane < 16) {
+                float *o = out + i * (int64_t)F + col0 + 17 * d;
+                const int idx = scatter_index<16>(lane);
+                const double mean = rlm_t / nr_t;
+                const double q = idx == 14 ? nr_t / Np : tot / nr_t; // run_percentage = Nr / Np; everything else over Nr
+                o[idx] = (float)q;                                    // idx 15: run_length_mean
+                if (idx == 1) o[16] = (float)(q - mean * mean);       // run_length_variance = sum R (l-mean)^2 / Nr = lre/nr - mean^2
             }
             wave_lds_fence();
         }
