@@ -284,16 +284,17 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void 
                                              const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
                                              const GlcmLuts *__restrict__ lut, double *__restrict__ sums)
 {
-    // hash slots per list entry: 2 in the first class (its table doubles as the staging area of a 64x64 patch), 11/8
-    // in the larger ones, where the 2.5-10 KB of LDS buy another wave per CU (8, 5 and 3 instead of 7, 4 and 2)
-    constexpr int QCAP = (1 << LOG2SLOTS) / 2, SLOTS = LOG2SLOTS == 10 ? 2 * QCAP : 11 * QCAP / 8;
+    // hash slots per list entry: 11/8 -- the 1.3-10 KB of LDS saved against 2 buy another wave per CU (11, 8, 5 and 3
+    // instead of 10, 7, 4 and 2) -- except in the first class of 64x64 patches, whose table memory doubles as the staging
+    // area of the 12 KB patch
+    constexpr int QCAP = (1 << LOG2SLOTS) / 2, SLOTS = (LOG2SLOTS == 10 && NPRE > 7) ? 2 * QCAP : 11 * QCAP / 8;
     constexpr int TAB_WORDS = GL_H128_OFF + SLOTS;
     __shared__ __attribute__((aligned(16))) unsigned s_mem[TAB_WORDS + GL_HIST_WORDS]; // tables | histograms
     __shared__ unsigned s_q[QCAP + 1];         // list entry: r << 24 | c << 16 | level128 << 8 | level254 (levels 64 and 32
                                              // are level128 >> 1 and >> 2: floor(128 g) >> 1 == floor(64 g))
     __shared__ uint64_t s_rows1[66];         // mask row r at [r + 1]; zero rows either side
     __shared__ unsigned short s_rowstart[66];
-    __shared__ unsigned s_dummy[64];
+    __shared__ unsigned s_dummy[8];    // parking words for the searches of lanes without a pair (lane & 7)
     __shared__ __attribute__((aligned(16))) double s_sums[4 * GL_NACC]; // one offset's sums (four levels), stored as one 320-byte piece
     __shared__ unsigned char s_memo[QCAP + 64];
     unsigned *const s_tab = s_mem, *const s_hist = s_mem + TAB_WORDS;
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void 
         }
         wave_lds_fence();
         sweep(s_hist, GL_HIST_WORDS, 0u, lane);
-        s_dummy[lane] = GL_DUMMY;
+        if (lane < 8) s_dummy[lane] = GL_DUMMY;
         double *sums_i = sums + i * 16 * GL_NACC; // [offset][level][GL_NACC]
 
 #pragma unroll 1
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void 
                 atomicAdd(&s_hist[320 + xa2 + xb2], X.fwd ? 1u : 0u);
                 atomicAdd(&s_hist[320 + ya2 + yb2], Y.fwd ? 1u : 0u);
                 unsigned rx2, ry2;
-                hash_rank2<SLOTS>(s_tab + GL_H128_OFF, s_dummy + lane, cell_key(xa2, xb2), X.fwd, cell_key(ya2, yb2), Y.fwd, rx2, ry2);
+                hash_rank2<SLOTS>(s_tab + GL_H128_OFF, s_dummy + (lane & 7), cell_key(xa2, xb2), X.fwd, cell_key(ya2, yb2), Y.fwd, rx2, ry2);
                 pend[0][0] = pair_acc(X.fwd, xa0, xb0, rx0, A0);
                 pend[1][0] = pair_acc(Y.fwd, ya0, yb0, ry0, A0);
                 pend[0][1] = pair_acc(X.fwd, xa1, xb1, rx1, A1);
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void 
                 atomicAdd(&s_hist[256 + xa + xb], X.fwd ? 1u : 0u);
                 atomicAdd(&s_hist[256 + ya + yb], Y.fwd ? 1u : 0u);
                 unsigned rx, ry;
-                hash_rank2<TAB_WORDS>(s_tab, s_dummy + lane, cell_key(xa, xb), X.fwd, cell_key(ya, yb), Y.fwd, rx, ry);
+                hash_rank2<TAB_WORDS>(s_tab, s_dummy + (lane & 7), cell_key(xa, xb), X.fwd, cell_key(ya, yb), Y.fwd, rx, ry);
                 pend3[0] = pair_acc(X.fwd, xa, xb, rx, A3);
                 pend3[1] = pair_acc(Y.fwd, ya, yb, ry, A3);
                 A3.ents += ev30 + ev31;
@@ -629,10 +630,10 @@ static void launch_classes(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, do
     const T *p = reinterpret_cast<const T *>(job.patches);
     const int P = job.ps * job.ps;
     auto grid = [&](int wgs_per_cu) { const int64_t m = 256ll * wgs_per_cu * 4; return (unsigned)(job.n < m ? job.n : m); };
-    // Smaller classes keep more nuclei in flight per CU (16 KB of LDS per wave for masks up to 512 pixels, 23 KB up
-    // to 1024, 36 KB up to 2048, 62 KB up to 4096).  Blocks beyond a list's length exit at once.
+    // Smaller classes keep more nuclei in flight per CU (15-16 KB of LDS per wave for masks up to 512 pixels, 20 KB up
+    // to 1024, 31 KB up to 2048, 53 KB up to 4096).  Blocks beyond a list's length exit at once.
     const int64_t n = job.n;
-    hipLaunchKernelGGL((k_glcm<T, 10, NPRE>), dim3(grid(10)), dim3(64), 0, ctx->stream, lists + 0 * n, counts + 0, job.ps, p, job.mask_rows, lut, sums);
+    hipLaunchKernelGGL((k_glcm<T, 10, NPRE>), dim3(grid(NPRE <= 7 ? 11 : 10)), dim3(64), 0, ctx->stream, lists + 0 * n, counts + 0, job.ps, p, job.mask_rows, lut, sums);
     if (P > 512) hipLaunchKernelGGL((k_glcm<T, 11, NPRE>), dim3(grid(8)), dim3(64), 0, ctx->stream, lists + 1 * n, counts + 1, job.ps, p, job.mask_rows, lut, sums);
     if (P > 1024) hipLaunchKernelGGL((k_glcm<T, 12, NPRE>), dim3(grid(5)), dim3(64), 0, ctx->stream, lists + 2 * n, counts + 2, job.ps, p, job.mask_rows, lut, sums);
     if (P > 2048) hipLaunchKernelGGL((k_glcm<T, 13, NPRE>), dim3(grid(3)), dim3(64), 0, ctx->stream, lists + 3 * n, counts + 3, job.ps, p, job.mask_rows, lut, sums);
