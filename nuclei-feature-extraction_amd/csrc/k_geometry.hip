@@ -387,8 +387,8 @@ size_t polygon_scratch_bytes(int64_t n, int64_t total_vertices)
     return sizeof(uint32_t) * (size_t)(3 * total_vertices + 4 * n + 16);
 }
 
-template <typename IDX>
-static __device__ __forceinline__ void polygon_one(const float2 *__restrict__ v, int V, IDX *srt, IDX *hull, float *__restrict__ o)
+template <typename IDX, typename VP>
+static __device__ __forceinline__ void polygon_one(VP v, int V, IDX *srt, IDX *hull, float *__restrict__ o)
 {
     auto P = [&](int k) { const float2 f = v[k]; return pt{(double)f.x, (double)f.y}; };
     const double PI = 3.14159265358979323846;
@@ -452,23 +452,50 @@ static __device__ __forceinline__ void polygon_one(const float2 *__restrict__ v,
     o[11] = (float)hperim;
 }
 
+static constexpr int PG_CAPV = 2432; // vertices of one wave's 64 rings kept in LDS (38 per ring on average)
+
 __global__ __launch_bounds__(64) void k_polygon(int64_t n, const uint32_t *__restrict__ poly_off,
                                                 const float *__restrict__ poly_xy, uint32_t *__restrict__ scratch,
                                                 float *__restrict__ out, int F, int col0)
 {
-    __shared__ uint8_t s_idx[64 * PG_SLICE];
-    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t v0 = poly_off[i];
-    const int V = (int)(poly_off[i + 1] - v0);
-    const float2 *v = reinterpret_cast<const float2 *>(poly_xy) + v0;
+    // The sort and the hull walk are chains of dependent vertex reads.  From global memory (L1/L2) each link costs a few
+    // hundred cycles; the rings of the wave's 64 nuclei are therefore copied once into LDS, packed back to back (a wave
+    // scan of the ring lengths gives every lane its slice of the vertex and of the index arrays), and all further reads
+    // are LDS reads.  A wave whose rings do not all fit (more than PG_CAPV vertices in total, or a ring longer than
+    // PG_MAXV) reads them in place, with per-lane index slices of the maximum size.
+    __shared__ __attribute__((aligned(8))) uint8_t s_raw[PG_CAPV * 8 + 3 * PG_CAPV + 64 * 8];
+    static_assert(sizeof(s_raw) >= 64 * PG_SLICE, "the in-place path's index slices fit too");
+    float2 *s_xy = reinterpret_cast<float2 *>(s_raw);
+    uint8_t *s_idx = s_raw + PG_CAPV * 8;
+    const int lane = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = i < n;
+    const uint32_t v0 = live ? poly_off[i] : 0u;
+    const int V = live ? (int)(poly_off[i + 1] - v0) : 0;
+    int incl = V;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    const int first = incl - V;
+    const float2 *gv = reinterpret_cast<const float2 *>(poly_xy) + v0;
+    const bool packed = __all(V <= PG_MAXV && incl <= PG_CAPV); // wave-uniform
     float *o = out + i * (int64_t)F + col0;
-    if (V <= PG_MAXV) {
-        uint8_t *srt = s_idx + threadIdx.x * PG_SLICE;
-        polygon_one<uint8_t>(v, V, srt, srt + PG_MAXV, o);
+    if (packed) {
+        for (int k = 0; k < V; ++k) s_xy[first + k] = gv[k];
+        if (!live) return;
+        uint8_t *srt = s_idx + 3 * first + 8 * lane; // V sort indices, then 2V + 2 hull slots
+        polygon_one<uint8_t, const float2 *>(s_xy + first, V, srt, srt + V, o);
     } else {
-        uint32_t *srt = scratch + 3 * (size_t)v0 + 4 * (size_t)i;
-        polygon_one<uint32_t>(v, V, srt, srt + V, o);
+        if (!live) return;
+        if (V <= PG_MAXV) {
+            uint8_t *srt = s_raw + lane * PG_SLICE;
+            polygon_one<uint8_t, const float2 *__restrict__>(gv, V, srt, srt + PG_MAXV, o);
+        } else {
+            uint32_t *srt = scratch + 3 * (size_t)v0 + 4 * (size_t)i;
+            polygon_one<uint32_t, const float2 *__restrict__>(gv, V, srt, srt + V, o);
+        }
     }
 }
 
