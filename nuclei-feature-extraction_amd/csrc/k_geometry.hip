@@ -21,12 +21,7 @@
 
 namespace nfx {
 
-static __device__ __forceinline__ int wave_sum(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+static __device__ __forceinline__ int wave_sum(int v) { return wave_total_i32(v); } // DPP, no LDS round trips
 
 static __device__ __forceinline__ float readlane_f(float v, int l)
 {
@@ -226,12 +221,12 @@ static __device__ void shape_from_row(uint64_t row, int ps, int lane, float *__r
 #pragma unroll
         for (int k = j + 1; k < 6; ++k) scc += __popcll(mj & PAT[k]) << (j + k + 1);
     }
-    const int K = wave_sum(kr);
-    const int sr = wave_sum(lane * kr);
-    const int scs = wave_sum(sc);
-    const int srr = wave_sum(lane * lane * kr);
-    const int src = wave_sum(lane * sc);
-    const int sccs = wave_sum(scc);
+    // seven totals in one reduce-scatter butterfly (wave_ops.h); lane l holds the total of M[scatter_index<8>(l & 7)]
+    unsigned M[8] = {(unsigned)kr, (unsigned)(lane * kr), (unsigned)sc, (unsigned)(lane * lane * kr), (unsigned)(lane * sc), (unsigned)scc, 0u, 0u};
+    const int tot = (int)wave_reduce_scatter(M, lane);
+    // scatter_index<8> reverses three bits: slots 0..5 sit in lanes 0, 4, 2, 6, 1, 5
+    const int K = __builtin_amdgcn_readlane(tot, 0), sr = __builtin_amdgcn_readlane(tot, 4), scs = __builtin_amdgcn_readlane(tot, 2);
+    const int srr = __builtin_amdgcn_readlane(tot, 6), src = __builtin_amdgcn_readlane(tot, 1), sccs = __builtin_amdgcn_readlane(tot, 5);
 
     // center_of_mass (shape.rs:219-226): integer sums < 2^24 are exact in f32
     const float mu_r = (float)sr / (float)K; // K == 0 -> NaN
