@@ -77,7 +77,19 @@ def main():
     use_dist = world > 1 or (os.environ.get("NFX_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL announces itself on stdout ("Librccl path : ...") when its first communicator comes up; stdout carries the
+        # one JSON line of the contract, so the process's fd 1 points at stderr until the communicator exists
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     n_def, ps, set_names, wl_desc = WORKLOADS[args.workload]
     if args.sets:
@@ -123,6 +135,9 @@ def main():
     d_off64 = d_off.to(torch.int64)
     slice_offs = [(d_off64[bounds[k]:bounds[k + 1] + 1] - v_bounds[k]).to(torch.int32) for k in range(n_slices)]
 
+    out_bufs = [d_out, torch.empty_like(d_out)] if (use_dist and h_patches is None) else [d_out]
+    state = {"step": 0, "pending": []}
+
     def step():
         if h_patches is not None:
             pipeline.extract_streamed(ctx, sets, off, xy, h_patches, ps, batch_size=B, chunk_nuclei=args.chunk, out=d_out)
@@ -132,16 +147,24 @@ def main():
         if not use_dist:
             ctx.extract(sets, d_off, d_xy, d_patches, ps, batch_size=B, out=d_out, want_centroids=False)
             return
+        # two row buffers alternate between steps: the gathers of step k stay in flight while step k+1 computes into the
+        # other buffer, and are waited for (on the stream, not the host) only before their buffer is written again
+        buf = out_bufs[state["step"] & 1]
         works = []
         for k in range(n_slices):
             b0, b1 = bounds[k], bounds[k + 1]
             ctx.extract(sets, slice_offs[k], d_xy[v_bounds[k]:v_bounds[k + 1]], d_patches[b0:b1] if d_patches is not None else None, ps,
-                        batch_size=B, out=d_out[b0:b1], want_centroids=False)
-            works.append(dist.gather(d_out[b0:b1], [g[b0:b1] for g in gather_list] if rank == 0 else None, dst=0, async_op=True))
-        for w in works:
+                        batch_size=B, out=buf[b0:b1], want_centroids=False)
+            works.append(dist.gather(buf[b0:b1], [g[b0:b1] for g in gather_list] if rank == 0 else None, dst=0, async_op=True))
+        for w in state["pending"]:
             w.wait()
+        state["pending"] = works
+        state["step"] += 1
 
     def fence():
+        for w in state["pending"]:
+            w.wait()
+        state["pending"] = []
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
