@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
             const bool rowhas = (anyrow >> r) & 1ull;
             unsigned q = 0xFFu;
             if (rowhas) {
-                const uint64_t w = __shfl(myrow, r, 64);
+                const uint64_t w = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myrow >> 32), r) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane((int)(unsigned)myrow, r); // r is wave-uniform
                 if (vec) {
                     if (lane < ps) q = s_q[r * QS + lane];
                 } else if (lane < ps && ((w >> lane) & 1ull)) {
@@ -159,9 +160,11 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
                     s_q[r * QS + lane] = (uint8_t)qi;
                 }
                 // predecessors: (1,0) left; (1,1) up-left; (0,1) up; (-1,1) up-right      (dx,dy) texture.rs:176
-                unsigned ql = __shfl_up(q, 1, 64), pul = __shfl_up(qprev, 1, 64), pur = __shfl_down(qprev, 1, 64);
-                if (lane == 0) { ql = 0xFFu; pul = 0xFFu; }
-                if (lane == 63) pur = 0xFFu;
+                // neighbours through whole-wave DPP shifts (one VALU op each, no LDS round trip); the lane that has no
+                // neighbour keeps the 'outside the mask' level
+                const unsigned ql = (unsigned)__builtin_amdgcn_update_dpp(0xFF, (int)q, 0x138, 0xF, 0xF, false);      // wave_shr:1
+                const unsigned pul = (unsigned)__builtin_amdgcn_update_dpp(0xFF, (int)qprev, 0x138, 0xF, 0xF, false);
+                const unsigned pur = (unsigned)__builtin_amdgcn_update_dpp(0xFF, (int)qprev, 0x130, 0xF, 0xF, false);  // wave_shl:1
                 const bool on = q != 0xFFu;
                 const uint64_t c0 = __ballot(on && ql == q), c1 = __ballot(on && pul == q);
                 const uint64_t c2 = __ballot(on && qprev == q), c3 = __ballot(on && pur == q);
@@ -183,8 +186,10 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
             uint64_t b0 = 0, b1 = 0, b2 = 0, b3 = 0; // bit-sliced min(length,16)-1 per start
             for (int k = 1; k < RL_MAXLEN; ++k) {
                 if (dy) {
-                    Y = __shfl_down(Y, 1, 64);
-                    if (lane == 63) Y = 0ull;
+                    // the next row's word: whole-wave DPP shift, lane 63 receives zero
+                    const unsigned ylo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)Y, 0x130, 0xF, 0xF, false);
+                    const unsigned yhi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(Y >> 32), 0x130, 0xF, 0xF, false);
+                    Y = ((uint64_t)yhi << 32) | ylo;
                 }
                 const uint64_t X = dx > 0 ? (Y >> k) : (dx < 0 ? (Y << k) : Y);
                 alive &= X;
