@@ -40,6 +40,19 @@ template <> struct RPx<float> {
 
 static __device__ __forceinline__ double rsum(double v) { return wave_total_f64(v); }
 
+// bit i of the result: byte i of a equals byte i of b (exact zero-byte test of a ^ b, then the four flag bits gathered)
+static __device__ __forceinline__ unsigned eq4(unsigned a, unsigned b)
+{
+    const unsigned x = a ^ b;
+    const unsigned y = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x; // bit 7 of a byte set iff the byte is non-zero
+    const unsigned t = (~y & 0x80808080u) >> 7;                // bits 0, 8, 16, 24
+    return (t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu;
+}
+static __device__ __forceinline__ unsigned eq16(const unsigned (&a)[4], unsigned b0, unsigned b1, unsigned b2, unsigned b3)
+{
+    return eq4(a[0], b0) | (eq4(a[1], b1) << 4) | (eq4(a[2], b2) << 8) | (eq4(a[3], b3) << 12);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__restrict__ patches,
                                               const uint64_t *__restrict__ mask_rows, float *__restrict__ out, int F,
@@ -49,10 +62,12 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
     __shared__ uint8_t s_q_all[4][NFX_MAX_PATCH_SIZE * QS];
     __shared__ unsigned s_R_all[4][RL_BINS];
     __shared__ uint64_t s_rows_all[4][64];
+    __shared__ __attribute__((aligned(16))) uint64_t s_C_all[4][4 * 64]; // vector path: C_d[r] assembled from 16-bit pieces
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint8_t *s_q = s_q_all[wv];
     unsigned *s_R = s_R_all[wv];
     uint64_t *s_rows = s_rows_all[wv];
+    uint64_t *s_C = s_C_all[wv];
     const int P = ps * ps;
     // vector staging: rows are whole 16-byte pieces, every patch starts on a 16-byte boundary
     constexpr int NPC = NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE / 16 / 64; // pieces per lane and channel (4)
@@ -98,9 +113,12 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
     for (int64_t i = (int64_t)blockIdx.x * 4 + wv; i < n; i += istep) {
         const uint64_t myrow = row_next;
         const uint64_t anyrow = __ballot(myrow != 0ull);
+        unsigned lvl[NPC][4]; // vector path: the sixteen levels of each of this lane's pieces
         if (vec) {
             // quantise this lane's pieces and put the levels down (0xFF outside the mask), then ask for the next nucleus
             s_rows[lane] = myrow;
+            reinterpret_cast<uint4 *>(s_C)[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
+            reinterpret_cast<uint4 *>(s_C)[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
             wave_lds_fence();
 #pragma unroll
             for (int k = 0; k < NPC; ++k) {
@@ -111,7 +129,7 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
                     const unsigned rr[4] = {pre[0][k].x, pre[0][k].y, pre[0][k].z, pre[0][k].w};
                     const unsigned gg[4] = {pre[1][k].x, pre[1][k].y, pre[1][k].z, pre[1][k].w};
                     const unsigned bb[4] = {pre[2][k].x, pre[2][k].y, pre[2][k].z, pre[2][k].w};
-                    unsigned packed[4];
+                    unsigned (&packed)[4] = lvl[k];
 #pragma unroll
                     for (int w4 = 0; w4 < 4; ++w4) {
                         unsigned word = 0;
@@ -133,6 +151,38 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
                 }
             }
             wave_lds_fence();
+            // "continues its predecessor" bits of all sixteen pixels of a piece at once (SWAR byte compares against the
+            // neighbouring words of the level map), per direction (dx,dy) of texture.rs:176: predecessor left, up-left, up,
+            // up-right.  The 16-bit results are filed into C_d[r] through LDS; lane r picks its four words up below.
+#pragma unroll
+            for (int k = 0; k < NPC; ++k) {
+                const int piece = lane + 64 * k;
+                if (piece < npieces) {
+                    const int p0 = 16 * piece, r = p0 / ps, c0 = p0 - r * ps;
+                    const unsigned mrow = (unsigned)(s_rows[r] >> c0) & 0xFFFFu;
+                    const unsigned *own = reinterpret_cast<const unsigned *>(s_q + r * QS + c0);
+                    const unsigned *up = reinterpret_cast<const unsigned *>(s_q + (r > 0 ? r - 1 : 0) * QS + c0);
+                    const bool has_up = r > 0, has_l = c0 > 0, has_r = c0 + 16 < ps;
+                    const unsigned none = 0xFFFFFFFFu;
+                    const unsigned lw = has_l ? own[-1] : none;
+                    const unsigned um = (has_up && has_l) ? up[-1] : none, up4 = (has_up && has_r) ? up[4] : none;
+                    const unsigned u0 = has_up ? up[0] : none, u1 = has_up ? up[1] : none, u2 = has_up ? up[2] : none, u3 = has_up ? up[3] : none;
+                    const unsigned (&o4)[4] = lvl[k];
+                    const unsigned c_l = eq16(o4, __builtin_amdgcn_alignbyte(o4[0], lw, 3), __builtin_amdgcn_alignbyte(o4[1], o4[0], 3),
+                                              __builtin_amdgcn_alignbyte(o4[2], o4[1], 3), __builtin_amdgcn_alignbyte(o4[3], o4[2], 3));
+                    const unsigned c_ul = eq16(o4, __builtin_amdgcn_alignbyte(u0, um, 3), __builtin_amdgcn_alignbyte(u1, u0, 3),
+                                               __builtin_amdgcn_alignbyte(u2, u1, 3), __builtin_amdgcn_alignbyte(u3, u2, 3));
+                    const unsigned c_u = eq16(o4, u0, u1, u2, u3);
+                    const unsigned c_ur = eq16(o4, __builtin_amdgcn_alignbyte(u1, u0, 1), __builtin_amdgcn_alignbyte(u2, u1, 1),
+                                               __builtin_amdgcn_alignbyte(u3, u2, 1), __builtin_amdgcn_alignbyte(up4, u3, 1));
+                    unsigned short *cw = reinterpret_cast<unsigned short *>(s_C) + r * 4 + (c0 >> 4);
+                    cw[0 * 256] = (unsigned short)(c_l & mrow);  // only masked pixels continue anything (0xFF == 0xFF does not count)
+                    cw[1 * 256] = (unsigned short)(c_ul & mrow);
+                    cw[2 * 256] = (unsigned short)(c_u & mrow);
+                    cw[3 * 256] = (unsigned short)(c_ur & mrow);
+                }
+            }
+            wave_lds_fence();
         }
         if (i + istep < n) request(i + istep);
         const double Np = (double)wave_total_i32(__popcll(myrow)); // pixel_count, texture.rs:196
@@ -140,8 +190,16 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
 
         // ---- staging: level map + the four "continues" words of every row ---------------------------------
         int clo[4] = {0, 0, 0, 0}, chi[4] = {0, 0, 0, 0}; // C_d[lane] as two 32-bit halves
+        if (vec) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint64_t cd = s_C[d * 64 + lane];
+                clo[d] = (int)(unsigned)cd;
+                chi[d] = (int)(unsigned)(cd >> 32);
+            }
+        }
         unsigned qprev = 0xFFu;                             // the previous row's level in this lane's column
-        for (int r = 0; r < ps; ++r) {
+        for (int r = 0; r < (vec ? 0 : ps); ++r) {
             const bool rowhas = (anyrow >> r) & 1ull;
             unsigned q = 0xFFu;
             if (rowhas) {
