@@ -1,0 +1,69 @@
+"""Error behaviour of the C ABI (SURVEY.md §8b "Errors"): the reference panics (assert!/unwrap, shape.rs:23-47,
+texture.rs:166) or exits (args.rs:137-183); the ABI returns a status and leaves a message in nfx_last_error, and a
+failed call leaves the context usable."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _parity as par
+
+pytestmark = pytest.mark.gpu
+
+OK, INVALID, UNSUPPORTED = 0, 1, 2
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _extract(nfx, ctx, sets, off, xy, pu8, ps, batch, n=None, nv=None, out=True):
+    L = nfx.lib()
+    n = len(off) - 1 if n is None else n
+    nv = int(off[-1]) if nv is None else nv
+    F = sum(nfx.num_columns(s) for s in sets if 0 <= s < 5) or 1
+    rows = np.zeros((max(n, 1), F), np.float32)
+    cen = np.zeros((max(n, 1), 2), np.float32)
+    s = np.asarray(sets, np.int32)
+    st = L.nfx_extract(ctx._h, _ptr(s, C.c_int32), len(sets), n, nv, _ptr(off, C.c_uint32), _ptr(xy, C.c_float), _ptr(pu8, C.c_uint8), ps, batch,
+                       _ptr(rows, C.c_float) if out else None, _ptr(cen, C.c_float), 0)
+    return st, L.nfx_last_error(ctx._h).decode()
+
+
+def test_invalid_arguments_are_reported_not_executed(nfx):
+    ctx = nfx.Context(0)
+    ps = 32
+    off, xy, pu8 = par.make_inputs(3, 20, ps)
+    off = off.astype(np.uint32)
+    cases = [
+        (dict(sets=[7]), INVALID, "unknown feature set"),
+        (dict(sets=[]), INVALID, "no feature set"),
+        (dict(batch=0), INVALID, "batch_size"),
+        (dict(ps=0), INVALID, "patch size"),
+        (dict(ps=65), UNSUPPORTED, "patch size > 64"),
+        (dict(n=-1), INVALID, "negative"),
+        (dict(nv=int(off[-1]) - 1), INVALID, "ring_offsets[n] != n_vertices"),
+        (dict(out=False), INVALID, "null"),
+        (dict(pu8=None, sets=[1]), INVALID, "null"),                 # a pixel set without pixels
+    ]
+    for kw, want, text in cases:
+        a = dict(sets=[0, 1], off=off, xy=xy, pu8=pu8, ps=ps, batch=100)
+        a.update(kw)
+        st, msg = _extract(nfx, ctx, a["sets"], a["off"], a["xy"], a["pu8"], a["ps"], a["batch"], a.get("n"), a.get("nv"), a.get("out", True))
+        assert st == want and text in msg, (kw, st, msg)
+    # geometry alone needs no pixels; and the context still works after nine failed calls
+    st, msg = _extract(nfx, ctx, [0], off, xy, None, ps, 100)
+    assert st == OK, msg
+    rows, _ = ctx.extract([0, 1], off, xy, pu8, ps)
+    assert rows.shape == (20, 30) and np.isfinite(rows[:, 0]).all()
+    ctx.close()
+
+
+def test_null_context_and_bad_device(nfx):
+    L = nfx.lib()
+    assert L.nfx_ctx_synchronize(None) == INVALID
+    h = C.c_void_p()
+    assert L.nfx_ctx_create(4096, C.byref(h)) == 3          # NFX_ERR_DEVICE: no such device
+    assert L.nfx_ctx_create(0, None) == INVALID
+    with pytest.raises(nfx.NfxError):
+        nfx.Context(4096)
