@@ -211,12 +211,7 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
     const double *Cc = S + P;
 
     const int rcnt = __popcll(myrow);
-    int incl = rcnt; // list position of the first pixel of this lane's row = exclusive prefix over the rows
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-    }
+    const int incl = wave_inclusive_scan_i32(rcnt); // list position of the first pixel of this lane's row = exclusive prefix over the rows
     const int K = __builtin_amdgcn_readlane(incl, 63);
     const int rowstart = incl - rcnt;
     {   // position list: lane = column, stores only (no round trip in the loop)

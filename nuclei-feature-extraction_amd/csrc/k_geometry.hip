@@ -85,12 +85,7 @@ static __device__ __forceinline__ uint64_t raster_row(const uint32_t *__restrict
             nrows = (int)db - ra;
             nrows = (nrows > 0 && ylo < yhi) ? nrows : 0;
         }
-        int incl = nrows;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
-        }
+        const int incl = wave_inclusive_scan_i32(nrows);
         const int total = __builtin_amdgcn_readlane(incl, 63);
         if (total > RS_CAP) {
             const double py = (double)lane - half;
@@ -467,12 +462,7 @@ __global__ __launch_bounds__(64) void k_polygon(int64_t n, const uint32_t *__res
     const bool live = i < n;
     const uint32_t v0 = live ? poly_off[i] : 0u;
     const int V = live ? (int)(poly_off[i + 1] - v0) : 0;
-    int incl = V;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-    }
+    const int incl = wave_inclusive_scan_i32(V);
     const int first = incl - V;
     const float2 *gv = reinterpret_cast<const float2 *>(poly_xy) + v0;
     const bool packed = __all(V <= PG_MAXV && incl <= PG_CAPV); // wave-uniform

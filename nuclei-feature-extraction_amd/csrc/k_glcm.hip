@@ -49,7 +49,8 @@ namespace nfx {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int GL_NACC = 10;
-static constexpr int GL_RANKS = 4096;      // rank / count range of the global difference tables
+static constexpr int GL_RANKS = 4096;      // rank range of the global difference tables (a cell holds at most 4032 pairs)
+static constexpr int GL_COUNTS = 8200;     // count range of the x ln x table (a marginal bin holds at most 2 * 4032)
 static constexpr int GL_HIST_WORDS = 768;
 static constexpr unsigned GL_EMPTY = 0xFFFFFFFFu;
 static constexpr int GL_D64_OFF = 272;     // pass A: d32 at 0 (264 words) | d64 at 272 (1040 words) | h128 at 1320
@@ -60,7 +61,7 @@ __constant__ int kGlcmOffsets[4][2] = {{0, 1}, {1, 1}, {1, 0}, {1, -1}}; // text
 struct GlcmLuts {           // device tables built on the host
     double dO[GL_RANKS];    // 2[h(k+1)-h(k)]
     double dD[GL_RANKS];    // H(k+1)-H(k)
-    double xlnx[GL_RANKS];  // x ln x
+    double xlnx[GL_COUNTS]; // x ln x
 };
 
 struct LevelAcc {
@@ -234,11 +235,9 @@ static __device__ __forceinline__ void sweep(unsigned *tab, int words, unsigned 
     for (int k = lane; k < words / 4; k += 64) t4[k] = v;
 }
 
-static __device__ __forceinline__ double xlnx_of(const GlcmLuts *__restrict__ lut, unsigned v, double fetched)
-{
-    return v < (unsigned)GL_RANKS ? fetched : (double)v * log((double)v); // beyond the table: masks above 2048 pixels
-}
-static __device__ __forceinline__ unsigned lut_slot(unsigned v) { return v < (unsigned)GL_RANKS ? v : 0u; }
+// histogram counts never leave the x ln x table (GL_COUNTS): no clamp, no fallback
+static __device__ __forceinline__ double xlnx_of(const GlcmLuts *__restrict__, unsigned, double fetched) { return fetched; }
+static __device__ __forceinline__ unsigned lut_slot(unsigned v) { return v; }
 
 // ---- mask-size classes ---------------------------------------------------------------------------------------
 // One list of nucleus indices per hash capacity, filled by k_glcm_classify (order inside a list is irrelevant).
@@ -343,12 +342,7 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void 
         }
         // ---- row prefix ---------------------------------------------------------------------------------------
         const int rcnt = __popcll(myrow);
-        int inc = rcnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += v;
-        }
+        const int inc = wave_inclusive_scan_i32(rcnt);
         const int K = __builtin_amdgcn_readlane(inc, 63);
         const int excl = inc - rcnt;
         if (lane < ps) s_rows1[lane + 1] = myrow;
@@ -365,19 +359,25 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void 
         wave_lds_fence();
         // ---- every masked pixel is read and quantised once, all lanes busy --------------------------------------
         const T *pp = patches + (size_t)i * 3 * P;
-        for (int e = lane; e < K; e += 64) {
-            const unsigned pos = s_q[e];
-            const int p = (int)(pos >> 24) * ps + (int)((pos >> 16) & 255u);
-            float g;
+        for (int e = lane; e < K; e += 128) { // two entries per lane: both read chains in flight
+            const int e2 = e + 64 < K ? e + 64 : e;
+            const unsigned pos = s_q[e], pos2 = s_q[e2];
+            const int p = (int)(pos >> 24) * ps + (int)((pos >> 16) & 255u), p2 = (int)(pos2 >> 24) * ps + (int)((pos2 >> 16) & 255u);
+            float g, g2;
             if (stage) {
                 const uint8_t *sb = reinterpret_cast<const uint8_t *>(s_mem);
-                float gs = u8_unit(sb[p]) + u8_unit(sb[P + p]); // utils.rs:172
-                gs = gs + u8_unit(sb[2 * P + p]);
-                g = third_of_u8_sum(gs);                        // texture.rs:36
+                const unsigned r0 = sb[p], g0 = sb[P + p], b0 = sb[2 * P + p], r1 = sb[p2], g1 = sb[P + p2], b1 = sb[2 * P + p2];
+                float gs = u8_unit(r0) + u8_unit(g0), gs2 = u8_unit(r1) + u8_unit(g1); // utils.rs:172
+                gs = gs + u8_unit(b0);
+                gs2 = gs2 + u8_unit(b1);
+                g = third_of_u8_sum(gs);                                                // texture.rs:36
+                g2 = third_of_u8_sum(gs2);
             } else {
                 g = gray_at<T>(pp, P, p);
+                g2 = gray_at<T>(pp, P, p2);
             }
             s_q[e] = pos | (quant(g, 128) << 8) | quant(g, 254); // texture.rs:19
+            if (e + 64 < K) s_q[e + 64] = pos2 | (quant(g2, 128) << 8) | quant(g2, 254);
         }
         wave_lds_fence();
         sweep(s_hist, GL_HIST_WORDS, 0u, lane);
@@ -612,13 +612,14 @@ size_t glcm_scratch_bytes(const Job &job)
 static hipError_t ensure_luts(nfx_ctx *ctx)
 {
     if (ctx->glcm_lut) return hipSuccess;
-    std::vector<double> h(3 * GL_RANKS);
+    std::vector<double> h(2 * GL_RANKS + GL_COUNTS);
     auto xl = [](double x) { return x > 0.0 ? x * std::log(x) : 0.0; };
     for (int k = 0; k < GL_RANKS; ++k) {
         h[k] = 2.0 * (xl(k + 1.0) - xl((double)k));                       // dO
         h[GL_RANKS + k] = xl(2.0 * (k + 1.0)) - xl(2.0 * (double)k);      // dD: H(x) = 2x ln 2x
-        h[2 * GL_RANKS + k] = xl((double)k);                              // x ln x
     }
+    for (int k = 0; k < GL_COUNTS; ++k) h[2 * GL_RANKS + k] = xl((double)k); // x ln x
+    static_assert(sizeof(GlcmLuts) == sizeof(double) * (2 * GL_RANKS + GL_COUNTS), "table layout");
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->glcm_lut), sizeof(double) * h.size());
     if (e != hipSuccess) return e;
     return hipMemcpy(ctx->glcm_lut, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);

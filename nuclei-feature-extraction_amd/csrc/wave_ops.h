@@ -24,6 +24,19 @@ static __device__ __forceinline__ int wave_total_i32(int v)
 }
 static __device__ __forceinline__ unsigned wave_total_u32(unsigned v) { return (unsigned)wave_total_i32((int)v); }
 
+// inclusive prefix sum over the 64 lanes, DPP only: Hillis-Steele inside each row of 16 (row_shr 1, 2, 4, 8 with zero
+// fill), then the row totals carried across rows (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3)
+static __device__ __forceinline__ int wave_inclusive_scan_i32(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true); // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); // row_bcast15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); // row_bcast31
+    return v;
+}
+
 template <int CTRL, int ROW_MASK>
 static __device__ __forceinline__ float dpp_f32(float v)
 {
