@@ -7,16 +7,24 @@
 
 namespace nfx {
 
-// One lane per nucleus: the centroid is a SEQUENTIAL f32 sum over the listed ring vertices
-// (utils.rs:56-64), so the summation order is part of the result and is kept.
+// One lane per nucleus for the centroid: it is a SEQUENTIAL f32 sum over the listed ring vertices (utils.rs:56-64), so
+// the summation order is part of the result and is kept.  The centred vertices are then written by the whole wave: the
+// 64 rings of a wave are one contiguous run of vertices, lane l takes vertices l, l + 64, ... of the run and finds the
+// ring of each by a binary search over the wave's offsets (LDS) -- coalesced 8-byte loads and stores instead of 64
+// separate streams.
 __global__ __launch_bounds__(256) void k_preprocess(int64_t n, const uint32_t *__restrict__ ring_off,
                                                     const float *__restrict__ ring_xy, float *__restrict__ centroids,
                                                     float *__restrict__ centred)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t v0 = ring_off[i], v1 = ring_off[i + 1];
+    __shared__ uint32_t s_off[4][65];
+    __shared__ float2 s_cen[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wv) * 64; // first nucleus of this wave
+    if (i0 >= n) return;                                    // wave-uniform
+    const int64_t i = i0 + lane;
+    const int live = (int)((n - i0) < 64 ? (n - i0) : 64);  // nuclei of this wave
     const float2 *p = reinterpret_cast<const float2 *>(ring_xy);
+    const uint32_t v0 = ring_off[i < n ? i : n], v1 = ring_off[i < n ? i + 1 : n];
     float ax = 0.0f, ay = 0.0f;
     for (uint32_t k = v0; k < v1; ++k) {
         const float2 v = p[k];
@@ -25,16 +33,27 @@ __global__ __launch_bounds__(256) void k_preprocess(int64_t n, const uint32_t *_
     }
     const float cnt = (float)(v1 - v0);
     const float cx = ax / cnt, cy = ay / cnt;
-    if (centroids) {
+    if (centroids && i < n) {
         centroids[2 * i] = cx;
         centroids[2 * i + 1] = cy;
     }
-    if (centred) {
-        float2 *q = reinterpret_cast<float2 *>(centred);
-        for (uint32_t k = v0; k < v1; ++k) {
-            const float2 v = p[k];
-            q[k] = make_float2(v.x - cx, v.y - cy);
+    if (!centred) return;
+    s_off[wv][lane] = v0;
+    if (lane == 63) s_off[wv][64] = v1;
+    s_cen[wv][lane] = make_float2(cx, cy);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t va = s_off[wv][0], vb = s_off[wv][live];
+    float2 *q = reinterpret_cast<float2 *>(centred);
+    for (uint32_t v = va + (uint32_t)lane; v < vb; v += 64u) {
+        int lo = 0, hi = live - 1; // last ring whose first vertex is <= v (empty rings share their start with the next one
+        while (lo < hi) {          // and are never chosen: the search keeps the LAST such ring)
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_off[wv][mid] <= v) lo = mid; else hi = mid - 1;
         }
+        const float2 c = s_cen[wv][lo], x = p[v];
+        q[v] = make_float2(x.x - c.x, x.y - c.y);
     }
 }
 
