@@ -15,8 +15,10 @@ python3 bench.py --workload config2 --steps 20 --warmup 3 > $OUT/${TAG}_config2_
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/kt.log 2>&1
 cp "$(find $OUT/kt -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_config3_kernel_stats_full.csv
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C -d $OUT/pmc_$C --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
+for WL in config3; do   # config5 under --pmc spends minutes in the data generator's thousands of small dispatches
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $C -d $OUT/pmc_${WL}_$C --output-format csv -- python3 $ROOT/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_${WL}_$C.log 2>&1
+  done
 done
 python3 - <<PY
 import csv, glob, json, collections
@@ -26,26 +28,28 @@ rows = [r for r in csv.DictReader(open(f"{out}/{tag}_config3_kernel_stats_full.c
 with open(f"{out}/{tag}_config3_kernel_stats.csv", "w") as f:
     f.write("kernel,calls,total_ns,average_ns,min_ns,max_ns\n")
     for r in rows: f.write(f"\"{r['Name'].split('(')[0]}\",{r['Calls']},{r['TotalDurationNs']},{r['AverageNs']},{r['MinNs']},{r['MaxNs']}\n")
-# PMC passes: mean value per launch per kernel
-acc = collections.defaultdict(lambda: [0.0, 0])
-for C in ("FETCH_SIZE", "WRITE_SIZE"):
-    for fn in glob.glob(f"{out}/pmc_{C}/**/*counter_collection.csv", recursive=True):
-        per_dispatch = collections.defaultdict(float)
-        for r in csv.DictReader(open(fn)):
-            if r["Counter_Name"] == C and "nfx" in r["Kernel_Name"]:
-                per_dispatch[(r["Dispatch_Id"], r["Kernel_Name"].split("(")[0])] += float(r["Counter_Value"])
-        for (d, k), v in per_dispatch.items():
-            acc[(C, k)][0] += v; acc[(C, k)][1] += 1
-with open(f"{out}/{tag}_config3_pmc_fetch_write.csv", "w") as f:
-    f.write("counter,kernel,launches,\"mean_value_per_launch (KB; rocprofv3 --pmc, separate passes)\"\n")
-    for (C, k), (v, n) in sorted(acc.items()): f.write(f"{C},\"{k}\",{n},{v / n}\n")
-# GLCM traffic per step: classify + every size class + finish; FETCH doubled per the gfx950 note
 steps = 3  # warmup 1 + steps 2
-fetch = sum(v for (C, k), (v, n) in acc.items() if C == "FETCH_SIZE" and "glcm" in k) / steps
-write = sum(v for (C, k), (v, n) in acc.items() if C == "WRITE_SIZE" and "glcm" in k) / steps
-traffic = {"config3": {"kernel": "k_glcm", "traffic_bytes_per_launch": int((2 * fetch + write) * 1024),
-    "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), profiles/{tag}_config3_pmc_fetch_write.csv; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the k_glcm_classify + k_glcm<10..13> + k_glcm_finish launches of one step; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts half of 16-B/lane streams; the 8-B/lane mask-row and table reads are uncalibrated)"}}
+traffic = {}
+for wl, dom in (("config3", "glcm"),):
+    # PMC passes: mean value per launch per kernel
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for C in ("FETCH_SIZE", "WRITE_SIZE"):
+        for fn in glob.glob(f"{out}/pmc_{wl}_{C}/**/*counter_collection.csv", recursive=True):
+            per_dispatch = collections.defaultdict(float)
+            for r in csv.DictReader(open(fn)):
+                if r["Counter_Name"] == C and "nfx" in r["Kernel_Name"]:
+                    per_dispatch[(r["Dispatch_Id"], r["Kernel_Name"].split("(")[0])] += float(r["Counter_Value"])
+            for (d, k), v in per_dispatch.items():
+                acc[(C, k)][0] += v; acc[(C, k)][1] += 1
+    with open(f"{out}/{tag}_{wl}_pmc_fetch_write.csv", "w") as f:
+        f.write("counter,kernel,launches,\"mean_value_per_launch (KB; rocprofv3 --pmc, separate passes)\"\n")
+        for (C, k), (v, n) in sorted(acc.items()): f.write(f"{C},\"{k}\",{n},{v / n}\n")
+    # the dominant kernel's traffic per step (every launch that belongs to it); FETCH doubled per the gfx950 note
+    fetch = sum(v for (C, k), (v, n) in acc.items() if C == "FETCH_SIZE" and dom in k) / steps
+    write = sum(v for (C, k), (v, n) in acc.items() if C == "WRITE_SIZE" and dom in k) / steps
+    traffic[wl] = {"kernel": "k_" + dom, "traffic_bytes_per_launch": int((2 * fetch + write) * 1024),
+        "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), profiles/{tag}_{wl}_pmc_fetch_write.csv; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over every k_{dom}* launch of one step; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts half of 16-B/lane streams; narrower reads are uncalibrated)"}
 json.dump(traffic, open(f"{out}/{tag}_pmc_traffic.json", "w"), indent=1)
-print(open(f"{out}/{tag}_config3_kernel_stats.csv").read()); print(json.dumps(traffic)[:300])
+print(open(f"{out}/{tag}_config3_kernel_stats.csv").read()); print(json.dumps(traffic)[:600])
 PY
 tail -n 1 $OUT/${TAG}_config3_bench.json $OUT/${TAG}_config5_bench.json $OUT/${TAG}_config2_bench.json
