@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void k_glcm_classify(int64_t n, int ps, const 
 // LOG2SLOTS: size class; serves the nuclei of its class list (K <= 2^LOG2SLOTS / 2 mask pixels).
 // NPRE: 16-byte pieces of a u8 patch per lane (3 ps^2 / 1024 rounded up: 3, 7 or 12 for ps <= 32, 48, 64)
 template <typename T, int LOG2SLOTS, int NPRE>
-__global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : 2)) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int ps,
+__global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : (LOG2SLOTS <= 12 ? 2 : 1))) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int ps,
                                              const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
                                              const GlcmLuts *__restrict__ lut, double *__restrict__ sums)
 {
