@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_hue_batch(int64_t n, int ps, int batch_
 {
     const int P = ps * ps;
     const int64_t b = blockIdx.y;
-    const int px = (blockIdx.x * 256 + threadIdx.x) * VEC;
+    const int px = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (px >= P) return;
     const int64_t j0 = b * batch_size;
     const int64_t j1 = (j0 + batch_size) < n ? (j0 + batch_size) : n;
@@ -357,8 +357,16 @@ hipError_t launch_color(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
                 hipLaunchKernelGGL((k_hue_batch<float, 1>), grid, dim3(256), 0, ctx->stream, nn, job.ps, job.batch_size,
                                    reinterpret_cast<const float *>(job.patches) + (size_t)j0 * 3 * P, SC + (size_t)b0 * 2 * P);
             else if ((P & 3) == 0 && (reinterpret_cast<uintptr_t>(job.patches) & 3) == 0) {
-                dim3 grid4((unsigned)((P / 4 + 255) / 256), (unsigned)nbs);
-                hipLaunchKernelGGL((k_hue_batch<uint8_t, 4>), grid4, dim3(256), 0, ctx->stream, nn, job.ps, job.batch_size,
+                // block size: the multiple of 64 (up to 256) that wastes the fewest lanes on a patch's P/4 pixel groups
+                // (48x48: 576 groups = 3 blocks of 192, not 2.25 blocks of 256)
+                const int groups = P / 4;
+                int bs = 256, waste = (groups + 255) / 256 * 256 - groups;
+                for (int cand = 192; cand >= 64; cand -= 64) {
+                    const int w = (groups + cand - 1) / cand * cand - groups;
+                    if (w < waste) { waste = w; bs = cand; }
+                }
+                dim3 grid4((unsigned)((groups + bs - 1) / bs), (unsigned)nbs);
+                hipLaunchKernelGGL((k_hue_batch<uint8_t, 4>), grid4, dim3(bs), 0, ctx->stream, nn, job.ps, job.batch_size,
                                    reinterpret_cast<const uint8_t *>(job.patches) + (size_t)j0 * 3 * P, SC + (size_t)b0 * 2 * P);
             } else
                 hipLaunchKernelGGL((k_hue_batch<uint8_t, 1>), grid, dim3(256), 0, ctx->stream, nn, job.ps, job.batch_size,
