@@ -139,7 +139,9 @@ __global__ __launch_bounds__(256) void k_hue_batch(int64_t n, int ps, int batch_
                          b4 = *reinterpret_cast<const uchar4 *>(pb + 2 * P + px);
             const uint8_t rr[4] = {r4.x, r4.y, r4.z, r4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) { r[q] = u8_unit(rr[q]); g[q] = u8_unit(gg[q]); bl[q] = u8_unit(bb[q]); }
+            // the hue angle depends on the channels only through order and the ratio of two differences: the raw byte
+            // values serve as well as value/255 (the quotient moves by 2e-7 relative, inside hue_sincos' own deviation)
+            for (int q = 0; q < VEC; ++q) { r[q] = (float)rr[q]; g[q] = (float)gg[q]; bl[q] = (float)bb[q]; }
         } else {
 #pragma unroll
             for (int q = 0; q < VEC; ++q) { r[q] = Px<T>::ld(p, px + q); g[q] = Px<T>::ld(p, P + px + q); bl[q] = Px<T>::ld(p, 2 * P + px + q); }
