@@ -235,8 +235,12 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
     // r g b h s v he eo da.  The hue statistics are taken on h itself: the reference shifts h by mean_h first
     // (color.rs:52), which only the standard deviation sees -- and that is shift-invariant -- so mean_h is not needed
     // before the pixels are read, and one pass replaces two.
+    // u8 pixels: r, g, b and v = max(r, g, b) are byte / 255, so their sums are kept as exact integers (two integer
+    // operations per channel and pixel instead of three f64 ones) and scaled once at the end
+    constexpr bool INT4 = sizeof(T) == 1;
     double ss = 0.0, cc = 0.0;
     double s1[9], s2[9];
+    unsigned iu[4] = {0u, 0u, 0u, 0u}, iu2[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int k = 0; k < 9; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
     auto pixel = [&](int p, bool on, unsigned b0, unsigned b1, unsigned b2, float f0, float f1, float f2, double sv, double cv) {
@@ -245,8 +249,15 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
         else pixel_channels<T>(f0, f1, f2, 0u, 0u, 0u, 0.0f, s_od, x);
         ss += on ? sv : 0.0;
         cc += on ? cv : 0.0;
+        if (INT4) {
+            const unsigned m = b0 > b1 ? (b0 > b2 ? b0 : b2) : (b1 > b2 ? b1 : b2);
+            const unsigned u4[4] = {on ? b0 : 0u, on ? b1 : 0u, on ? b2 : 0u, on ? m : 0u};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { iu[c] += u4[c]; iu2[c] += u4[c] * u4[c]; }
+        }
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
+            if (INT4 && (k < 3 || k == 5)) continue;
             const double xd = on ? (double)x[k] : 0.0;
             s1[k] += xd;
             s2[k] += xd * xd;
@@ -287,34 +298,53 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
             pixel(p, on, a0, a1, a2, fa0, fa1, fa2, S[p], Cc[p]);
         }
     }
-    // twenty totals in two reduce-scatter butterflies (wave_ops.h): lane l ends up with sum x and sum x^2 of channel
-    // scatter_index<16>(l & 15) (slots 9 and 10 of the first carry the circular sums), and nine lanes finish the nine
-    // channels side by side
-    double T1[16] = {s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7], s1[8], ss, cc, 0.0, 0.0, 0.0, 0.0, 0.0};
-    double T2[16] = {s2[0], s2[1], s2[2], s2[3], s2[4], s2[5], s2[6], s2[7], s2[8], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    const double a = wave_reduce_scatter(T1, lane);
-    const double b = wave_reduce_scatter(T2, lane);
-    // scatter_index<16> reverses the four bits: slot 9 (1001b) sits in lane 9, slot 10 (1010b) in lane 5
-    ss = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 9), __builtin_amdgcn_readlane(__double2loint(a), 9));
-    cc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 5), __builtin_amdgcn_readlane(__double2loint(a), 5));
     const float area = (float)K;
-    const float rad2deg = (float)(180.0 / 3.14159265358979323846);
-    const float sinm = (float)ss / area, cosm = (float)cc / area;
-    float mh = (float)atan2((double)sinm, (double)cosm);
-    mh = mh * rad2deg;
-    mh = mh + 360.0f;
-    mh = fmodf(mh, 360.0f); // color.rs:154
-
-    const int k = scatter_index<16>(lane & 15);
-    if (lane < 16 && k < 9) {
+    float *o = out + i * (int64_t)F + col0; // column order color.rs:80-99: mean rgb, std rgb, mean hsv, std hsv, mean hed, std hed
+    // mean and population standard deviation of channel k from sum x (a) and sum x^2 (b), one lane per channel
+    auto finish = [&](int k, double a, double b, float mh) {
         const float mu = (float)a / area;
         const double mud = (double)mu;
         double D = b - 2.0 * mud * a + (double)K * mud * mud; // sum (x-mu)^2 about the f32 mean
         D = D > 0.0 ? D : (D == D ? 0.0 : D);                 // rounding can leave -1e-17; keep NaN
         const float sd = sqrtf((float)D / area);
-        float *o = out + i * (int64_t)F + col0; // column order color.rs:80-99: mean rgb, std rgb, mean hsv, std hsv, mean hed, std hed
         o[k < 3 ? k : (k < 6 ? 3 + k : 6 + k)] = k == 3 ? mh : mu; // mean_h is the circular mean
         o[k < 3 ? 3 + k : (k < 6 ? 6 + k : 9 + k)] = sd;
+    };
+    auto circular_mean = [&](double ssum, double csum) {
+        const float rad2deg = (float)(180.0 / 3.14159265358979323846);
+        const float sinm = (float)ssum / area, cosm = (float)csum / area;
+        float mh = (float)atan2((double)sinm, (double)cosm);
+        mh = mh * rad2deg;
+        mh = mh + 360.0f;
+        return fmodf(mh, 360.0f); // color.rs:154
+    };
+    // all totals in reduce-scatter butterflies (wave_ops.h); lane l ends up with the pair (sum x, sum x^2) of one channel
+    if (INT4) {
+        unsigned A4[4] = {iu[0], iu[1], iu[2], iu[3]}, B4[4] = {iu2[0], iu2[1], iu2[2], iu2[3]};
+        const unsigned ua = wave_reduce_scatter(A4, lane), ub = wave_reduce_scatter(B4, lane);
+        double T1[8] = {s1[3], s1[4], s1[6], s1[7], s1[8], ss, cc, 0.0};
+        double T2[8] = {s2[3], s2[4], s2[6], s2[7], s2[8], 0.0, 0.0, 0.0};
+        const double a = wave_reduce_scatter(T1, lane), b = wave_reduce_scatter(T2, lane);
+        // scatter_index<8> reverses three bits: slot 5 (101b) sits in lane 5, slot 6 (110b) in lane 3
+        ss = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 5), __builtin_amdgcn_readlane(__double2loint(a), 5));
+        cc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 3), __builtin_amdgcn_readlane(__double2loint(a), 3));
+        const float mh = circular_mean(ss, cc);
+        if (lane < 4) { // r, g, b, v: sums of bytes -> sums of byte / 255
+            const int c = scatter_index<4>(lane);
+            finish(c < 3 ? c : 5, (double)ua / 255.0, (double)ub / 65025.0, mh);
+        }
+        const int j = scatter_index<8>(lane & 7);
+        if (lane < 8 && j < 5) finish(j < 2 ? 3 + j : 4 + j, a, b, mh); // h, s, he, eo, da
+    } else {
+        double T1[16] = {s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7], s1[8], ss, cc, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double T2[16] = {s2[0], s2[1], s2[2], s2[3], s2[4], s2[5], s2[6], s2[7], s2[8], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        const double a = wave_reduce_scatter(T1, lane), b = wave_reduce_scatter(T2, lane);
+        // scatter_index<16> reverses the four bits: slot 9 (1001b) sits in lane 9, slot 10 (1010b) in lane 5
+        ss = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 9), __builtin_amdgcn_readlane(__double2loint(a), 9));
+        cc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 5), __builtin_amdgcn_readlane(__double2loint(a), 5));
+        const float mh = circular_mean(ss, cc);
+        const int k = scatter_index<16>(lane & 15);
+        if (lane < 16 && k < 9) finish(k, a, b, mh);
     }
 }
 
