@@ -6,8 +6,8 @@
 //                -b/--batch-size <100>  -v/--verbose
 // and its driver (main.rs:110-190): validate -> load geometry -> load image -> extract -> write by extension.
 // Differences, all stated at run time: there is no CPU compute path (without -g the engine uses GPU 0);
-// rows come out in input order (the reference's order is batch-completion order); only csv and json
-// writers exist (parquet/ipc need polars); only .png slides decode here (no JPEG / OpenSlide in this image).
+// rows come out in input order (the reference's order is batch-completion order); csv, json, parquet/pqt and
+// ipc/feather writers (columnar.hpp); only .png slides decode here (no JPEG / OpenSlide in this image).
 // The whole slide's nuclei are extracted by ONE nfx_extract_tile call per GPU -- 288 GB of HBM holds them.
 #include <algorithm>
 #include <charconv>
@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/nfx.h"
+#include "columnar.hpp"
 #include "geojson.hpp"
 #include "png.hpp"
 
@@ -84,7 +85,7 @@ Args parse_args(int argc, char **argv)
         } else if (s == "-h" || s == "--help") {
             printf("Usage: nuclei-feature-extraction [OPTIONS] <GEOMETRY> <SLIDE> <OUTPUT> [FEATURE_SETS]...\n\n"
                    "Arguments:\n  <GEOMETRY>         Input geometry file (.geojson)\n  <SLIDE>            Input slide file\n"
-                   "  <OUTPUT>           Output file (csv, json)\n  [FEATURE_SETS]...  geometry color glcm glrlm gabor texture all\n\n"
+                   "  <OUTPUT>           Output file (csv, parquet, pqt, json, ipc, feather)\n  [FEATURE_SETS]...  geometry color glcm glrlm gabor texture all\n\n"
                    "Options:\n  -o, --overwrite\n  -p, --patch-size <PATCH_SIZE>      [default: 64]\n  -t, --thread-count <THREAD_COUNT>\n"
                    "  -g, --gpus <GPUS>...\n  -b, --batch-size <BATCH_SIZE>      [default: 100]\n  -v, --verbose\n  -h, --help\n");
             exit(0);
@@ -141,10 +142,6 @@ int main(int argc, char **argv)
     if (oext.empty()) { log_error("Output file must have an extension"); return 1; }
     if (oext != "csv" && oext != "parquet" && oext != "pqt" && oext != "json" && oext != "ipc" && oext != "feather") {
         log_error("Unsupported output format. Please use one of the following : csv, parquet, json, ipc, feather");
-        return 1;
-    }
-    if (oext != "csv" && oext != "json") {
-        log_error("Output format ." + oext + " needs the polars writers of the reference (main.rs:169-180); this build writes csv and json");
         return 1;
     }
     // feature sets (args.rs:18-73)
@@ -253,6 +250,15 @@ int main(int argc, char **argv)
                 line += '\n';
                 fwrite(line.data(), 1, line.size(), fo);
             }
+        } else if (oext != "json") { // parquet | pqt | ipc | feather (main.rs:169-180)
+            std::vector<std::string> keys((size_t)n);
+            for (int64_t i = 0; i < n; ++i) {
+                nfx_centroid_key(cen[2 * (size_t)i], cen[2 * (size_t)i + 1], key, sizeof key);
+                keys[(size_t)i] = key;
+            }
+            const FeatureTable table{&header, &keys, rows.data(), n, F};
+            if (oext == "parquet" || oext == "pqt") write_parquet(fo, table);
+            else write_arrow_ipc(fo, table);
         } else { // json lines: one object per row
             for (int64_t i = 0; i < n; ++i) {
                 line.clear();
