@@ -100,6 +100,15 @@ void nfx_ctx_destroy(nfx_ctx *ctx);
 const char *nfx_last_error(const nfx_ctx *ctx);
 /* hipStream_t the NFX_MEM_DEVICE calls are enqueued on (NULL = the default stream) */
 nfx_status nfx_ctx_set_stream(nfx_ctx *ctx, void *hip_stream);
+/* How nfx_extract_tile / nfx_gather_patches place the ps x ps window around a centroid.  The reference has two loaders:
+     NFX_ADDR_IMAGE  load_image_dataset (png/jpg), utils.rs:159-191: box [trunc(c-ps/2), trunc(c+ps/2)) as i64, clipped
+                     to the image, pasted at offset (-min(top,0), -min(left,0)) of a zero patch.  Default.
+     NFX_ADDR_SLIDE  load_slide_dataset (svs through OpenSlide), utils.rs:97-122: region address `(c-ps/2) as u32`
+                     (negatives saturate to 0, so border nuclei are shifted, not padded), ps x ps from there, anything the
+                     slide does not cover stays 0 at the bottom/right.  (A failed region read drops the nucleus in the
+                     reference, utils.rs:125; a resident image cannot fail, so no nucleus is ever dropped here.) */
+typedef enum { NFX_ADDR_IMAGE = 0, NFX_ADDR_SLIDE = 1 } nfx_addressing;
+nfx_status nfx_ctx_set_patch_addressing(nfx_ctx *ctx, nfx_addressing mode);
 /* blocks until everything enqueued by this context has finished */
 nfx_status nfx_ctx_synchronize(nfx_ctx *ctx);
 

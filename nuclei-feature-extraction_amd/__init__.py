@@ -35,6 +35,7 @@ ABI_SYMBOLS = (
     "nfx_version", "nfx_feature_set_count", "nfx_feature_set_name", "nfx_feature_set_cli_name",
     "nfx_feature_set_num_columns", "nfx_feature_set_column_name", "nfx_parse_feature_sets", "nfx_centroid_key",
     "nfx_ctx_create", "nfx_ctx_destroy", "nfx_last_error", "nfx_ctx_set_stream", "nfx_ctx_synchronize",
+    "nfx_ctx_set_patch_addressing",
     "nfx_ctx_enable_timing", "nfx_ctx_kernel_timing", "nfx_ctx_reset_timing",
     "nfx_preprocess_polygons", "nfx_rasterize_polygons", "nfx_compute_features_batched",
     "nfx_extract", "nfx_extract_tile", "nfx_gather_patches",
@@ -69,6 +70,7 @@ def lib() -> C.CDLL:
     L.nfx_ctx_destroy.argtypes = [vp]
     L.nfx_ctx_destroy.restype = None
     L.nfx_ctx_set_stream.argtypes = [vp, vp]
+    L.nfx_ctx_set_patch_addressing.argtypes = [vp, C.c_int]
     L.nfx_ctx_synchronize.argtypes = [vp]
     L.nfx_ctx_enable_timing.argtypes = [vp, C.c_int]
     L.nfx_ctx_reset_timing.argtypes = [vp]
@@ -195,6 +197,12 @@ class Context:
 
     def set_stream(self, stream: int):
         self._check(lib().nfx_ctx_set_stream(self._h, C.c_void_p(stream)))
+
+    def set_patch_addressing(self, mode: str):
+        """"image": load_image_dataset's window (utils.rs:159-191, default); "slide": load_slide_dataset's (utils.rs:97-122)."""
+        if mode not in ("image", "slide"):
+            raise ValueError("patch addressing is 'image' or 'slide'")
+        self._check(lib().nfx_ctx_set_patch_addressing(self._h, 1 if mode == "slide" else 0))
 
     def synchronize(self):
         self._check(lib().nfx_ctx_synchronize(self._h))

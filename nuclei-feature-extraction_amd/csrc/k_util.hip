@@ -84,16 +84,30 @@ __global__ __launch_bounds__(256) void k_unpack_masks(int64_t nrows, const uint6
 // crop is pasted at (-min(top,0), -min(left,0)) into a zeroed [3,ps,ps] patch.
 __global__ __launch_bounds__(256) void k_gather_patches(int64_t n, const float *__restrict__ centroids,
                                                         const uint8_t *__restrict__ image, int64_t H, int64_t W, int ps,
-                                                        uint8_t *__restrict__ patches)
+                                                        int slide_addressing, uint8_t *__restrict__ patches)
 {
     const int64_t i = blockIdx.x;
     const float cx = centroids[2 * i], cy = centroids[2 * i + 1];
     const float half = (float)ps / 2.0f;
-    const int64_t top = (int64_t)(cy - half), left = (int64_t)(cx - half);
-    const int64_t bottom = (int64_t)(cy + half), right = (int64_t)(cx + half);
-    const int64_t t0 = top > 0 ? top : 0, l0 = left > 0 ? left : 0;
-    const int64_t b0 = bottom < H ? bottom : H, r0 = right < W ? right : W;
-    const int64_t oy = -(top < 0 ? top : 0), ox = -(left < 0 ? left : 0);
+    int64_t t0, l0, b0, r0, oy, ox;
+    if (slide_addressing) {
+        // load_slide_dataset, utils.rs:97-122: the region's address is `(c - ps/2) as u32` (truncates, negatives and NaN
+        // give 0, large values saturate), the region is ps x ps from there and whatever the slide cannot supply stays 0
+        auto as_u32 = [](float v) -> int64_t { return v >= 4294967296.0f ? 4294967295ll : (v > 0.0f ? (int64_t)v : 0ll); };
+        t0 = as_u32(cy - half);
+        l0 = as_u32(cx - half);
+        b0 = t0 + ps < H ? t0 + ps : H;
+        r0 = l0 + ps < W ? l0 + ps : W;
+        oy = 0;
+        ox = 0;
+    } else {
+        // load_image_dataset, utils.rs:159-191
+        const int64_t top = (int64_t)(cy - half), left = (int64_t)(cx - half);
+        const int64_t bottom = (int64_t)(cy + half), right = (int64_t)(cx + half);
+        t0 = top > 0 ? top : 0, l0 = left > 0 ? left : 0;
+        b0 = bottom < H ? bottom : H, r0 = right < W ? right : W;
+        oy = -(top < 0 ? top : 0), ox = -(left < 0 ? left : 0);
+    }
     const int P = ps * ps;
     uint8_t *dst = patches + (size_t)i * 3 * P;
     for (int k = threadIdx.x; k < 3 * P; k += blockDim.x) {
@@ -138,7 +152,8 @@ hipError_t launch_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids
 {
     if (n == 0) return hipSuccess;
     ScopedTiming t(ctx, KS_GATHER);
-    hipLaunchKernelGGL(k_gather_patches, dim3((unsigned)n), dim3(256), 0, ctx->stream, n, centroids, image, H, W, ps, patches);
+    hipLaunchKernelGGL(k_gather_patches, dim3((unsigned)n), dim3(256), 0, ctx->stream, n, centroids, image, H, W, ps,
+                       ctx->addressing == NFX_ADDR_SLIDE ? 1 : 0, patches);
     return hipGetLastError();
 }
 

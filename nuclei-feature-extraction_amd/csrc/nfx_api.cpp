@@ -263,6 +263,14 @@ nfx_status nfx_ctx_set_stream(nfx_ctx *ctx, void *hip_stream)
     return NFX_OK;
 }
 
+nfx_status nfx_ctx_set_patch_addressing(nfx_ctx *ctx, nfx_addressing mode)
+{
+    if (!ctx) return NFX_ERR_INVALID_ARGUMENT;
+    if (mode != NFX_ADDR_IMAGE && mode != NFX_ADDR_SLIDE) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "unknown patch addressing mode");
+    ctx->addressing = mode;
+    return NFX_OK;
+}
+
 nfx_status nfx_ctx_synchronize(nfx_ctx *ctx)
 {
     if (!ctx) return NFX_ERR_INVALID_ARGUMENT;

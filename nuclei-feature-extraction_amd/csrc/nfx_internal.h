@@ -37,6 +37,7 @@ struct Timing {
 struct nfx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    nfx_addressing addressing = NFX_ADDR_IMAGE;
     std::string err;
     // grow-only device workspace with a bump pointer, reset at the start of every API call
     char *ws = nullptr;

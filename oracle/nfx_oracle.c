@@ -878,6 +878,26 @@ int orc_extract(const int *sets, int nsets, int64_t n, const uint32_t *ring_offs
     return 0;
 }
 
+/* §8f-1, the slide variant, load_slide_dataset (utils.rs:97-122): region address `(c - ps/2) as u32` (Rust's float->int
+   cast truncates, sends negatives and NaN to 0 and saturates), a ps x ps region from there, zero where the slide ends. */
+static int64_t orc_as_u32(float v)
+{
+    if (!(v > 0.0f)) return 0;
+    if (v >= 4294967296.0f) return 4294967295ll;
+    return (int64_t)v;
+}
+
+void orc_crop_patch_slide(const uint8_t *image, int H, int W, float cx, float cy, int ps, uint8_t *patch)
+{
+    float half = (float)ps / 2.0f;
+    int64_t x0 = orc_as_u32(cx - half), y0 = orc_as_u32(cy - half);       /* utils.rs:104-105 */
+    memset(patch, 0, (size_t)3 * ps * ps);                                /* utils.rs:113-122: pad bottom/right */
+    for (int ch = 0; ch < 3; ++ch)
+        for (int pr = 0; pr < ps && y0 + pr < H; ++pr)
+            for (int pc = 0; pc < ps && x0 + pc < W; ++pc)
+                patch[((size_t)ch * ps + pr) * ps + pc] = image[((size_t)ch * H + (y0 + pr)) * W + (x0 + pc)];
+}
+
 /* §8f-1 patch addressing, load_image_dataset (utils.rs:141-206): crop a [3,H,W] u8 planar image at the
    truncated box around the centroid, zero-padded, into [3,ps,ps] u8. */
 void orc_crop_patch(const uint8_t *image, int H, int W, float cx, float cy, int ps, uint8_t *patch)

@@ -123,9 +123,9 @@ def gabor_bank():
     return w
 
 
-def crop_patch(image, cx, cy, ps):
+def crop_patch(image, cx, cy, ps, slide=False):
     image = np.ascontiguousarray(image, np.uint8)
     _, H, W = image.shape
     out = np.zeros((3, ps, ps), np.uint8)
-    lib().orc_crop_patch(_p(image, C.c_uint8), C.c_int(H), C.c_int(W), C.c_float(cx), C.c_float(cy), C.c_int(ps), _p(out, C.c_uint8))
+    (lib().orc_crop_patch_slide if slide else lib().orc_crop_patch)(_p(image, C.c_uint8), C.c_int(H), C.c_int(W), C.c_float(cx), C.c_float(cy), C.c_int(ps), _p(out, C.c_uint8))
     return out

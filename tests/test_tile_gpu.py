@@ -39,6 +39,31 @@ def test_gather_patches_matches_reference_addressing(synth, ctx, ps):
     assert (got == 0).any() and (got != 0).any()
 
 
+@pytest.mark.parametrize("ps", [32, 64])
+def test_slide_addressing_shifts_border_windows_instead_of_padding(synth, ctx, ps):
+    """load_slide_dataset (utils.rs:97-122): the region address is `(c - ps/2) as u32`, so a nucleus closer than ps/2 to
+    the top/left border gets the window at 0 (not a zero-padded one); bottom/right overhang stays zero."""
+    off, xy, img = _scene(synth, ps)
+    cen, _ = ctx.preprocess_polygons(off, xy)
+    cen = np.concatenate([cen, np.array([[np.nan, 5.0], [-1e9, 1e12], [3e9, 5e9]], np.float32)])   # `as u32` corner cases
+    image_mode = ctx.gather_patches(cen, img, ps)
+    ctx.set_patch_addressing("slide")
+    try:
+        got = ctx.gather_patches(cen, img, ps)
+    finally:
+        ctx.set_patch_addressing("image")
+    differs = 0
+    for i in range(len(cen)):
+        want = orc.crop_patch(img, cen[i, 0], cen[i, 1], ps, slide=True)
+        assert np.array_equal(got[i], want), f"patch {i} at {cen[i]} differs in {(got[i] != want).sum()} bytes"
+        differs += not np.array_equal(got[i], image_mode[i])
+    assert np.array_equal(got[0], np.ascontiguousarray(img[:, :ps, :ps]))       # centre (0.2, 0.4): window at the origin
+    assert not got[-1].any()                                                     # saturated address: nothing to read
+    assert 0 < differs < len(cen)                                                # only border nuclei see the difference
+    with pytest.raises(ValueError):
+        ctx.set_patch_addressing("tiled")
+
+
 def test_tile_entry_equals_packed_entry_and_oracle(nfx, synth, ctx):
     ps = 48
     off, xy, img = _scene(synth, ps, n=90)
