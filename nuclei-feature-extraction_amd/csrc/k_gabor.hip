@@ -17,9 +17,9 @@
 //     tap and output, and yields two filter responses:
 //         45 / 135 degrees, |A| = |B|:  (ra, rb) = (G cos Ax, G sin Ax), (ca, cb) = (G cos By, G sin By),
 //                                       responses accA - accB and accA + accB;
-//         0 degrees (B = 0), two frequencies f0, f1 at once: (ra, rb) = (G cos A0 x, G cos A1 x), (ca, cb) = (G, G);
-//         90 degrees (A = 0): (ra, rb) = (G, G) once, then three column passes with (ca, cb) = (G cos B0 y, G cos B1 y).
-//   10 row passes and 12 column passes serve the whole bank (25 + 24 unpaired ones before).
+//         90 degrees (A = 0): (ra, rb) = (G, G) once, then three column passes with (ca, cb) = (G cos B0 y, G cos B1 y);
+//         0 degrees (B = 0): the same group shape on the TRANSPOSED nucleus (see gabor_nucleus).
+//   8 row passes and 12 column passes serve the whole bank (25 + 24 unpaired ones at first).
 //
 // One 256-thread workgroup per nucleus (persistent): gray patch with a zero apron and the plane pair (zero aprons,
 // odd row stride) live in LDS (76 KB, two workgroups per CU).  Both passes are REGISTER-TILED and WAVE-STRIPED:
@@ -63,7 +63,7 @@ struct GaborFilter {
     int pad;
 };
 struct GaborTables {
-    int n_groups, n_filters, pad0, pad1;
+    int n_groups, n_filters, n_plain, pad1; // groups [n_plain, n_groups) run on the transposed nucleus
     GaborGroup groups[GB_MAX_GROUPS];
     GaborFilter filters[GB_MAX_FILTERS];
 };
@@ -148,27 +148,49 @@ struct GaborShared {
     const uint64_t *rows;
 };
 
+// the mask as one orientation of the nucleus sees it (kept in LDS, so that nothing of the second view occupies
+// registers while the first one runs): mask row l for lane l; bounding box; rows the row pass covers
+struct GaborView {
+    uint64_t wrow[64];
+    int rmin, rmax, cmin, cmax, rlo, nrow_rp, pad0, pad1;
+};
+
 // All groups of one nucleus with strip size TS: wave w owns column strip w of every row pass and row strip w of
 // every column pass, so each pass is exactly one round for every wave.  No lane-divergent branches: lanes outside the
 // bounding box duplicate their neighbour's work (row pass: same values to the same address) or carry an all-zero
 // mask (column pass), which keeps every FMA block in one basic block.  Everything that does not depend on the group
 // (window addresses, the strip's mask bits) is set up once; everything that does (taps, DC gains, filter slots,
 // number of passes) sits in the group's LDS image, so the loop issues no scalar loads.
+//
+// TWO VIEWS.  The 0-degree filters (B = 0) are the 90-degree ones of the TRANSPOSED nucleus, and masked mean / variance do
+// not care about a transposition.  So they run as a second 90-degree-style group (one envelope row pass, three column
+// passes for six filters -- four passes instead of the six that three row-then-envelope groups would take) on the
+// transposed view: swapped bounding box, transposed mask, and a row-pass window that walks DOWN the gray image (lanes along
+// its columns: still conflict-free; the rows above and below the patch are the zero apron a transposed image would have).
 template <int TS>
-static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const GaborTables *__restrict__ tab, int n_groups, int ps,
-                                                     int gw, int rlo, int nrow_rp, int rmin, int rmax, int cmin, int cmax,
-                                                     float mu_gray, uint64_t wrow, int t, float (*s_wt)[GB_WBUF], int &buf,
+static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const GaborTables *__restrict__ tab, int n_groups, int n_plain, int ps,
+                                                     const GaborView *s_view,
+                                                     float mu_gray, int t, float (*s_wt)[GB_WBUF], int &buf,
                                                      double (*s_part)[GB_MAX_FILTERS][2], int dbg)
 {
     constexpr int WIN = TS + GB_SIZE - 1;
     const int lane = t & 63, wv = t >> 6;
-    // row pass geometry: lanes run along rows (LDS stride gw, odd), the wave's strip along columns
+#pragma unroll 1
+  for (int view = 0; view < 2; ++view) {
+    const bool tr = view == 1; // wave-uniform
+    const int g_begin = tr ? n_plain : 0, g_end = tr ? n_groups : n_plain;
+    if (g_begin >= g_end) continue;
+    const GaborView &V = s_view[view];
+    const int rmin = __builtin_amdgcn_readfirstlane(V.rmin), rmax = __builtin_amdgcn_readfirstlane(V.rmax);
+    const int cmin = __builtin_amdgcn_readfirstlane(V.cmin), cmax = __builtin_amdgcn_readfirstlane(V.cmax);
+    const int rlo = __builtin_amdgcn_readfirstlane(V.rlo), nrow_rp = __builtin_amdgcn_readfirstlane(V.nrow_rp);
+    // row pass geometry: lanes run along rows (LDS stride GB_GW, odd), the wave's strip along columns
     const int c0 = cmin + wv * TS;
     const bool rstrip = c0 <= cmax && !(dbg & 1); // wave-uniform
     const int rr = rlo + (lane < nrow_rp ? lane : nrow_rp - 1);
     int c0c = c0 < ps - TS ? c0 : ps - TS; // keep the window inside the apron row
     c0c = c0c > 0 ? c0c : 0;
-    const float *src = &S.g[rr * gw + c0c]; // gray column c-15 sits at apron index c
+    const float *src = tr ? &S.g[rr + GB_PAD] : &S.g[rr * GB_GW + c0c]; // gray column c-15 sits at apron index c; transposed: column rr
     f2 *du = &S.UW[(rr + GB_PAD) * GB_UW + c0c];
     // column pass geometry: lanes run along columns, the wave's strip along rows
     const int r0 = rmin + wv * TS;
@@ -177,19 +199,17 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
     int r0c = r0 < ps - TS ? r0 : ps - TS; // clamped strips overlap: rows below r0 are masked out
     r0c = r0c > 0 ? r0c : 0;
     const f2 *su = &S.UW[r0c * GB_UW + c]; // row (r0c - 15) + 15
-    unsigned mbits = 0; // bit q: pixel (r0c + q, c) is in the mask and belongs to this strip
+    // bit q: pixel (r0c + q, c) is in the mask and belongs to this strip.  Column c of this view's mask is row c of
+    // the other view's: one LDS word instead of TS lane reads
+    unsigned mbits;
     {
-        const unsigned wlo = (unsigned)wrow, whi = (unsigned)(wrow >> 32); // lane l holds mask row l
-#pragma unroll
-        for (int q = 0; q < TS; ++q) {
-            const int R = (r0c + q) & 63;
-            const uint64_t row = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)whi, R) << 32) | (unsigned)__builtin_amdgcn_readlane((int)wlo, R);
-            if (r0c + q >= r0) mbits |= (unsigned)((row >> c) & 1ull) << q;
-        }
+        const uint64_t column = s_view[view ^ 1].wrow[c];
+        const int skip = r0 - r0c < 31 ? r0 - r0c : 31; // clamped strips overlap: rows below r0 belong to the strip before
+        mbits = (unsigned)(column >> r0c) & ((1u << TS) - 1u) & ~((1u << skip) - 1u);
         if (cmin + lane > cmax) mbits = 0u;
     }
 
-    for (int g = 0; g < ((dbg & 4) ? 0 : n_groups); ++g) {
+    for (int g = g_begin; g < ((dbg & 4) ? 0 : g_end); ++g) {
         __syncthreads(); // taps (and, for g = 0, gray) visible; every wave has left the previous group's column passes
         const float *wt = s_wt[buf];
         // the taps are the same for every nucleus: group g+1's image is fetched into registers while group g runs and
@@ -201,8 +221,18 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
         if (rstrip) {
             float x[WIN];
             f2 acc[TS];
+            if (tr) { // window element j is gray row c0c + j - 15 (wave-uniform): outside the patch it is the apron's zero
+                // (the first row is made opaque here so that the 40-odd range tests are evaluated on the spot: hoisted out
+                // of the group loop they would sit in registers the FMA blocks need)
+                int row0 = __builtin_amdgcn_readfirstlane(c0c - GB_PAD);
+                asm volatile("" : "+s"(row0));
+                const float *col = src + row0 * GB_GW;
 #pragma unroll
-            for (int j = 0; j < WIN; ++j) x[j] = src[j];
+                for (int j = 0; j < WIN; ++j) x[j] = (unsigned)(row0 + j) < (unsigned)ps ? col[j * GB_GW] : 0.0f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < WIN; ++j) x[j] = src[j];
+            }
             taps2<TS, float>(x, wt, (f2){0.0f, 0.0f}, acc);
             // unconditional stores (c0c <= ps - TS keeps them inside the row; for ps < TS they land in the row's unused tail)
 #pragma unroll
@@ -259,6 +289,7 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
         buf ^= 1; // the other buffer was last read by group g-1, which every wave left before this iteration's first barrier
         if (t < GB_WBUF / 4) reinterpret_cast<float4 *>(s_wt[buf])[t] = wnext;
     }
+  }
 }
 
 template <typename T>
@@ -273,14 +304,14 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
     __shared__ uint64_t s_rows[64 + 16];
     __shared__ double s_part[4][GB_MAX_FILTERS][2];
     __shared__ float s_gsum[4];
+    __shared__ GaborView s_view[2];
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int P = ps * ps;
-    const int gw = ps + GB_SIZE - 1;
     for (int k = t; k < NFX_MAX_PATCH_SIZE * GB_GW + 16; k += GB_THREADS) s_g[k] = 0.0f; // apron stays zero
     for (int k = t; k < GB_UH * GB_UW; k += GB_THREADS) s_UW[k] = (f2){0.0f, 0.0f};
     if (t < 64 + 16) s_rows[t] = 0ull;
-    const int n_groups = tab->n_groups, n_filters = tab->n_filters;
+    const int n_groups = tab->n_groups, n_filters = tab->n_filters, n_plain = tab->n_plain;
     int buf = 0;
     if (t < GB_WBUF / 4) reinterpret_cast<float4 *>(s_wt[0])[t] = reinterpret_cast<const float4 *>(tab->groups[0].image)[t];
     __syncthreads();
@@ -301,7 +332,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
                 const unsigned rr[4] = {r4.x, r4.y, r4.z, r4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
                 const int p0 = 16 * k, r = p0 / ps, c0 = p0 - r * ps;
                 const unsigned mrow = (unsigned)(s_rows[r] >> c0) & 0xFFFFu;
-                float *dst = &s_g[r * gw + c0 + GB_PAD];
+                float *dst = &s_g[r * GB_GW + c0 + GB_PAD];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int sh = 8 * (q & 3);
@@ -319,7 +350,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
                 float gs = BPx<T>::ld(pp, p) + BPx<T>::ld(pp, P + p);
                 gs = gs + BPx<T>::ld(pp, 2 * P + p);
                 gs = sizeof(T) == 1 ? third_of_u8_sum(gs) : gs / 3.0f; // texture.rs:332
-                s_g[r * gw + c + GB_PAD] = gs;
+                s_g[r * GB_GW + c + GB_PAD] = gs;
                 if ((s_rows[r] >> c) & 1ull) gsum += gs;
                 c += dc; r += dr;
                 if (c >= ps) { c -= ps; r += 1; }
@@ -343,14 +374,36 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
         }
         const int cmin = __ffsll((long long)orr) - 1, cmax = 63 - __clzll((long long)orr);
         const int ncol = cmax - cmin + 1, nrow = rmax - rmin + 1;
-        const int rlo = rmin - GB_PAD > 0 ? rmin - GB_PAD : 0;
-        const int rhi = rmax + (GB_SIZE - 1 - GB_PAD) < ps - 1 ? rmax + (GB_SIZE - 1 - GB_PAD) : ps - 1;
-        const int nrow_rp = rhi - rlo + 1;
-        const int span = ncol > nrow ? ncol : nrow;   // both passes use the same strip size
+        const int span = ncol > nrow ? ncol : nrow;   // both passes and both views use the same strip size
+        auto put_view = [&](GaborView &V, bool with_rows, uint64_t rows_of_lane, int r_lo, int r_hi, int c_lo, int c_hi) {
+            if (with_rows) V.wrow[lane] = rows_of_lane;
+            if (lane == 0) {
+                V.rmin = r_lo; V.rmax = r_hi; V.cmin = c_lo; V.cmax = c_hi;
+                V.rlo = r_lo - GB_PAD > 0 ? r_lo - GB_PAD : 0;
+                const int rhi = r_hi + (GB_SIZE - 1 - GB_PAD) < ps - 1 ? r_hi + (GB_SIZE - 1 - GB_PAD) : ps - 1;
+                V.nrow_rp = rhi - V.rlo + 1;
+            }
+        };
+        // transposed mask: lane c collects column c, one bit per mask row (three instructions a row); wave w does rows
+        // 16w .. 16w+15 and puts its 16 bits down as one quarter of the lane's word
+        {
+            unsigned acc = 0u;
+            const unsigned wlo = (unsigned)wrow, whi = (unsigned)(wrow >> 32);
+            const int Ra = rmin > 16 * wv ? rmin : 16 * wv, Rb = rmax < 16 * wv + 15 ? rmax : 16 * wv + 15;
+            for (int R = Ra; R <= Rb; ++R) {
+                const unsigned rl = (unsigned)__builtin_amdgcn_readlane((int)wlo, R), rh = (unsigned)__builtin_amdgcn_readlane((int)whi, R);
+                acc |= (((lane < 32 ? rl : rh) >> (lane & 31)) & 1u) << (R & 15);
+            }
+            reinterpret_cast<unsigned short *>(s_view[1].wrow)[4 * lane + wv] = (unsigned short)acc;
+        }
+        if (wv == 0) { // visible to the other waves after the barrier below
+            put_view(s_view[0], true, wrow, rmin, rmax, cmin, cmax);
+            put_view(s_view[1], false, 0ull, cmin, cmax, rmin, rmax);
+        }
         if (lane == 0) s_gsum[wv] = gsum;
         __syncthreads();
         const float mu_gray = (s_gsum[0] + s_gsum[1] + s_gsum[2] + s_gsum[3]) / (float)area;
-#define NFX_GB_CALL(TS) gabor_nucleus<TS>(S, tab, n_groups, ps, gw, rlo, nrow_rp, rmin, rmax, cmin, cmax, mu_gray, wrow, t, s_wt, buf, s_part, dbg)
+#define NFX_GB_CALL(TS) gabor_nucleus<TS>(S, tab, n_groups, n_plain, ps, s_view, mu_gray, t, s_wt, buf, s_part, dbg)
         // four strips of the smallest even size that covers the bounding box: every wave has work in every pass
         if (span <= 24) NFX_GB_CALL(6);
         else if (span <= 32) NFX_GB_CALL(8);
@@ -445,36 +498,22 @@ static void build_tables(GaborTables &T)
         u.placed = true;
         if (mir) mir->placed = true;
     }
-    // (2) B = 0: the column kernel is the bare envelope; two frequencies ride in one plane pair
-    for (size_t i = 0; i < uniq.size() && ok; ++i) {
-        Uniq &u = uniq[i];
-        if (u.placed || u.B != 0.0) continue;
-        Uniq *v = nullptr;
-        for (size_t k = i + 1; k < uniq.size(); ++k)
-            if (!uniq[k].placed && uniq[k].B == 0.0) { v = &uniq[k]; break; }
-        GaborGroup *G = new_group();
-        if (!G) { ok = false; break; }
-        for (int j = 0; j < GB_SIZE; ++j) {
-            set_row(*G, j, env(tk(j)) * cos(u.A * tk(j)), v ? env(tk(j)) * cos(v->A * tk(j)) : 0.0);
-            set_col(*G, 0, j, env(tk(j)), env(tk(j)));
-        }
-        G->n_pass = 1;
-        G->filt[0][0] = u.slot; G->filt[0][1] = v ? v->slot : -1;
-        u.placed = true;
-        if (v) v->placed = true;
-    }
-    // (3) A = 0: one row pass with the bare envelope (in both halves), two frequencies per column pass
-    {
+    // (2) A = 0 (90 degrees), then B = 0 (0 degrees) on the transposed nucleus, where x and y swap roles: one row pass with
+    // the bare envelope (in both halves), two frequencies per column pass
+    for (int view = 0; view < 2 && ok; ++view) {
+        if (view == 1) T.n_plain = ng;
         std::vector<Uniq *> col;
         for (auto &u : uniq)
-            if (!u.placed && u.A == 0.0) col.push_back(&u);
+            if (!u.placed && (view == 0 ? u.A == 0.0 : u.B == 0.0)) col.push_back(&u);
+        auto wave_number = [&](const Uniq *u) { return view == 0 ? u->B : u->A; };
         for (size_t i = 0; i < col.size() && ok; i += 2 * GB_MAX_PASSES) {
             GaborGroup *G = new_group();
             if (!G) { ok = false; break; }
             for (int j = 0; j < GB_SIZE; ++j) set_row(*G, j, env(tk(j)), env(tk(j)));
             for (int p = 0; p < GB_MAX_PASSES && i + 2 * p < col.size(); ++p) {
                 Uniq *u = col[i + 2 * p], *v = i + 2 * p + 1 < col.size() ? col[i + 2 * p + 1] : nullptr;
-                for (int j = 0; j < GB_SIZE; ++j) set_col(*G, p, j, env(tk(j)) * cos(u->B * tk(j)), v ? env(tk(j)) * cos(v->B * tk(j)) : 0.0);
+                for (int j = 0; j < GB_SIZE; ++j)
+                    set_col(*G, p, j, env(tk(j)) * cos(wave_number(u) * tk(j)), v ? env(tk(j)) * cos(wave_number(v) * tk(j)) : 0.0);
                 G->filt[p][0] = u->slot; G->filt[p][1] = v ? v->slot : -1;
                 u->placed = true;
                 if (v) v->placed = true;
