@@ -607,12 +607,16 @@ __global__ __launch_bounds__(256) void k_glcm_finish(int64_t n, const double *__
     const double eij = (S2 - D2) / (4.0 * N);
     const double con = D2 / N, dis = D1 / N, sa = S1 / N;
     const double sv = S2 / N - sa * sa;
+    // All pairs in one (diagonal) cell -- a flat nucleus -- is known exactly: sum G^2 == (sum G)^2 in integers.  The three
+    // entropies are then exactly 0, as a sum over cells finds them; the closed forms below would leave ln T - (T ln T)/T,
+    // a rounding residue, and information_measure_correlation1 = 0/0 must come out NaN, not residue/residue.
+    const bool one_cell = ASMN == T2 * T2;
     const double lnT = log(T2);
-    const double se = log(N) - HSS / N;
-    const double ent = lnT - ENTS / T2;
+    const double se = one_cell ? 0.0 : log(N) - HSS / N;
+    const double ent = one_cell ? 0.0 : lnT - ENTS / T2;
     const double asm_ = ASMN / (T2 * T2);
     const double dv = D2 / N - dis * dis;
-    const double hx = lnT - HXS / T2;
+    const double hx = one_cell ? 0.0 : lnT - HXS / T2;
     const double hxy1 = 2.0 * hx; // = HXY2 for a symmetric matrix (marginalisation)
     double a2 = 1.0 - exp(-2.0 * (hxy1 - ent));
     a2 = a2 > 0.0 ? a2 : 0.0;

@@ -1,0 +1,81 @@
+"""Parity on textures chosen to hit the limits of the counting structures rather than typical H&E statistics:
+
+  constant patches      every co-occurring pair falls into ONE diagonal GLCM cell (rank up to ps(ps-1)-1, the end of the
+                        rank tables), one GLRLM run per row clipped at the maximum run length, zero Gabor variance,
+                        zero saturation (hue is defined as 0), log(0) in the stain separation for black
+  white noise           as many distinct GLCM cells as pairs (hash tables at their design load), runs of length 1
+  0/255 checkerboards   two cells only, maximal contrast, alternating runs
+  one-level ramps       neighbouring levels differ by exactly one quantisation step along x
+each under a full-patch mask (the largest size class), a typical nucleus and a one-pixel mask.
+"""
+import numpy as np
+import pytest
+
+import _oracle as orc
+import _parity as par
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(nfx):
+    c = nfx.Context(0)
+    yield c
+    c.close()
+
+
+def textures(ps, rng):
+    yy, xx = np.mgrid[0:ps, 0:ps]
+    out = {}
+    for v in (0, 1, 127, 254, 255):
+        out[f"constant {v}"] = np.full((3, ps, ps), v, np.uint8)
+    out["noise"] = rng.integers(0, 256, (3, ps, ps), dtype=np.uint8)
+    out["gray noise"] = np.repeat(rng.integers(0, 256, (1, ps, ps), dtype=np.uint8), 3, 0)
+    out["checkerboard"] = np.repeat((((yy + xx) & 1) * 255).astype(np.uint8)[None], 3, 0)
+    out["stripes"] = np.repeat(((yy & 1) * 255).astype(np.uint8)[None], 3, 0)
+    out["ramp x"] = np.repeat((xx * 255 // (ps - 1)).astype(np.uint8)[None], 3, 0)
+    out["ramp y, one channel"] = np.stack([(yy * 255 // (ps - 1)).astype(np.uint8), np.zeros((ps, ps), np.uint8), np.full((ps, ps), 255, np.uint8)])
+    out["two levels"] = np.repeat(np.where(xx < ps // 2, 100, 101).astype(np.uint8)[None], 3, 0)
+    return out
+
+
+def rings(ps):
+    c = 700.0
+    t = np.linspace(0, 2 * np.pi, 33)
+    return [
+        np.array([[c - 2 * ps, c - 2 * ps], [c + 2 * ps, c - 2 * ps], [c + 2 * ps, c + 2 * ps], [c - 2 * ps, c + 2 * ps], [c - 2 * ps, c - 2 * ps]], np.float32),  # full mask
+        np.stack([c + 0.3 * ps * np.cos(t), c + 0.22 * ps * np.sin(t)], 1).astype(np.float32),                                                               # typical
+        np.array([[c - 0.5, c - 0.5], [c + 0.5, c - 0.5], [c + 0.5, c + 0.5], [c - 0.5, c + 0.5], [c - 0.5, c - 0.5]], np.float32),                          # one pixel
+    ]
+
+
+@pytest.mark.parametrize("ps", [32, 48, 64])
+def test_extreme_textures_match_the_oracle(nfx, ctx, ps):
+    rng = np.random.default_rng(ps)
+    tex = textures(ps, rng)
+    rs = rings(ps)
+    names, ring_list, patches = [], [], []
+    for nm, p in tex.items():
+        for k, r in enumerate(rs):
+            names.append(f"{nm} / ring {k}")
+            ring_list.append(r)
+            patches.append(p)
+    off = np.zeros(len(ring_list) + 1, np.uint32)
+    np.cumsum([len(r) for r in ring_list], out=off[1:])
+    xy = np.concatenate(ring_list).astype(np.float32)
+    pu8 = np.stack(patches)
+    sets = [0, 1, 2, 3, 4]
+    batch = 7  # ragged batches mix textures inside the batch-coupled hue mean
+    want, wcen = orc.extract(sets, off, xy, pu8, ps, batch_size=batch)
+    got, gcen = ctx.extract(sets, off, xy, pu8, ps, batch_size=batch)
+    assert np.array_equal(gcen, wcen, equal_nan=True)
+    scales = par.column_scales(nfx, sets, ps)
+    for i, nm in enumerate(names):  # report by texture
+        par.assert_rows_close(got[i:i + 1], want[i:i + 1], scales, what=f"ps={ps} {nm}")
+    # the counting features of a constant patch under the full mask are known in closed form: one cell, p = 1
+    cols = nfx.all_column_names(sets)[1:]
+    i = names.index("constant 127 / ring 0")
+    for L in (32, 64, 128, 254):
+        assert got[i, cols.index(f"angular_second_moment_0_1_{L}")] == 1.0
+        assert got[i, cols.index(f"entropy_0_1_{L}")] == 0.0
+        assert got[i, cols.index(f"contrast_0_1_{L}")] == 0.0
