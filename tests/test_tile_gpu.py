@@ -28,7 +28,7 @@ def _scene(synth, ps, n=120, H=300, W=340, seed=17):
     return off, xy, img
 
 
-@pytest.mark.parametrize("ps", [32, 48, 64])
+@pytest.mark.parametrize("ps", [32, 33, 47, 48, 64])
 def test_gather_patches_matches_reference_addressing(synth, ctx, ps):
     off, xy, img = _scene(synth, ps)
     cen, _ = ctx.preprocess_polygons(off, xy)
