@@ -258,17 +258,22 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
                 t = b2 & c; b2 ^= c; c = t;
                 b3 ^= c;
             }
-            // one bin update per run
+            // one bin update per run; the row's starts are walked as two 32-bit words (single-instruction find-first-set
+            // and bit-field extracts instead of their 64-bit sequences)
             {
-                uint64_t rem = S;
                 const int rbase = lane * QS;
-                while (rem) {
-                    const int pos = __ffsll((long long)rem) - 1;
-                    rem &= rem - 1ull;
-                    const unsigned len1 = (unsigned)((b0 >> pos) & 1ull) | ((unsigned)((b1 >> pos) & 1ull) << 1) |
-                                          ((unsigned)((b2 >> pos) & 1ull) << 2) | ((unsigned)((b3 >> pos) & 1ull) << 3);
-                    const unsigned q = s_q[rbase + pos];
-                    atomicAdd(&s_R[q * RL_MAXLEN + len1], 1u);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int sh = 32 * half;
+                    unsigned rem = (unsigned)(S >> sh);
+                    const unsigned h0 = (unsigned)(b0 >> sh), h1 = (unsigned)(b1 >> sh), h2 = (unsigned)(b2 >> sh), h3 = (unsigned)(b3 >> sh);
+                    while (rem) {
+                        const int pos = __ffs((int)rem) - 1;
+                        rem &= rem - 1u;
+                        const unsigned len1 = ((h0 >> pos) & 1u) | (((h1 >> pos) & 1u) << 1) | (((h2 >> pos) & 1u) << 2) | (((h3 >> pos) & 1u) << 3);
+                        const unsigned q = s_q[rbase + sh + pos];
+                        atomicAdd(&s_R[q * RL_MAXLEN + len1], 1u);
+                    }
                 }
             }
             wave_lds_fence();
