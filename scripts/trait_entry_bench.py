@@ -1,0 +1,35 @@
+"""Throughput of the strict drop-in entry (`nfx_compute_features_batched`: one feature set, one reference batch of f32
+patchs + f32 masks per call -- what the reference's `extract_features` closure would call, main.rs:52-73), with host
+tensors (the reference's CPU loader) and with device tensors.  usage: python scripts/trait_entry_bench.py [ps] [batch] [calls]"""
+import importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+torch.cuda.init()
+nfx = importlib.import_module("nuclei-feature-extraction_amd")
+synth = importlib.import_module("nuclei-feature-extraction_amd.synth")
+ps = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+calls = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+ctx = nfx.Context(0)
+seed = synth.SEED_BASE + 31
+off, xy = synth.polygons(seed, 0, B, ps)
+pu8 = synth.patches(seed, 0, B, ps)
+cen, ctr = ctx.preprocess_polygons(off, xy)
+masks = ctx.rasterize_polygons(off, ctr, ps)
+patchs = pu8.astype(np.float32) / np.float32(255.0)
+d = torch.device("cuda", 0)
+t_off, t_ctr, t_p, t_m = (torch.from_numpy(np.ascontiguousarray(a)).to(d) for a in (off.astype(np.int32), ctr, patchs, masks))
+ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+for s in range(5):
+    name = nfx.feature_set_cli_name(s)
+    for label, args in (("host", (off, ctr, patchs, masks)), ("device", (t_off, t_ctr, t_p, t_m))):
+        for _ in range(5):
+            ctx.compute_features_batched(s, *args)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            ctx.compute_features_batched(s, *args)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / calls
+        print(f"{name:9s} {label:6s} ps={ps} batch={B}: {dt * 1e6:8.1f} us per call, {B / dt / 1e3:8.1f} k nuclei/s", flush=True)
