@@ -98,7 +98,10 @@ int nfx_centroid_key(float x, float y, char *buf, size_t buflen);
 nfx_status nfx_ctx_create(int device, nfx_ctx **out);
 void nfx_ctx_destroy(nfx_ctx *ctx);
 const char *nfx_last_error(const nfx_ctx *ctx);
-/* hipStream_t the NFX_MEM_DEVICE calls are enqueued on (NULL = the default stream) */
+/* hipStream_t the NFX_MEM_DEVICE calls are enqueued on (NULL = the default stream).  NFX_MEM_HOST calls are synchronous
+   and run on a private non-blocking stream of the context, so contexts driven from different host threads (the reference's
+   rayon workers, main.rs:146-151) overlap on the GPU; such a call first waits for the device calls still in flight on
+   this context, whose workspace it shares. */
 nfx_status nfx_ctx_set_stream(nfx_ctx *ctx, void *hip_stream);
 /* How nfx_extract_tile / nfx_gather_patches place the ps x ps window around a centroid.  The reference has two loaders:
      NFX_ADDR_IMAGE  load_image_dataset (png/jpg), utils.rs:159-191: box [trunc(c-ps/2), trunc(c+ps/2)) as i64, clipped

@@ -236,6 +236,7 @@ nfx_status nfx_ctx_create(int device, nfx_ctx **out)
     if (hipSetDevice(device) != hipSuccess) return NFX_ERR_DEVICE;
     nfx_ctx *c = new nfx_ctx();
     c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return NFX_ERR_DEVICE; }
     *out = c;
     return NFX_OK;
 }
@@ -245,6 +246,7 @@ void nfx_ctx_destroy(nfx_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
     for (auto &t : ctx->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->ws) (void)hipFree(ctx->ws);
@@ -321,6 +323,21 @@ static nfx_status check_common(nfx_ctx *ctx, int64_t n, int64_t nv, int ps)
     if (nv > 0xFFFFFFFFll) return fail(ctx, NFX_ERR_UNSUPPORTED, "more than 2^32-1 vertices in one call");
     return NFX_OK;
 }
+
+// A synchronous (host-memory) call runs on the context's own stream.  It first waits for whatever the caller still has in
+// flight on the device-call stream: both kinds of call share the context's workspace.
+struct StreamScope {
+    nfx_ctx *ctx;
+    hipStream_t saved;
+    StreamScope(nfx_ctx *c, nfx_mem mem) : ctx(c), saved(c->stream)
+    {
+        if (mem == NFX_MEM_HOST && c->own_stream) {
+            (void)hipStreamSynchronize(saved);
+            c->stream = c->own_stream;
+        }
+    }
+    ~StreamScope() { ctx->stream = saved; }
+};
 
 static int sets_total_columns(const int *sets, int n_sets)
 {
@@ -456,6 +473,7 @@ nfx_status nfx_preprocess_polygons(nfx_ctx *ctx, int64_t n, int64_t nv, const ui
     if (st != NFX_OK) return st;
     if (!ring_offsets || (nv && !ring_xy)) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null input");
     NFX_HIP(ctx, hipSetDevice(ctx->device));
+    StreamScope stream_scope(ctx, mem);
     if (mem == NFX_MEM_DEVICE) {
         NFX_HIP(ctx, launch_preprocess(ctx, n, ring_offsets, ring_xy, centroids_xy, centred_xy));
         return NFX_OK;
@@ -481,6 +499,7 @@ nfx_status nfx_rasterize_polygons(nfx_ctx *ctx, int64_t n, int64_t nv, const uin
     if (st != NFX_OK) return st;
     if (!poly_offsets || (nv && !poly_xy)) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null input");
     NFX_HIP(ctx, hipSetDevice(ctx->device));
+    StreamScope stream_scope(ctx, mem);
     const size_t rows_b = sizeof(uint64_t) * (size_t)n * ps, mask_b = sizeof(float) * (size_t)n * ps * ps;
     if (mem == NFX_MEM_DEVICE) {
         uint64_t *rows = mask_rows;
@@ -521,6 +540,7 @@ nfx_status nfx_compute_features_batched(nfx_ctx *ctx, int set, int64_t n, int64_
         return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null input");
     if (n > 0x7FFFFFFF) return fail(ctx, NFX_ERR_UNSUPPORTED, "batch too large");
     NFX_HIP(ctx, hipSetDevice(ctx->device));
+    StreamScope stream_scope(ctx, mem);
     const int F = kNumCols[set];
     const size_t P = (size_t)ps * ps;
     Job job;
@@ -593,6 +613,7 @@ static nfx_status extract_common(nfx_ctx *ctx, const int *sets, int n_sets, int6
         return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null input");
     if (image && (H < 1 || W < 1)) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "empty image");
     NFX_HIP(ctx, hipSetDevice(ctx->device));
+    StreamScope stream_scope(ctx, mem);
     const size_t P = (size_t)ps * ps;
     size_t need = extract_ws_bytes(sets, n_sets, n, nv, ps, batch_size, image && !out_centroids, image && pix);
     if (mem == NFX_MEM_HOST) {
@@ -644,6 +665,7 @@ nfx_status nfx_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids_xy
     if (st != NFX_OK) return st;
     if (!centroids_xy || !image_u8 || !patches_u8 || H < 1 || W < 1) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null input");
     NFX_HIP(ctx, hipSetDevice(ctx->device));
+    StreamScope stream_scope(ctx, mem);
     if (mem == NFX_MEM_DEVICE) {
         NFX_HIP(ctx, launch_gather_patches(ctx, n, centroids_xy, image_u8, H, W, ps, patches_u8));
         return NFX_OK;

@@ -36,7 +36,9 @@ struct Timing {
 
 struct nfx_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // where NFX_MEM_DEVICE calls are enqueued (nfx_ctx_set_stream; NULL = the default stream)
+    hipStream_t own_stream = nullptr; // non-blocking stream of the synchronous NFX_MEM_HOST calls: contexts driven from
+                                      // different host threads overlap on the GPU instead of queueing on the default stream
     nfx_addressing addressing = NFX_ADDR_IMAGE;
     std::string err;
     // grow-only device workspace with a bump pointer, reset at the start of every API call

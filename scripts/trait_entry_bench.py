@@ -33,3 +33,23 @@ for s in range(5):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / calls
         print(f"{name:9s} {label:6s} ps={ps} batch={B}: {dt * 1e6:8.1f} us per call, {B / dt / 1e3:8.1f} k nuclei/s", flush=True)
+
+# ---- the reference's calling pattern: several worker threads, one context each, host tensors ----------------------
+import threading
+for s in (2, 4):
+    name = nfx.feature_set_cli_name(s)
+    for T in (1, 2, 4, 8, 16):
+        ctxs = [nfx.Context(0) for _ in range(T)]
+        for c in ctxs:
+            c.compute_features_batched(s, off, ctr, patchs, masks)
+        per = max(20, calls // 2)
+        def work(c):
+            for _ in range(per):
+                c.compute_features_batched(s, off, ctr, patchs, masks)
+        th = [threading.Thread(target=work, args=(c,)) for c in ctxs]
+        t0 = time.perf_counter()
+        for t in th: t.start()
+        for t in th: t.join()
+        dt = time.perf_counter() - t0
+        print(f"{name:9s} host, {T:2d} threads x {per} calls: {T * per * B / dt / 1e3:8.1f} k nuclei/s aggregate", flush=True)
+        for c in ctxs: c.close()
