@@ -399,12 +399,62 @@ static __device__ __forceinline__ void polygon_one(VP v, int V, IDX *srt, IDX *h
     const double eq_perim = 2.0 * sqrt(PI * area);
     const double compacity = 4.0 * PI * area / (perim * perim);
 
-    // insertion sort of the indices (lexicographic x then y; ties keep ring order, as a stable sort of the points would)
-    for (int k = 0; k < V; ++k) {
-        const pt key = P(k);
-        int j = k - 1;
-        while (j >= 0 && pt_less(key, P(srt[j]))) { srt[j + 1] = srt[j]; --j; }
-        srt[j + 1] = (IDX)k;
+    // NATURAL MERGE SORT of the indices (lexicographic x then y; ties keep ring order, as a stable sort of the points would).
+    // A ring listed around its centre is two or three monotone runs in x, so the whole sort is one or two linear merges
+    // (~2V dependent steps; the insertion sort it replaces paid one per inversion, ~V^2/4).
+    // Phase 1 cuts the ring into maximal runs -- non-descending ones as they are, STRICTLY descending ones reversed, which
+    // cannot reorder equal points -- and notes their ends; phase 2 merges neighbouring runs, left run first on ties, between
+    // the index array and the (still unused) hull array until one run is left.
+    {
+        auto F2 = [&](int k) { return v[k]; };
+        auto less = [](const float2 &a, const float2 &b) { return (a.x < b.x) || (a.x == b.x && a.y < b.y); }; // f32: widening is exact
+        IDX *src = srt, *dst = hull, *ends = hull + V; // run r ends (exclusive) at ends[r]
+        int nr = 0;
+        for (int k = 0; k < V;) {
+            int e = k + 1;
+            float2 prev = F2(k);
+            if (e < V && less(F2(e), prev)) {
+                for (; e < V; ++e) { const float2 c = F2(e); if (!less(c, prev)) break; prev = c; }
+                for (int t = 0; t < e - k; ++t) src[k + t] = (IDX)(e - 1 - t);
+            } else {
+                for (; e < V; ++e) { const float2 c = F2(e); if (less(c, prev)) break; prev = c; }
+                for (int t = k; t < e; ++t) src[t] = (IDX)t;
+            }
+            ends[nr++] = (IDX)e;
+            k = e;
+        }
+        while (nr > 1) {
+            int lo = 0, nout = 0;
+            for (int r = 0; r < nr; r += 2) {
+                const int mid = (int)ends[r], hi = r + 1 < nr ? (int)ends[r + 1] : mid;
+                int i = lo, j = mid, o = lo;
+                if (i < mid && j < hi) {
+                    IDX ia = src[i], ib = src[j];
+                    float2 pa = F2((int)ia), pb = F2((int)ib);
+                    for (;;) {
+                        if (less(pb, pa)) {
+                            dst[o++] = ib;
+                            if (++j == hi) break;
+                            ib = src[j]; pb = F2((int)ib);
+                        } else {
+                            dst[o++] = ia;
+                            if (++i == mid) break;
+                            ia = src[i]; pa = F2((int)ia);
+                        }
+                    }
+                }
+                for (; i < mid; ++i) dst[o++] = src[i];
+                for (; j < hi; ++j) dst[o++] = src[j];
+                // the merged run's end goes to the front of the list: slot nout <= r has been consumed already.  When the
+                // destination is the hull array the ends live right behind its first V slots, which stay untouched
+                ends[nout++] = (IDX)hi;
+                lo = hi;
+            }
+            nr = nout;
+            IDX *t = src; src = dst; dst = t;
+        }
+        if (src != srt)
+            for (int k = 0; k < V; ++k) srt[k] = src[k];
     }
     int m = 0;
     for (int k = 0; k < V; ++k) {
