@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "exact_div.h"
@@ -192,11 +193,17 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
     c0c = c0c > 0 ? c0c : 0;
     const float *src = tr ? &S.g[rr + GB_PAD] : &S.g[rr * GB_GW + c0c]; // gray column c-15 sits at apron index c; transposed: column rr
     f2 *du = &S.UW[(rr + GB_PAD) * GB_UW + c0c];
-    // column pass geometry: lanes run along columns, the wave's strip along rows
-    const int r0 = rmin + wv * TS;
-    const bool cstrip = r0 <= rmax && !(dbg & 2); // wave-uniform
-    const int c = cmin + lane <= cmax ? cmin + lane : cmax;
-    int r0c = r0 < ps - TS ? r0 : ps - TS; // clamped strips overlap: rows below r0 are masked out
+    // column pass geometry: lanes run along columns, the wave's strip along rows.  A box at most 32 columns wide would
+    // leave half of the lanes idle, so there the strip is SPLIT: lanes 0-31 take its upper half, lanes 32-63 the lower half
+    // (CT = TS / 2 outputs per lane from a window of CT + 29: half the FMAs, six loads fewer)
+    const bool split = (TS % 2 == 0) && cmax - cmin < 32; // wave-uniform
+    const int CTr = split ? TS / 2 : TS;
+    const int cl = split ? (lane & 31) : lane;
+    const int r0w = rmin + wv * TS;
+    const bool cstrip = r0w <= rmax && !(dbg & 2); // wave-uniform: the wave's strip holds mask rows
+    const int r0 = r0w + (split ? (lane >> 5) * CTr : 0);
+    const int c = cmin + cl <= cmax ? cmin + cl : cmax;
+    int r0c = r0 < ps - CTr ? r0 : ps - CTr; // clamped strips overlap: rows below r0 are masked out
     r0c = r0c > 0 ? r0c : 0;
     const f2 *su = &S.UW[r0c * GB_UW + c]; // row (r0c - 15) + 15
     // bit q: pixel (r0c + q, c) is in the mask and belongs to this strip.  Column c of this view's mask is row c of
@@ -205,8 +212,8 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
     {
         const uint64_t column = s_view[view ^ 1].wrow[c];
         const int skip = r0 - r0c < 31 ? r0 - r0c : 31; // clamped strips overlap: rows below r0 belong to the strip before
-        mbits = (unsigned)(column >> r0c) & ((1u << TS) - 1u) & ~((1u << skip) - 1u);
-        if (cmin + lane > cmax) mbits = 0u;
+        mbits = (unsigned)(column >> r0c) & ((1u << CTr) - 1u) & ~((1u << skip) - 1u);
+        if (cmin + cl > cmax || r0 > rmax) mbits = 0u;
     }
 
     for (int g = g_begin; g < ((dbg & 4) ? 0 : g_end); ++g) {
@@ -241,51 +248,56 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
         __syncthreads();
         // ---- column passes ------------------------------------------------------------------------------------------
         const int n_pass = __float_as_int(wt[GB_META]);
-        f2 x[WIN];
-        if (cstrip) {
-#pragma unroll
-            for (int j = 0; j < WIN; ++j) x[j] = su[j * GB_UW];
-        }
-#pragma unroll 1
-        for (int p = 0; p < n_pass; ++p) {
-            const float *wp = wt + (1 + p) * GB_WSLOT;
-            const int meta = __float_as_int(wp[GB_META + 2]); // combine | slot0 << 8 | slot1 << 16 (255: none)
-            f2 a = {0.0f, 0.0f}, b = {0.0f, 0.0f};
+        auto column_passes = [&](auto ct_tag) {
+            constexpr int CT = decltype(ct_tag)::value, CWIN = CT + GB_SIZE - 1;
+            f2 x[CWIN];
             if (cstrip) {
-                f2 acc[TS];
-                const float sh0 = wp[GB_META] * mu_gray, sh1 = wp[GB_META + 1] * mu_gray; // DC gain x mean masked gray
-                // the accumulators start at minus the shift (for the mixed pair: A - B starts at -sh0, A + B at -sh1), so
-                // the responses come out already shifted; masked partial sums of the strip's TS responses follow (f32
-                // inside the strip and the wave, f64 across waves)
-                if (meta & 1) {
-                    taps2<TS, f2>(x, wp, (f2){-0.5f * (sh0 + sh1), 0.5f * (sh0 - sh1)}, acc);
 #pragma unroll
-                    for (int q = 0; q < TS; ++q) {
-                        const float mq = ((mbits >> q) & 1u) ? 1.0f : 0.0f; // the mask as a 0/1 factor: packed multiply
-                        const f2 d = (f2){acc[q].x - acc[q].y, acc[q].x + acc[q].y} * (f2){mq, mq};
-                        a += d;
-                        b = __builtin_elementwise_fma(d, d, b);
-                    }
-                } else {
-                    taps2<TS, f2>(x, wp, (f2){-sh0, -sh1}, acc);
+                for (int j = 0; j < CWIN; ++j) x[j] = su[j * GB_UW];
+            }
+#pragma unroll 1
+            for (int p = 0; p < n_pass; ++p) {
+                const float *wp = wt + (1 + p) * GB_WSLOT;
+                const int meta = __float_as_int(wp[GB_META + 2]); // combine | slot0 << 8 | slot1 << 16 (255: none)
+                f2 a = {0.0f, 0.0f}, b = {0.0f, 0.0f};
+                if (cstrip) {
+                    f2 acc[CT];
+                    const float sh0 = wp[GB_META] * mu_gray, sh1 = wp[GB_META + 1] * mu_gray; // DC gain x mean masked gray
+                    // the accumulators start at minus the shift (for the mixed pair: A - B starts at -sh0, A + B at -sh1), so
+                    // the responses come out already shifted; masked partial sums of the strip's responses follow (f32
+                    // inside the strip and the wave, f64 across waves)
+                    if (meta & 1) {
+                        taps2<CT, f2>(x, wp, (f2){-0.5f * (sh0 + sh1), 0.5f * (sh0 - sh1)}, acc);
 #pragma unroll
-                    for (int q = 0; q < TS; ++q) {
-                        const float mq = ((mbits >> q) & 1u) ? 1.0f : 0.0f;
-                        const f2 d = acc[q] * (f2){mq, mq};
-                        a += d;
-                        b = __builtin_elementwise_fma(d, d, b);
+                        for (int q = 0; q < CT; ++q) {
+                            const float mq = ((mbits >> q) & 1u) ? 1.0f : 0.0f; // the mask as a 0/1 factor: packed multiply
+                            const f2 d = (f2){acc[q].x - acc[q].y, acc[q].x + acc[q].y} * (f2){mq, mq};
+                            a += d;
+                            b = __builtin_elementwise_fma(d, d, b);
+                        }
+                    } else {
+                        taps2<CT, f2>(x, wp, (f2){-sh0, -sh1}, acc);
+#pragma unroll
+                        for (int q = 0; q < CT; ++q) {
+                            const float mq = ((mbits >> q) & 1u) ? 1.0f : 0.0f;
+                            const f2 d = acc[q] * (f2){mq, mq};
+                            a += d;
+                            b = __builtin_elementwise_fma(d, d, b);
+                        }
                     }
                 }
+                // every wave runs exactly one strip per pass; each lane holds shifted sums (small numbers), so an f32 wave
+                // reduction is exact enough
+                const float a0 = wave_total_f32(a.x), b0 = wave_total_f32(b.x), a1 = wave_total_f32(a.y), b1 = wave_total_f32(b.y);
+                if (lane == 0) {
+                    const int f0 = (meta >> 8) & 255, f1 = (meta >> 16) & 255;
+                    if (f0 != 255) { s_part[wv][f0][0] = (double)a0; s_part[wv][f0][1] = (double)b0; }
+                    if (f1 != 255) { s_part[wv][f1][0] = (double)a1; s_part[wv][f1][1] = (double)b1; }
+                }
             }
-            // every wave runs exactly one strip per pass; each lane holds shifted sums (small numbers), so an f32 wave
-            // reduction is exact enough
-            const float a0 = wave_total_f32(a.x), b0 = wave_total_f32(b.x), a1 = wave_total_f32(a.y), b1 = wave_total_f32(b.y);
-            if (lane == 0) {
-                const int f0 = (meta >> 8) & 255, f1 = (meta >> 16) & 255;
-                if (f0 != 255) { s_part[wv][f0][0] = (double)a0; s_part[wv][f0][1] = (double)b0; }
-                if (f1 != 255) { s_part[wv][f1][0] = (double)a1; s_part[wv][f1][1] = (double)b1; }
-            }
-        }
+        };
+        if (split) column_passes(std::integral_constant<int, (TS % 2 == 0) ? TS / 2 : TS>{});
+        else column_passes(std::integral_constant<int, TS>{});
         buf ^= 1; // the other buffer was last read by group g-1, which every wave left before this iteration's first barrier
         if (t < GB_WBUF / 4) reinterpret_cast<float4 *>(s_wt[buf])[t] = wnext;
     }
