@@ -13,7 +13,8 @@
 //   k_color      one wavefront per nucleus.  The masked pixels' positions are compacted into a per-wave LDS list
 //                (a mask row fills well under half a wave), then ONE pass walks the list with every lane busy,
 //                two pixels per lane in flight: it dots the mask with S and C (-> mean_h), converts
-//                RGB->HSV/HED in registers and accumulates sum x and sum x^2 of nine channels in f64; the
+//                RGB->HSV/HED in registers and accumulates sum x and sum x^2 of nine channels (exact integers for the
+//                byte-valued r, g, b, v of u8 pixels, f64 for the rest); the
 //                variance about the f32-rounded mean is then sum x^2 - 2 mu sum x + K mu^2 (the two-pass
 //                result of color.rs:123-128 without a second pass over the pixels).  The hue statistics are
 //                taken on h itself: the shift by mean_h (color.rs:52) only reaches the standard deviation,
