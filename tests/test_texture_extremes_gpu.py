@@ -79,3 +79,32 @@ def test_extreme_textures_match_the_oracle(nfx, ctx, ps):
         assert got[i, cols.index(f"angular_second_moment_0_1_{L}")] == 1.0
         assert got[i, cols.index(f"entropy_0_1_{L}")] == 0.0
         assert got[i, cols.index(f"contrast_0_1_{L}")] == 0.0
+
+
+@pytest.mark.parametrize("ps", [32, 64])
+def test_extreme_textures_through_the_trait_entry(nfx, ctx, ps):
+    """The same textures as f32 tensors through `compute_features_batched` (one set, one batch of f32 patchs + f32 masks):
+    the kernels take their f32 loaders here (no byte staging, no exact-division shortcuts), and the batch-coupled hue
+    mean sees all textures in ONE batch, as a reference batch would."""
+    rng = np.random.default_rng(100 + ps)
+    tex = textures(ps, rng)
+    rs = rings(ps)
+    names, ring_list, patches = [], [], []
+    for nm, p in tex.items():
+        for k, r in enumerate(rs):
+            names.append(f"{nm} / ring {k}")
+            ring_list.append(r)
+            patches.append(p)
+    off = np.zeros(len(ring_list) + 1, np.uint32)
+    np.cumsum([len(r) for r in ring_list], out=off[1:])
+    xy = np.concatenate(ring_list).astype(np.float32)
+    patchs = (np.stack(patches).astype(np.float32) / np.float32(255.0)).astype(np.float32)
+    patchs[1::7] = np.clip(patchs[1::7] * np.float32(1.0001), 0, 1)   # some values that are not k / 255
+    cen, ctr = ctx.preprocess_polygons(off, xy)
+    masks = ctx.rasterize_polygons(off, ctr, ps)
+    for set_id in range(5):
+        want = orc.compute_features_batched(set_id, off, ctr, patchs, masks[:, 0])
+        got = ctx.compute_features_batched(set_id, off, ctr, patchs, masks)
+        scales = par.column_scales(nfx, [set_id], ps)
+        for i, nm in enumerate(names):
+            par.assert_rows_close(got[i:i + 1], want[i:i + 1], scales, what=f"trait {nfx.feature_set_cli_name(set_id)} ps={ps} {nm}")
