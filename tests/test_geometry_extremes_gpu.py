@@ -79,3 +79,38 @@ def test_boundary_rings_match_the_oracle(nfx, ctx, ps):
     scales = par.column_scales(nfx, sets, ps)
     for i, nm in enumerate(names):
         par.assert_rows_close(got[i:i + 1], want[i:i + 1], scales, exact_cols=(0,), what=f"ps={ps} {nm}")
+
+
+@pytest.mark.parametrize("ps", [32, 48, 64])
+def test_random_rings_of_any_shape(nfx, ctx, ps):
+    """Rings nobody would draw: 0-80 uniformly random vertices in a box twice the patch (self-intersecting, mostly outside,
+    many crossings per scanline), a third of them on integer or half-integer coordinates (ties), every feature set."""
+    rng = np.random.default_rng(1234 + ps)
+    n = 240
+    ring_list = []
+    for i in range(n):
+        V = int(rng.integers(0, 81))
+        c = rng.uniform(200.0, 5000.0, 2)
+        pts = c + rng.uniform(-ps, ps, (V, 2)) * rng.uniform(0.05, 1.0)
+        if i % 3 == 0:
+            pts = np.round(pts * 2.0) / 2.0
+        if V and i % 2 == 0:
+            pts = np.concatenate([pts, pts[:1]])
+        ring_list.append(pts.astype(np.float32))
+    off = np.zeros(n + 1, np.uint32)
+    np.cumsum([len(r) for r in ring_list], out=off[1:])
+    xy = np.concatenate(ring_list).astype(np.float32)
+    cen, ctr = ctx.preprocess_polygons(off, xy)
+    got_masks = ctx.rasterize_polygons(off, ctr, ps)[:, 0]
+    for i in range(n):
+        _, wctr = orc.preprocess_polygon(ring_list[i])
+        want = orc.raster_polygon(wctr, ps)
+        assert np.array_equal(got_masks[i], want), f"ps={ps} ring {i} (V={len(ring_list[i])}): mask differs in {(got_masks[i] != want).sum()} pixels"
+    pu8 = rng.integers(0, 256, (n, 3, ps, ps), dtype=np.uint8)
+    sets = [0, 1, 2, 3, 4]
+    want, wcen = orc.extract(sets, off, xy, pu8, ps, batch_size=50, threads=8)
+    got, gcen = ctx.extract(sets, off, xy, pu8, ps, batch_size=50)
+    assert np.array_equal(gcen, wcen, equal_nan=True)
+    scales = par.column_scales(nfx, sets, ps)
+    for i in range(n):
+        par.assert_rows_close(got[i:i + 1], want[i:i + 1], scales, exact_cols=(0,), what=f"ps={ps} random ring {i} (V={len(ring_list[i])})")
