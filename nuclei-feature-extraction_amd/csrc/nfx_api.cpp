@@ -236,7 +236,13 @@ nfx_status nfx_ctx_create(int device, nfx_ctx **out)
     if (hipSetDevice(device) != hipSuccess) return NFX_ERR_DEVICE;
     nfx_ctx *c = new nfx_ctx();
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return NFX_ERR_DEVICE; }
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        nfx_ctx_destroy(c);
+        return NFX_ERR_DEVICE;
+    }
     *out = c;
     return NFX_OK;
 }
@@ -247,6 +253,9 @@ void nfx_ctx_destroy(nfx_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
+    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (auto &t : ctx->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->ws) (void)hipFree(ctx->ws);
@@ -399,6 +408,16 @@ static nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int6
     if (!centred || (pix && !rows) || (image && !centroids)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
 
     NFX_HIP(ctx, launch_preprocess(ctx, n, ring_off, ring_xy, centroids, centred));
+    // fork: the polygon columns only need the centred rings, and their kernel is bound by the latency of 64 serial programs
+    // per wave, not by issue slots or bandwidth -- it runs on the side stream next to everything below and is joined at the end
+    bool forked = false;
+    hipStream_t const main_stream = ctx->stream;
+    for (int s = 0; s < n_sets; ++s) forked = forked || sets[s] == NFX_SET_GEOMETRY;
+    forked = forked && pix; // next to the rasteriser alone (geometry only) the two f64-heavy kernels just share the issue slots: no gain
+    if (forked) {
+        NFX_HIP(ctx, hipEventRecord(ctx->ev_fork, main_stream));
+        NFX_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+    }
     if (image && pix) {
         uint8_t *gp = (uint8_t *)ws_alloc(ctx, (size_t)n * 3 * ps * ps);
         if (!gp) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
@@ -431,7 +450,10 @@ static nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int6
             if (!scr) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
             if (geo_done) // a repeated "geometry" (args.rs does not de-duplicate): recompute into its own columns
                 NFX_HIP(ctx, launch_raster_shape(ctx, n, ring_off, centred, ps, nullptr, out_rows, F, col));
-            NFX_HIP(ctx, launch_polygon(ctx, n, ring_off, centred, scr, out_rows, F, col));
+            if (forked) ctx->stream = ctx->side_stream; // launch (and time) on the side stream
+            const hipError_t pe = launch_polygon(ctx, n, ring_off, centred, scr, out_rows, F, col);
+            ctx->stream = main_stream;
+            NFX_HIP(ctx, pe);
             geo_done = true;
             break;
         }
@@ -451,6 +473,10 @@ static nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int6
         case NFX_SET_GABOR: NFX_HIP(ctx, launch_gabor(ctx, job, col)); break;
         }
         col += kNumCols[sets[s]];
+    }
+    if (forked) { // join
+        NFX_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
+        NFX_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
     }
     return NFX_OK;
 }

@@ -39,6 +39,8 @@ struct nfx_ctx {
     hipStream_t stream = nullptr;     // where NFX_MEM_DEVICE calls are enqueued (nfx_ctx_set_stream; NULL = the default stream)
     hipStream_t own_stream = nullptr; // non-blocking stream of the synchronous NFX_MEM_HOST calls: contexts driven from
                                       // different host threads overlap on the GPU instead of queueing on the default stream
+    hipStream_t side_stream = nullptr; // the polygon kernel (64 serial programs per wave: latency-bound, hardly any issue slots) runs
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr; // here, beside the rasteriser and the pixel kernels of the same call
     nfx_addressing addressing = NFX_ADDR_IMAGE;
     std::string err;
     // grow-only device workspace with a bump pointer, reset at the start of every API call
