@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_unpack_masks(int64_t nrows, const uint6
 
 // utils.rs:159-191: top/left/bottom/right = trunc(c -/+ ps/2) as i64, clipped to the image; the
 // crop is pasted at (-min(top,0), -min(left,0)) into a zeroed [3,ps,ps] patch.
-__global__ __launch_bounds__(256) void k_gather_patches(int64_t n, const float *__restrict__ centroids,
+__global__ __launch_bounds__(1024) void k_gather_patches(int64_t n, const float *__restrict__ centroids,
                                                         const uint8_t *__restrict__ image, int64_t H, int64_t W, int ps,
                                                         int slide_addressing, uint8_t *__restrict__ patches)
 {
@@ -110,6 +110,33 @@ __global__ __launch_bounds__(256) void k_gather_patches(int64_t n, const float *
     }
     const int P = ps * ps;
     uint8_t *dst = patches + (size_t)i * 3 * P;
+    // a window that lies wholly inside the image -- all but the border nuclei -- is 3 ps rows of ps consecutive bytes each
+    // way: 16 bytes per thread and trip (one unaligned load, one aligned store) instead of one
+    if (oy == 0 && ox == 0 && b0 - t0 == ps && r0 - l0 == ps && (ps & 15) == 0 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0) {
+        const int cpr = ps >> 4; // 16-byte chunks per row
+        const int chunks = 3 * ps * cpr;
+        // four chunks per thread, all loads before the first store.  (With nuclei in random order over a large slide every
+        // 48-byte row of a window is its own DRAM burst: the kernel then runs at the memory's pace for ~4x the useful
+        // bytes, whatever the shape of the copy loop; slide-ordered nuclei hit L2 for the 2.25x overlap of their windows.)
+        for (int k0 = threadIdx.x; k0 < chunks; k0 += 4 * blockDim.x) {
+            uint4 v[4];
+            int at[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * (int)blockDim.x;
+                const int kk = k < chunks ? k : k0;
+                const int rowi = kk / cpr, chunk = kk - rowi * cpr; // rowi = channel * ps + patch row
+                const int ch = rowi / ps, pr = rowi - ch * ps;
+                const uint8_t *src = image + ((size_t)ch * H + (size_t)(t0 + pr)) * W + (size_t)l0 + 16 * chunk;
+                __builtin_memcpy(&v[u], src, 16); // the target allows unaligned vector loads: one global_load_dwordx4
+                at[u] = k < chunks ? rowi * ps + 16 * chunk : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (at[u] >= 0) *reinterpret_cast<uint4 *>(dst + at[u]) = v[u];
+        }
+        return;
+    }
     for (int k = threadIdx.x; k < 3 * P; k += blockDim.x) {
         const int ch = k / P, rem = k - ch * P;
         const int pr = rem / ps, pc = rem - pr * ps;
@@ -152,7 +179,14 @@ hipError_t launch_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids
 {
     if (n == 0) return hipSuccess;
     ScopedTiming t(ctx, KS_GATHER);
-    hipLaunchKernelGGL(k_gather_patches, dim3((unsigned)n), dim3(256), 0, ctx->stream, n, centroids, image, H, W, ps,
+    // one block per nucleus; when the 16-byte path applies a thread moves four chunks (128 threads for 48x48, 192 for 64x64)
+    int threads = 256;
+    if ((ps & 15) == 0) {
+        const int chunks = 3 * ps * (ps >> 4);
+        threads = ((chunks + 3) / 4 + 63) / 64 * 64; // four chunks per thread
+        threads = threads > 1024 ? 1024 : threads;
+    }
+    hipLaunchKernelGGL(k_gather_patches, dim3((unsigned)n), dim3((unsigned)threads), 0, ctx->stream, n, centroids, image, H, W, ps,
                        ctx->addressing == NFX_ADDR_SLIDE ? 1 : 0, patches);
     return hipGetLastError();
 }
