@@ -100,7 +100,7 @@ inline ImageU8 decode_png(const uint8_t *buf, size_t len)
             case 2: case 6: R[x] = px[0]; G[x] = px[1]; B[x] = px[2]; break;
             case 3: {
                 const size_t k = (size_t)px[0] * 3;
-                if (k + 2 >= plte.size() + 0 && k + 2 > plte.size() - 1) throw std::runtime_error("png: palette index out of range");
+                if (k + 2 >= plte.size()) throw std::runtime_error("png: palette index out of range");
                 R[x] = plte[k]; G[x] = plte[k + 1]; B[x] = plte[k + 2];
                 break;
             }

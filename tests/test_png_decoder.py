@@ -1,0 +1,136 @@
+"""The C++ host's PNG decoder (host/png.hpp; the reference loads slides with tch::vision::image::load, main.rs:25-27, into a
+[3,H,W] u8 tensor): every colour type and every scanline filter against images encoded here, plus malformed files.
+A small driver is compiled around the header; no GPU involved."""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "nuclei-feature-extraction_amd", "host", "png.hpp")
+
+DRIVER = r"""
+#include "%s"
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+int main(int argc, char **argv)
+{
+    std::ifstream f(argv[1], std::ios::binary);
+    std::vector<uint8_t> b((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    try {
+        nfxhost::ImageU8 img = nfxhost::decode_png(b.data(), b.size());
+        FILE *o = fopen(argv[2], "wb");
+        int64_t hw[2] = {img.H, img.W};
+        fwrite(hw, 8, 2, o);
+        fwrite(img.data.data(), 1, img.data.size(), o);
+        fclose(o);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "%%s\n", e.what());
+        return 3;
+    }
+    return 0;
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    d = tmp_path_factory.mktemp("png")
+    src = d / "driver.cpp"
+    src.write_text(DRIVER % HEADER)
+    exe = d / "driver"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-o", str(exe), str(src), "-lz"], check=True)
+    return exe
+
+
+def chunk(t, d):
+    return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+
+def paeth(a, b, c):
+    p = a + b - c
+    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+    return a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+
+
+def encode(pix, ctype, filters, plte=None, idat_pieces=1):
+    """pix: [H, W, ch] u8 samples as stored in the file; filters: one filter type per row."""
+    H, W, ch = pix.shape
+    raw = bytearray()
+    prev = np.zeros(W * ch, np.int32)
+    for y in range(H):
+        cur = pix[y].reshape(-1).astype(np.int32)
+        ft = filters[y % len(filters)]
+        out = np.zeros_like(cur)
+        for i in range(W * ch):
+            a = cur[i - ch] if i >= ch else 0
+            b = prev[i]
+            c = prev[i - ch] if i >= ch else 0
+            pred = [0, a, b, (a + b) >> 1, paeth(a, b, c)][ft]
+            out[i] = (cur[i] - pred) & 255
+        raw.append(ft)
+        raw += out.astype(np.uint8).tobytes()
+        prev = cur
+    z = zlib.compress(bytes(raw), 6)
+    n = max(1, len(z) // idat_pieces)
+    body = b"".join(chunk(b"IDAT", z[i:i + n]) for i in range(0, len(z), n))
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, ctype, 0, 0, 0))
+    if plte is not None:
+        png += chunk(b"PLTE", plte.astype(np.uint8).tobytes())
+    return png + chunk(b"tEXt", b"Comment\x00ancillary chunks are skipped") + body + chunk(b"IEND", b"")
+
+
+def decode(driver, tmp_path, png):
+    (tmp_path / "a.png").write_bytes(png)
+    r = subprocess.run([str(driver), str(tmp_path / "a.png"), str(tmp_path / "a.bin")], capture_output=True, text=True)
+    if r.returncode != 0:
+        return r.returncode, r.stderr
+    b = (tmp_path / "a.bin").read_bytes()
+    H, W = struct.unpack("qq", b[:16])
+    return 0, np.frombuffer(b[16:], np.uint8).reshape(3, H, W)
+
+
+@pytest.mark.parametrize("filters", [[0], [1], [2], [3], [4], [0, 1, 2, 3, 4]])
+def test_rgb_every_filter(driver, tmp_path, filters):
+    rng = np.random.default_rng(len(filters) * 7 + filters[0])
+    pix = rng.integers(0, 256, (23, 31, 3), dtype=np.uint8)
+    pix[5:9] = np.linspace(0, 255, 31).astype(np.uint8)[None, :, None]   # smooth rows: the predictors actually predict
+    rc, img = decode(driver, tmp_path, encode(pix, 2, filters, idat_pieces=3))
+    assert rc == 0
+    assert np.array_equal(img, pix.transpose(2, 0, 1))                 # planar [3,H,W], as image::load returns it
+
+
+def test_other_colour_types(driver, tmp_path):
+    rng = np.random.default_rng(3)
+    gray = rng.integers(0, 256, (9, 14, 1), dtype=np.uint8)
+    rc, img = decode(driver, tmp_path, encode(gray, 0, [4]))
+    assert rc == 0 and all(np.array_equal(img[k], gray[:, :, 0]) for k in range(3))       # gray replicated
+    ga = rng.integers(0, 256, (9, 14, 2), dtype=np.uint8)
+    rc, img = decode(driver, tmp_path, encode(ga, 4, [3]))
+    assert rc == 0 and all(np.array_equal(img[k], ga[:, :, 0]) for k in range(3))         # alpha dropped
+    rgba = rng.integers(0, 256, (9, 14, 4), dtype=np.uint8)
+    rc, img = decode(driver, tmp_path, encode(rgba, 6, [1, 4]))
+    assert rc == 0 and np.array_equal(img, rgba[:, :, :3].transpose(2, 0, 1))
+    plte = rng.integers(0, 256, (40, 3), dtype=np.uint8)
+    idx = rng.integers(0, 40, (9, 14, 1), dtype=np.uint8)
+    rc, img = decode(driver, tmp_path, encode(idx, 3, [0, 2], plte=plte))
+    assert rc == 0 and np.array_equal(img, plte[idx[:, :, 0]].transpose(2, 0, 1))
+
+
+def test_malformed_files_are_errors_not_crashes(driver, tmp_path):
+    rng = np.random.default_rng(4)
+    pix = rng.integers(0, 256, (6, 6, 3), dtype=np.uint8)
+    good = encode(pix, 2, [0])
+    assert decode(driver, tmp_path, b"not a png at all")[0] == 3
+    assert decode(driver, tmp_path, good[:len(good) // 2])[0] == 3                      # truncated
+    assert decode(driver, tmp_path, good.replace(b"IDAT", b"iDAT"))[0] == 3              # no image data
+    idx = rng.integers(0, 40, (6, 6, 1), dtype=np.uint8)
+    assert decode(driver, tmp_path, encode(idx, 3, [0]))[0] == 3                          # palette image without a palette
+    short = rng.integers(0, 256, (10, 3), dtype=np.uint8)
+    assert decode(driver, tmp_path, encode(np.full((6, 6, 1), 30, np.uint8), 3, [0], plte=short))[0] == 3   # index past the palette
+    sixteen = bytearray(good); sixteen[24] = 16                                          # IHDR depth byte; the CRC is not checked
+    assert decode(driver, tmp_path, bytes(sixteen))[0] == 3
