@@ -53,3 +53,32 @@ for s in (2, 4):
         dt = time.perf_counter() - t0
         print(f"{name:9s} host, {T:2d} threads x {per} calls: {T * per * B / dt / 1e3:8.1f} k nuclei/s aggregate", flush=True)
         for c in ctxs: c.close()
+
+# ---- one reference batch through the fast entry (u8 patches, all five sets), eager launches vs one HIP graph ---------
+ctx = nfx.Context(0)
+d_off_i = torch.from_numpy(off.astype(np.int32)).to(d); d_xy_raw = torch.from_numpy(xy).to(d); d_pu8 = torch.from_numpy(pu8).to(d)
+out = torch.empty((B, 418), dtype=torch.float32, device=d)
+all_sets = [0, 1, 2, 3, 4]
+ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+for _ in range(3):
+    ctx.extract(all_sets, d_off_i, d_xy_raw, d_pu8, ps, batch_size=B, out=out, want_centroids=False)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(calls):
+    ctx.extract(all_sets, d_off_i, d_xy_raw, d_pu8, ps, batch_size=B, out=out, want_centroids=False)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / calls
+print(f"fast entry, all sets, batch {B}, eager : {dt * 1e6:8.1f} us per call, {B / dt / 1e3:8.1f} k nuclei/s", flush=True)
+g = torch.cuda.CUDAGraph(); side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    ctx.set_stream(side.cuda_stream)
+    with torch.cuda.graph(g, stream=side):
+        ctx.extract(all_sets, d_off_i, d_xy_raw, d_pu8, ps, batch_size=B, out=out, want_centroids=False)
+torch.cuda.current_stream().wait_stream(side)
+for _ in range(3): g.replay()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(calls): g.replay()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / calls
+print(f"fast entry, all sets, batch {B}, graph : {dt * 1e6:8.1f} us per call, {B / dt / 1e3:8.1f} k nuclei/s", flush=True)
