@@ -5,21 +5,34 @@
 
 A "step" is one pass of the hot path (polygon preprocessing + rasterisation + every selected feature
 set, rows gathered on rank 0) over one resident batch of synthetic nuclei.  Inputs are generated
-directly in HBM before the timed region (SURVEY.md §8d generator).  Scaling is weak: every rank holds
-its own index shard of `--nuclei` nuclei (shard boundaries are multiples of the reference batch size,
-SURVEY.md §8e), extracts it with no data-path collective, then the feature rows are gathered to rank 0
-over RCCL (the path's only exchange step, the reference's vstack under a mutex, main.rs:96-108).
+directly in HBM before the timed region (SURVEY.md §8d generator).
 
 Default workload = BASELINE.json configs[2], the largest single-GPU configuration:
 1M nuclei, 48x48 patches, geometry+color+glcm (F=254), batch 100.
 
+N > 1 (`--gpus N`): started bare, this script launches its own N ranks as child processes
+(torch.distributed.run, one per GPU) before it touches a GPU itself; started by torch.distributed.run it is
+one of those ranks.  The headline is WEAK scaling -- every rank holds its own index shard of `--nuclei`
+nuclei (shard boundaries are multiples of the reference batch size), extracts it with no
+data-path collective and its rows are gathered to rank 0 over RCCL (the reference's vstack under a mutex,
+main.rs:96-108) through `distributed.ShardedExtraction`, the class the CPU gloo test drives.  The same run
+then times BASELINE.json configs[3] (the 1M nuclei of configs[2] cut into N shards: strong scaling) and rank 0
+checks that the gathered matrix is bit-identical to its own single-GPU extraction of the same nuclei; both
+go into the line's `also` object.
+
 The one JSON line also carries
   roofline     -- the dominant kernel's algorithmic bytes / its average launch time (HIP events on the
-                  engine's stream, measured live in this process) against the HBM peak;
-  cpu_baseline -- the CPU oracle (oracle/nfx_oracle.c, a port of the reference's arithmetic, OpenMP
-                  over reference batches) timed on this host on a bounded sample of the same workload.
+                  engine's stream, measured live in this process) against the HBM peak, plus the VALU issue
+                  rate of the same kernel from the committed SQ counter summary (if taken on this csrc/);
+  cpu_baseline -- the CPU oracle (oracle/nfx_oracle.c, a C/OpenMP port of the reference's arithmetic)
+                  timed on this host on a bounded sample of the same workload;
+  also         -- N = 1: the full-feature-set rate of the configs[4] per-GPU shard (the metric's "full feature
+                  set") with its own roofline, and the PCIe-inclusive rate of the headline workload (patches
+                  streamed from pinned host memory, rows copied back to pinned host memory, all inside the
+                  timed region: SURVEY.md §8d's wall-time definition).
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -33,15 +46,46 @@ sys.path.insert(0, ROOT)
 PKG = "nuclei-feature-extraction_amd"
 
 WORKLOADS = {
-    # name: (nuclei per GPU, patch size, feature sets, BASELINE.json config it is)
-    "config2": (100_000, 32, ["geometry"], "configs[1]: 100k nuclei, 32x32, geometry"),
-    "config3": (1_000_000, 48, ["geometry", "color", "glcm"], "configs[2]: 1M nuclei, 48x48, geometry+color+glcm"),
-    "config5": (1_250_000, 64, ["all"], "configs[4] per-GPU shard: 1.25M nuclei, 64x64, all"),
+    # name: (nuclei per GPU, patch size, feature sets, BASELINE.json config it is, seed index)
+    "config2": (100_000, 32, ["geometry"], "configs[1]: 100k nuclei, 32x32, geometry", 1),
+    "config3": (1_000_000, 48, ["geometry", "color", "glcm"], "configs[2]: 1M nuclei, 48x48, geometry+color+glcm", 2),
+    "config5": (1_250_000, 64, ["all"], "configs[4] per-GPU shard: 1.25M nuclei, 64x64, all", 4),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles, 2.4 GHz
+VALU_ISSUE_PEAK = 256 * 4 * 0.5 * 2.4e9   # wave-instructions per second
 
 
-def main():
+def csrc_stamp():
+    """sha256 over the kernel and ABI sources: committed counter summaries carry the stamp they were taken on."""
+    d = os.path.join(ROOT, PKG, "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h", ".cpp")):
+            h.update(fn.encode())
+            with open(os.path.join(d, fn), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(workload, kernel):
+    """(traffic bytes per launch, VALU wave-instructions per nucleus, source) from profiles/pmc_current.json when it
+    was taken on this build of csrc/ for this workload and kernel, else (None, None, why)."""
+    path = os.path.join(ROOT, "profiles", "pmc_current.json")
+    try:
+        with open(path) as fh:
+            doc = json.load(fh)
+    except (OSError, ValueError):
+        return None, None, "no profiles/pmc_current.json"
+    if doc.get("csrc_stamp") != csrc_stamp():
+        return None, None, f"profiles/pmc_current.json was taken on csrc {doc.get('csrc_stamp')}, this is {csrc_stamp()}"
+    t = doc.get(workload)
+    if not t or t.get("kernel") != kernel:
+        return None, None, f"profiles/pmc_current.json holds no counters for {workload}/{kernel}"
+    return t.get("traffic_bytes_per_launch"), t.get("valu_insts_per_nucleus"), doc.get("source", "profiles/pmc_current.json")
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -52,12 +96,100 @@ def main():
     ap.add_argument("--sets", default="", help="override the workload's feature sets (comma separated; experiments only)")
     ap.add_argument("--h2d", default="resident", choices=["resident", "stream"],
                     help="resident (default, the metric): inputs in HBM before the timed region; stream: patches start in pinned "
-                         "host memory and every step streams them in, double-buffered (PCIe-inclusive rate, DESIGN.md)")
+                         "host memory, every step streams them in and the rows back out (PCIe-inclusive rate, DESIGN.md)")
     ap.add_argument("--gather-slices", type=int, default=4, help="N>1: slices per step whose row gather overlaps the next slice's compute")
     ap.add_argument("--chunk", type=int, default=100_000, help="nuclei per streamed chunk (--h2d stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements of the `also` object")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+class Resident:
+    """One workload's synthetic inputs resident in HBM (nuclei [i0, i0+n) of the workload's seed stream)."""
+
+    def __init__(self, nfx, synth, torch, dev, workload, n, i0, set_names):
+        self.ps = WORKLOADS[workload][1]
+        self.sets = nfx.parse_feature_sets(set_names)
+        self.F = sum(nfx.num_columns(s) for s in self.sets)
+        self.seed = synth.SEED_BASE + WORKLOADS[workload][4]
+        self.n, self.i0 = n, i0
+        t0 = time.time()
+        self.off, self.xy = synth.polygons(self.seed, i0, n, self.ps)
+        self.d_off = torch.from_numpy(self.off.astype(np.int32)).to(dev)
+        self.d_off64 = self.d_off.to(torch.int64)
+        self.d_xy = torch.from_numpy(self.xy).to(dev)
+        self.pixel_sets = any(s != nfx.GEOMETRY for s in self.sets)
+        self.d_patches = synth.patches(self.seed, i0, n, self.ps, xp=torch, device=dev) if self.pixel_sets else None
+        torch.cuda.synchronize()
+        self.gen_s = time.time() - t0
+        self.torch = torch
+        v_mean = float(len(self.xy)) / max(1, n)
+        self.bytes_per_nucleus = (3 * self.ps * self.ps if self.pixel_sets else 0) + 8.0 * v_mean + 8 + 4 * self.F   # SURVEY.md §8d
+
+    def extract(self, ctx, b0, b1, out, batch_size):
+        """rows of the local nuclei [b0, b1) into out"""
+        if b0 == 0 and b1 == self.n:
+            ctx.extract(self.sets, self.d_off, self.d_xy, self.d_patches, self.ps, batch_size=batch_size, out=out, want_centroids=False)
+            return
+        v0, v1 = int(self.off[b0]), int(self.off[b1])
+        off = (self.d_off64[b0:b1 + 1] - v0).to(self.torch.int32)
+        ctx.extract(self.sets, off, self.d_xy[v0:v1], self.d_patches[b0:b1] if self.d_patches is not None else None, self.ps,
+                    batch_size=batch_size, out=out, want_centroids=False)
+
+
+def timed(torch, dist, use_dist, ctx, steps, warmup, step, fence):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.
+    Returns (seconds, per-kernel HIP-event timing of rank-local launches)."""
+    for _ in range(warmup):
+        step()
+    fence()
+    ctx.enable_timing(True)
+    ctx.reset_timing()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timing = ctx.kernel_timing()
+    ctx.enable_timing(False)
+    if use_dist:
+        el = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+        if dist.get_backend() == "gloo":
+            el = el.cpu()
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+    return elapsed, timing
+
+
+def roofline_of(timing, steps, res, workload, full_size):
+    dom_name, dom_t = max(timing.items(), key=lambda kv: kv[1]["total_ms"])
+    dom_avg_ms = dom_t["total_ms"] / max(1, dom_t["launches"])
+    launches_per_step = max(1, dom_t["launches"] // max(1, steps))
+    nuclei_per_launch = res.n / launches_per_step    # a kernel launched once per step processes the rank's nuclei
+    achieved = res.bytes_per_nucleus * nuclei_per_launch / (dom_avg_ms * 1e-3) / 1e9
+    traffic, valu, src = (None, None, "not the full-size workload") if not full_size else committed_counters(workload, dom_name)
+    issue = None
+    if valu is not None:
+        rate = valu * nuclei_per_launch / (dom_avg_ms * 1e-3)
+        issue = {"unit": "valu", "insts_per_nucleus": valu, "achieved": round(rate / 1e9, 2), "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
+                 "rate_unit": "G wave-instructions/s", "frac": round(rate / VALU_ISSUE_PEAK, 4)}
+    return {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "issue": issue, "counters_source": src,
+            "limiter": "VALU issue + LDS atomics (DESIGN.md §3): no kernel of this path is HBM-bound at these byte counts; the HBM "
+                       "fraction is reported because the metric asks for it",
+            "algorithmic_bytes_per_nucleus": round(res.bytes_per_nucleus, 1), "avg_launch_ms": round(dom_avg_ms, 4),
+            "kernels_ms_per_step": {k: round(v["total_ms"] / steps, 4) for k, v in timing.items() if v["launches"]}}
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        # bare `python bench.py --gpus N`: start the N ranks as children BEFORE this process touches a GPU
+        D = importlib.import_module(PKG + ".distributed")
+        sys.exit(D.launch_ranks(os.path.abspath(__file__), args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -74,16 +206,20 @@ def main():
             time.sleep(2.0)
     nfx = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
+    D = importlib.import_module(PKG + ".distributed")
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # the collective path is taken for N > 1 (or when forced, to rehearse it on a one-GPU box)
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    n_dev = torch.cuda.device_count()
+    # fewer GPUs than ranks (a one-GPU box rehearsing the N>1 path): ranks share devices and the collective runs over gloo
+    # through host memory -- same sharding, slicing and verification code, NOT a scaling measurement (flagged in the line)
+    rehearsal = world > max(1, n_dev)
+    torch.cuda.set_device(local_rank % max(1, n_dev))
+    dev = torch.device("cuda", local_rank % max(1, n_dev))
+    # the collective path is taken for N > 1 (or when forced, to rehearse RCCL itself with one rank)
     use_dist = world > 1 or (os.environ.get("NFX_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -93,7 +229,10 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=dev)
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -101,168 +240,165 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
-    n_def, ps, set_names, wl_desc = WORKLOADS[args.workload]
+    n_def, ps, set_names, wl_desc, _ = WORKLOADS[args.workload]
     if args.sets:
         set_names = args.sets.split(",")
         wl_desc += f" [feature sets overridden: {args.sets}]"
-    n_local = args.nuclei or n_def
     B = args.batch_size
-    n_local = max(B, (n_local // B) * B)          # shard boundary on a reference-batch boundary
-    sets = nfx.parse_feature_sets(set_names)
-    F = sum(nfx.num_columns(s) for s in sets)
-    cfg_idx = {"config2": 1, "config3": 2, "config5": 4}[args.workload]
-    seed = synth.SEED_BASE + cfg_idx
+    n_local = max(B, ((args.nuclei or n_def) // B) * B)          # shard boundary on a reference-batch boundary
+    full_size = n_local == n_def and not args.sets
 
-    # ---- synthetic inputs, resident in HBM before the timed region ----------------------------------
-    i0 = rank * n_local
-    t0 = time.time()
-    off, xy = synth.polygons(seed, i0, n_local, ps)
-    d_off = torch.from_numpy(off.astype(np.int32)).to(dev)
-    d_xy = torch.from_numpy(xy).to(dev)
-    pixel_sets = any(s != nfx.GEOMETRY for s in sets)
-    d_patches = synth.patches(seed, i0, n_local, ps, xp=torch, device=dev) if pixel_sets else None
-    d_out = torch.empty((n_local, F), dtype=torch.float32, device=dev)
-    gather_list = [torch.empty((n_local, F), dtype=torch.float32, device=dev) for _ in range(world)] if (use_dist and rank == 0) else None
-    torch.cuda.synchronize()
-    gen_s = time.time() - t0
-
-    ctx = nfx.Context(local_rank)
+    res = Resident(nfx, synth, torch, dev, args.workload, n_local, rank * n_local, set_names)
+    sets, F = res.sets, res.F
+    ctx = nfx.Context(dev.index)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
+    ctx.reserve(sets, n_local, len(res.xy), ps, batch_size=B)   # device-memory calls never allocate after this
+    d_out = torch.empty((n_local, F), dtype=torch.float32, device=dev)
 
-    h_patches = None
-    if args.h2d == "stream" and pixel_sets:
-        pipeline = importlib.import_module(PKG + ".pipeline")
-        h_patches = torch.empty(d_patches.shape, dtype=torch.uint8, pin_memory=True)
-        h_patches.copy_(d_patches)
-        torch.cuda.synchronize()
-
-    # N > 1: the shard is extracted in a few batch-aligned slices and each slice's rows start their way to rank 0
-    # (RCCL gather, asynchronous on RCCL's own stream) while the next slice is being computed
-    n_slices = max(1, min(args.gather_slices, n_local // B)) if use_dist else 1
-    bounds = [((n_local // B) * k // n_slices) * B for k in range(n_slices)] + [n_local]
-    v_bounds = [int(off[b]) for b in bounds]
-    d_off64 = d_off.to(torch.int64)
-    slice_offs = [(d_off64[bounds[k]:bounds[k + 1] + 1] - v_bounds[k]).to(torch.int32) for k in range(n_slices)]
-
-    out_bufs = [d_out, torch.empty_like(d_out)] if (use_dist and h_patches is None) else [d_out]
-    state = {"step": 0, "pending": []}
-
-    def step():
-        if h_patches is not None:
-            pipeline.extract_streamed(ctx, sets, off, xy, h_patches, ps, batch_size=B, chunk_nuclei=args.chunk, out=d_out)
-            if use_dist:
-                dist.gather(d_out, gather_list, dst=0)
-            return
-        if not use_dist:
-            ctx.extract(sets, d_off, d_xy, d_patches, ps, batch_size=B, out=d_out, want_centroids=False)
-            return
-        # two row buffers alternate between steps: the gathers of step k stay in flight while step k+1 computes into the
-        # other buffer, and are waited for (on the stream, not the host) only before their buffer is written again
-        buf = out_bufs[state["step"] & 1]
-        works = []
-        for k in range(n_slices):
-            b0, b1 = bounds[k], bounds[k + 1]
-            ctx.extract(sets, slice_offs[k], d_xy[v_bounds[k]:v_bounds[k + 1]], d_patches[b0:b1] if d_patches is not None else None, ps,
-                        batch_size=B, out=buf[b0:b1], want_centroids=False)
-            works.append(dist.gather(buf[b0:b1], [g[b0:b1] for g in gather_list] if rank == 0 else None, dst=0, async_op=True))
-        for w in state["pending"]:
-            w.wait()
-        state["pending"] = works
-        state["step"] += 1
-
-    def fence():
-        for w in state["pending"]:
-            w.wait()
-        state["pending"] = []
+    def fence(sx=None):
+        if sx is not None:
+            sx.finish()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    ctx.enable_timing(True)
-    ctx.reset_timing()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    timing = ctx.kernel_timing()
-    ctx.enable_timing(False)
+    # ---- the headline: resident inputs; N > 1 weak scaling through ShardedExtraction ----------------------------------
+    stream_mode = args.h2d == "stream" and res.pixel_sets
+    sx = None
+    h_patches = h_rows = None
+    if stream_mode:
+        pipeline = importlib.import_module(PKG + ".pipeline")
+        h_patches = torch.empty(res.d_patches.shape, dtype=torch.uint8, pin_memory=True)
+        h_patches.copy_(res.d_patches)
+        h_rows = torch.empty((n_local, F), dtype=torch.float32, pin_memory=True)
+        torch.cuda.synchronize()
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+        def step():
+            pipeline.extract_streamed(ctx, sets, res.off, res.xy, h_patches, ps, batch_size=B, chunk_nuclei=args.chunk, out=d_out,
+                                      host_rows=h_rows, want_centroids=False)
+    elif use_dist:
+        sx = D.ShardedExtraction(world * n_local, F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if rehearsal else None)
+        assert (sx.i0, sx.i1) == (rank * n_local, (rank + 1) * n_local)
+
+        def step():
+            sx.step(lambda b0, b1, out: res.extract(ctx, b0, b1, out, B))
+    else:
+        def step():
+            res.extract(ctx, 0, n_local, d_out, B)
+
+    elapsed, timing = timed(torch, dist, use_dist, ctx, args.steps, args.warmup, step, lambda: fence(sx))
     total_nuclei = n_local * world
     value = total_nuclei * args.steps / elapsed
+    roofline = roofline_of(timing, args.steps, res, args.workload, full_size)
+    also = {}
+    if sx is not None:
+        ok = sx.verify_transport()
+        if rank == 0:
+            also["gather_checksums_match"] = bool(all(ok))
+        d_out = sx.local_rows()
 
-    # ---- roofline of the dominant kernel (rank 0's events) -------------------------------------------
-    v_mean = float(len(xy)) / n_local
-    bytes_per_nucleus = (3 * ps * ps if pixel_sets else 0) + 8.0 * v_mean + 8 + 4 * F
-    dom = max(timing.items(), key=lambda kv: kv[1]["total_ms"])
-    dom_name, dom_t = dom
-    dom_avg_ms = dom_t["total_ms"] / max(1, dom_t["launches"])
-    launches_per_step = max(1, dom_t["launches"] // max(1, args.steps))
-    # a kernel launched once per step processes the rank's n_local nuclei per launch
-    achieved = bytes_per_nucleus * (n_local / launches_per_step) / (dom_avg_ms * 1e-3) / 1e9
-    # HBM traffic of the dominant kernel from the PMC passes (rocprofv3 cannot run inside this process): taken from the
-    # committed summary of the same command when it matches this workload and kernel, else null
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-            t = json.load(fh).get(args.workload)
-        if t and t["kernel"] == dom_name and n_local == n_def and not args.sets:
-            traffic = t["traffic_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "algorithmic_bytes_per_nucleus": round(bytes_per_nucleus, 1), "avg_launch_ms": round(dom_avg_ms, 4),
-                "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in timing.items() if v["launches"]}}
-
-    # ---- CPU baseline: the oracle port on a bounded sample, rank 0 at N=1 only --------------------------
+    # ---- CPU baseline: the oracle port on a bounded sample, rank 0 at N=1 only ------------------------------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import _oracle as orc      # checker / baseline only -- never on the product path
+        import _parity as par
         # the GPU box grants 16 host cores per GPU (use NFX_CPU_THREADS to override)
         cores = int(os.environ.get("NFX_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
 
         def run_sample(m):
-            m = max(B, (m // B) * B)
-            m = min(m, n_local)
-            pu = d_patches[:m].cpu().numpy() if pixel_sets else np.zeros((m, 3, ps, ps), np.uint8)
-            so, sx = off[:m + 1], xy[:off[m]]
+            m = min(max(B, (m // B) * B), n_local)
+            pu = res.d_patches[:m].cpu().numpy() if res.pixel_sets else np.zeros((m, 3, ps, ps), np.uint8)
+            so, sxy = res.off[:m + 1], res.xy[:res.off[m]]
             t = time.perf_counter()
-            rows, _ = orc.extract(sets, so, sx, pu, ps, batch_size=B, threads=cores)
+            rows, _ = orc.extract(sets, so, sxy, pu, ps, batch_size=B, threads=cores)
             return m, time.perf_counter() - t, rows
 
         m0, dt0, _ = run_sample(max(B, cores * B))
-        rate0 = m0 / dt0
-        m1, dt1, rows = run_sample(int(rate0 * args.cpu_seconds))
+        m1, dt1, rows = run_sample(int(m0 / dt0 * args.cpu_seconds))
         # the sample doubles as an end-of-bench parity spot check of the resident result
-        got = d_out[:m1].cpu().numpy()
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import _parity as par
-        par.assert_rows_close(got, rows, par.column_scales(nfx, sets, ps), what="bench sample vs oracle")
+        got = (h_rows[:m1].numpy() if stream_mode else d_out[:m1].cpu().numpy())
+        worst = par.assert_rows_close(got, rows, par.column_scales(nfx, sets, ps), what="bench sample vs oracle")
         cpu = {"value": round(m1 / dt1, 1), "unit": "nuclei/s", "cores": cores, "kind": "port",
-               "sample": f"first {m1} nuclei of the same workload, oracle/nfx_oracle.c with OpenMP over reference batches ({cores} threads), {dt1:.1f} s"}
+               "what": "C/OpenMP oracle port of the reference's arithmetic (oracle/nfx_oracle.c), not the torch-CPU twin BASELINE.md §3 "
+                       "describes: a stronger (faster) CPU baseline than the reference's libtorch-CPU path would be",
+               "sample": f"first {m1} nuclei of the same workload, OpenMP over reference batches ({cores} threads), {dt1:.1f} s",
+               "parity_spot_check_worst_scaled_err": float(f"{worst:.3g}")}
+
+    # ---- also: the figures the metric names, under the same clock --------------------------------------------------------
+    if not args.no_also and full_size and args.workload == "config3" and not stream_mode:
+        if world == 1:
+            # (ii) PCIe-inclusive rate of the headline workload: first H2D byte to last row in pinned host memory
+            pipeline = importlib.import_module(PKG + ".pipeline")
+            hp = torch.empty(res.d_patches.shape, dtype=torch.uint8, pin_memory=True)
+            hp.copy_(res.d_patches)
+            hr = torch.empty((n_local, F), dtype=torch.float32, pin_memory=True)
+            torch.cuda.synchronize()
+            el_s, _ = timed(torch, dist, False, ctx, args.steps, 1,
+                            lambda: pipeline.extract_streamed(ctx, sets, res.off, res.xy, hp, ps, batch_size=B, chunk_nuclei=args.chunk,
+                                                              out=d_out, host_rows=hr, want_centroids=False), fence)
+            same = bool(torch.equal(hr.view(torch.int32), d_out.cpu().view(torch.int32)))
+            also["streamed_pcie_inclusive"] = {
+                "value": round(n_local * args.steps / el_s, 1), "unit": "nuclei/s", "ms_per_step": round(el_s / args.steps * 1e3, 3),
+                "what": f"{wl_desc}; patches start in pinned host memory and stream in every step in chunks of {args.chunk} nuclei "
+                        "(double-buffered), rows are copied back to pinned host memory chunk by chunk; timed from the first H2D "
+                        "byte to the last row on the host (SURVEY.md §8d); never the headline value",
+                "host_rows_equal_resident_rows": same}
+            del hp, hr
+            # (i) the metric's "full feature set": configs[4] per-GPU shard
+            res = None
+            d_out = None
+            torch.cuda.empty_cache()
+            r5 = Resident(nfx, synth, torch, dev, "config5", WORKLOADS["config5"][0], 0, WORKLOADS["config5"][2])
+            ctx.reserve(r5.sets, r5.n, len(r5.xy), r5.ps, batch_size=B)
+            o5 = torch.empty((r5.n, r5.F), dtype=torch.float32, device=dev)
+            el5, t5 = timed(torch, dist, False, ctx, max(2, args.steps // 2), 1, lambda: r5.extract(ctx, 0, r5.n, o5, B), fence)
+            k5 = max(2, args.steps // 2)
+            also["full_feature_set"] = {
+                "value": round(r5.n * k5 / el5, 1), "unit": "nuclei/s", "steps": k5, "ms_per_step": round(el5 / k5 * 1e3, 3),
+                "config": {"workload": WORKLOADS["config5"][3], "nuclei_per_gpu": r5.n, "patch_size": r5.ps, "feature_sets": ["all"],
+                           "columns": r5.F, "batch_size": B, "gen_seconds": round(r5.gen_s, 1)},
+                "roofline": roofline_of(t5, k5, r5, "config5", True)}
+            del r5, o5
+        elif use_dist:
+            # configs[3]: the SAME 1M nuclei cut into `world` batch-aligned shards (strong scaling); rank 0's weak-scaling
+            # inputs are exactly those 1M nuclei, so it can check the gathered matrix against its own single-GPU result
+            ssx = D.ShardedExtraction(n_def, F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if rehearsal else None)
+            rs = Resident(nfx, synth, torch, dev, args.workload, ssx.n_local, ssx.i0, set_names)
+            el_s, _ = timed(torch, dist, True, ctx, args.steps, 1, lambda: ssx.step(lambda b0, b1, out: rs.extract(ctx, b0, b1, out, B)),
+                            lambda: fence(ssx))
+            ok = ssx.verify_transport()
+            full = ssx.result()
+            if rank == 0:
+                single = torch.empty((n_def, F), dtype=torch.float32, device=dev)
+                res.extract(ctx, 0, n_def, single, B)
+                torch.cuda.synchronize()
+                same = bool(torch.equal(full.to(dev).view(torch.int32), single.view(torch.int32)))
+                also["strong_scaling_config4"] = {
+                    "value": round(n_def * args.steps / el_s, 1), "unit": "nuclei/s", "ms_per_step": round(el_s / args.steps * 1e3, 3),
+                    "scaling": "strong", "what": f"BASELINE.json configs[3]: the {n_def} nuclei of configs[2] index-sharded x{world} "
+                    "(batch-aligned shards), rows gathered to rank 0",
+                    "shard_nuclei": ssx.counts, "gather_checksums_match": bool(all(ok)), "gathered_equals_single_gpu": same,
+                    "gathered_checksum": D.row_checksum(full)}
+            dist.barrier()
 
     if rank == 0:
+        sharding = "single GPU"
+        if world > 1:
+            sharding = f"index-sharded x{world}, rows gathered to rank 0 " + ("(gloo through host memory: REHEARSAL on fewer GPUs than "
+                                                                             "ranks, not a scaling measurement)" if rehearsal else "(RCCL)")
         line = {
             "metric": "nuclei/sec", "value": round(value, 1), "unit": "nuclei/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64 (u8 pixels, integer counts)", "data": "synthetic",
             "config": {"workload": wl_desc, "nuclei_per_gpu": n_local, "patch_size": ps, "feature_sets": set_names,
-                       "columns": F, "batch_size": B, "sharding": f"index-sharded x{world}, rows gathered to rank 0 (RCCL)" if world > 1 else "single GPU",
-                       "inputs": "packed u8 patches + polygons resident in HBM" if h_patches is None else
-                                 f"patches streamed from pinned host memory every step in chunks of {args.chunk} (PCIe-inclusive; NOT the headline metric)",
-                       "gen_seconds": round(gen_s, 1)},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "columns": F, "batch_size": B, "sharding": sharding,
+                       "inputs": "packed u8 patches + polygons resident in HBM" if not stream_mode else
+                                 f"patches streamed from pinned host memory every step in chunks of {args.chunk}, rows copied back to "
+                                 "pinned host memory (PCIe-inclusive; NOT the headline metric)",
+                       "csrc_stamp": csrc_stamp()},
+            "roofline": roofline, "cpu_baseline": cpu, "also": also or None,
         }
         print(json.dumps(line), flush=True)
     if use_dist:

@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define NFX_VERSION 100 /* 0.1.0 */
+#define NFX_VERSION 200 /* 0.2.0 */
 
 typedef struct nfx_ctx nfx_ctx;
 
@@ -93,6 +93,12 @@ int nfx_feature_set_column_name(int set, int j, char *buf, size_t buflen);
 int nfx_parse_feature_sets(const char *const *names, int n_names, int *out_sets, int cap);
 /* "{x},{y}" with Rust's f32 Display (shortest round-trip, positional).  Returns length or -1. */
 int nfx_centroid_key(float x, float y, char *buf, size_t buflen);
+/* dtype of column j in the reference's frame: every tensor-derived column is f32 (`f32::from` / `Vec::<f32>::from`,
+   shape.rs:138-224, color.rs:55-77, texture.rs:64-79); the seven polygon-derived geometry columns are pushed as
+   geometric_features' own return values (shape.rs:89-97,116-127), f64 by inference from its (f64,f64) input points
+   (utils.rs:39-42).  nfx_extract writes f32 rows; nfx_polygon_features_f64 gives those seven columns unrounded. */
+typedef enum { NFX_DTYPE_F32 = 0, NFX_DTYPE_F64 = 1 } nfx_dtype;
+int nfx_feature_set_column_dtype(int set, int j); /* -1 on bad index */
 
 /* ---- context ----------------------------------------------------------------------------- */
 nfx_status nfx_ctx_create(int device, nfx_ctx **out);
@@ -114,6 +120,15 @@ typedef enum { NFX_ADDR_IMAGE = 0, NFX_ADDR_SLIDE = 1 } nfx_addressing;
 nfx_status nfx_ctx_set_patch_addressing(nfx_ctx *ctx, nfx_addressing mode);
 /* blocks until everything enqueued by this context has finished */
 nfx_status nfx_ctx_synchronize(nfx_ctx *ctx);
+/* Sizes the context's device workspace and builds every device table the listed sets need, once, up front, for
+   device-memory calls (nfx_extract, nfx_extract_tile, nfx_compute_features_batched, nfx_rasterize_polygons) of up to n nuclei,
+   n_vertices ring vertices, patch size ps and reference batch size batch_size (repeat the call for the largest of several
+   shapes: the reservation only grows).  Synchronises; call it when nothing is in flight on the context.
+   After a reservation NFX_MEM_DEVICE calls never allocate, free or synchronise: a call that does not fit fails with
+   NFX_ERR_OUT_OF_MEMORY instead of growing the workspace.  WITHOUT a reservation the first device-memory call of a larger
+   shape grows the workspace itself (hipStreamSynchronize + hipFree + hipMalloc) and builds missing tables with a synchronous
+   copy -- legal only outside stream capture; during a capture such a call fails with NFX_ERR_INVALID_ARGUMENT. */
+nfx_status nfx_ctx_reserve(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t n_vertices, int ps, int batch_size);
 
 /* Per-kernel device timing with HIP events on the context's stream (off by default).
    nfx_ctx_kernel_timing synchronises, then reports for kernel slot k: name, number of launches
@@ -165,9 +180,28 @@ nfx_status nfx_extract_tile(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n
                             const uint32_t *ring_offsets, const float *ring_xy, const uint8_t *image_u8, int64_t H,
                             int64_t W, int ps, int batch_size, float *out_rows, float *out_centroids_xy, nfx_mem mem);
 
+/* ---- geometric_features::{area, perimeter, equivalent_perimeter, compacity, convex_hull::convex_hull_features},
+   call sites shape.rs:89-97 -- the polygon-derived geometry columns at the reference's own width:
+     poly_offsets/poly_xy   centred polygons (utils.rs:66-73), as for nfx_compute_features_batched
+     out_f64 [n][7]         area, perimeter, equivalent_perimeter, compacity, convex_hull_area, convex_deffect, convex_perimeter
+   (the f32 rows of nfx_extract / nfx_compute_features_batched hold these same values rounded once to f32) */
+nfx_status nfx_polygon_features_f64(nfx_ctx *ctx, int64_t n, int64_t n_vertices, const uint32_t *poly_offsets,
+                                    const float *poly_xy, double *out_f64, nfx_mem mem);
+
 /* utils.rs:159-191 alone: crops [n][3][ps][ps] u8 out of image_u8 at the given centroids */
 nfx_status nfx_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids_xy, const uint8_t *image_u8, int64_t H,
                               int64_t W, int ps, uint8_t *patches_u8, nfx_mem mem);
+
+/* ---- TEST HOOK (not part of the reference's surface): the exact integers behind the texture columns, for count-level
+   parity checks against tch_utils::glcm::glcm / glrlm::glrlm as called at texture.rs:40-46,193-194.  Inputs as nfx_extract.
+   Either output may be NULL.
+     glcm_sums  [n][4 levels: 32,64,128,254][4 offsets: texture.rs:20][6] int64 of the SYMMETRIC count matrix G (G[a][b] +=1 and
+                G[b][a] += 1 per in-mask pair): pairs N = sum G / 2, sum (a+b) G / 2, sum (a+b)^2 G / 2, sum |a-b| G / 2,
+                sum (a-b)^2 G / 2, sum G^2
+     glrlm_bins [n][4 directions: texture.rs:176][24 levels][16 lengths] uint32 run counts */
+nfx_status nfx_debug_texture_counts(nfx_ctx *ctx, int64_t n, int64_t n_vertices, const uint32_t *ring_offsets,
+                                    const float *ring_xy, const uint8_t *patches_u8, int ps, int64_t *glcm_sums,
+                                    uint32_t *glrlm_bins, nfx_mem mem);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,8 @@ ABI_SYMBOLS = (
     "nfx_version", "nfx_feature_set_count", "nfx_feature_set_name", "nfx_feature_set_cli_name",
     "nfx_feature_set_num_columns", "nfx_feature_set_column_name", "nfx_parse_feature_sets", "nfx_centroid_key",
     "nfx_ctx_create", "nfx_ctx_destroy", "nfx_last_error", "nfx_ctx_set_stream", "nfx_ctx_synchronize",
-    "nfx_ctx_set_patch_addressing",
+    "nfx_ctx_set_patch_addressing", "nfx_ctx_reserve", "nfx_feature_set_column_dtype",
+    "nfx_polygon_features_f64", "nfx_debug_texture_counts",
     "nfx_ctx_enable_timing", "nfx_ctx_kernel_timing", "nfx_ctx_reset_timing",
     "nfx_preprocess_polygons", "nfx_rasterize_polygons", "nfx_compute_features_batched",
     "nfx_extract", "nfx_extract_tile", "nfx_gather_patches",
@@ -81,6 +82,10 @@ def lib() -> C.CDLL:
     L.nfx_extract.argtypes = [vp, i32p, C.c_int, i64, i64, u32p, f32p, u8p, C.c_int, C.c_int, f32p, f32p, C.c_int]
     L.nfx_extract_tile.argtypes = [vp, i32p, C.c_int, i64, i64, u32p, f32p, u8p, i64, i64, C.c_int, C.c_int, f32p, f32p, C.c_int]
     L.nfx_gather_patches.argtypes = [vp, i64, f32p, u8p, i64, i64, C.c_int, u8p, C.c_int]
+    L.nfx_ctx_reserve.argtypes = [vp, i32p, C.c_int, i64, i64, C.c_int, C.c_int]
+    L.nfx_feature_set_column_dtype.argtypes = [C.c_int, C.c_int]
+    L.nfx_polygon_features_f64.argtypes = [vp, i64, i64, u32p, f32p, vp, C.c_int]
+    L.nfx_debug_texture_counts.argtypes = [vp, i64, i64, u32p, f32p, u8p, C.c_int, vp, vp, C.c_int]
     _lib = L
     return L
 
@@ -106,6 +111,11 @@ def column_names(set_id: int) -> List[str]:
             raise NfxError("column name")
         out.append(buf.value.decode())
     return out
+
+
+def column_dtypes(set_id: int) -> List[str]:
+    """dtype of every column in the reference's frame ("f32" / "f64"): nfx_feature_set_column_dtype."""
+    return ["f64" if lib().nfx_feature_set_column_dtype(set_id, j) == 1 else "f32" for j in range(num_columns(set_id))]
 
 
 def parse_feature_sets(names: Sequence[str]) -> List[int]:
@@ -207,6 +217,12 @@ class Context:
     def synchronize(self):
         self._check(lib().nfx_ctx_synchronize(self._h))
 
+    def reserve(self, sets: Sequence[int], n: int, n_vertices: int, ps: int, batch_size: int = 100):
+        """nfx_ctx_reserve: workspace and device tables for device-memory calls of up to this shape, built up front; after it
+        such calls never allocate or synchronise (and fail instead of growing)."""
+        sets_arr = (C.c_int * len(sets))(*sets)
+        self._check(lib().nfx_ctx_reserve(self._h, sets_arr, len(sets), n, n_vertices, ps, batch_size))
+
     def enable_timing(self, on: bool = True):
         self._check(lib().nfx_ctx_enable_timing(self._h, int(on)))
 
@@ -252,6 +268,32 @@ class Context:
             r = np.empty((n, ps), np.uint64) if rows else None
         self._check(lib().nfx_rasterize_polygons(self._h, n, nv, _ptr(off), _ptr(xy), ps, _ptr(masks), _ptr(r), int(dev)))
         return (masks, r) if rows else masks
+
+    # -- geometric_features::* at their own width (shape.rs:89-97) ------------------------------------
+    def polygon_features_f64(self, poly_offsets, poly_xy):
+        dev = _is_torch(poly_xy) and poly_xy.is_cuda
+        off = _prep(poly_offsets, np.uint32, dev, "poly_offsets")
+        xy = _prep(poly_xy, np.float32, dev, "poly_xy")
+        n, nv = len(off) - 1, int(xy.shape[0])
+        if dev:
+            import torch
+            out = torch.empty((n, 7), dtype=torch.float64, device=xy.device)
+        else:
+            out = np.empty((n, 7), np.float64)
+        self._check(lib().nfx_polygon_features_f64(self._h, n, nv, _ptr(off), _ptr(xy), _ptr(out), int(dev)))
+        return out
+
+    # -- test hook: the integers behind the texture columns ----------------------------------------------
+    def debug_texture_counts(self, ring_offsets, ring_xy, patches_u8, ps: int, glcm: bool = True, glrlm: bool = True):
+        """(glcm_sums int64 [n,4 levels,4 offsets,6], glrlm_bins uint32 [n,4 directions,24,16]) -- nfx_debug_texture_counts."""
+        off = _prep(ring_offsets, np.uint32, False, "ring_offsets")
+        xy = _prep(ring_xy, np.float32, False, "ring_xy")
+        pu = _prep(patches_u8, np.uint8, False, "patches_u8")
+        n, nv = len(off) - 1, int(xy.shape[0])
+        g = np.zeros((n, 4, 4, 6), np.int64) if glcm else None
+        r = np.zeros((n, 4, 24, 16), np.uint32) if glrlm else None
+        self._check(lib().nfx_debug_texture_counts(self._h, n, nv, _ptr(off), _ptr(xy), _ptr(pu), ps, _ptr(g), _ptr(r), 0))
+        return g, r
 
     # -- trait FeatureSet::compute_features_batched ---------------------------------------------
     def compute_features_batched(self, set_id: int, poly_offsets, poly_xy, patchs, masks, centroids=None):

@@ -356,24 +356,29 @@ size_t color_scratch_bytes(const Job &job)
     return sizeof(double) * 2 * (size_t)(nb > 0 ? nb : 1) * job.ps * job.ps + 256;
 }
 
-static hipError_t ensure_od_lut(nfx_ctx *ctx)
+hipError_t prepare_color(nfx_ctx *ctx)
 {
     if (ctx->od_lut) return hipSuccess;
+    if (ctx->reserved || stream_capturing(ctx)) return hipErrorNotReady; // tables are built by nfx_ctx_reserve or before a capture
     float h[256];
     for (int u = 0; u < 256; ++u) {
         const float x = (float)u / 255.0f;
         const float xc = x > 1e-6f ? x : 1e-6f;
         h[u] = (float)(log((double)xc) / log(1e-6));
     }
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->od_lut), sizeof(h));
+    float *d = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), sizeof(h));
     if (e != hipSuccess) return e;
-    return hipMemcpy(ctx->od_lut, h, sizeof(h), hipMemcpyHostToDevice);
+    e = hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return e; }
+    ctx->od_lut = d; // published only once it is complete
+    return hipSuccess;
 }
 
 hipError_t launch_color(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
 {
     if (job.n == 0) return hipSuccess;
-    hipError_t e = ensure_od_lut(ctx);
+    hipError_t e = prepare_color(ctx);
     if (e != hipSuccess) return e;
     const int P = job.ps * job.ps;
     const int64_t nb = (job.n + job.batch_size - 1) / job.batch_size;

@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -549,28 +550,46 @@ static void build_tables(GaborTables &T)
     T.n_groups = ok ? ng : GB_MAX_GROUPS + 1;
 }
 
-static hipError_t ensure_tables(nfx_ctx *ctx)
+// The bank is the same for every context: built once per process (contexts are created and first used concurrently,
+// one per host thread -- main.rs:146-151), immutable afterwards.
+static const GaborTables &gabor_tables()
+{
+    static GaborTables T;
+    static std::once_flag once;
+    std::call_once(once, [] { build_tables(T); });
+    return T;
+}
+
+hipError_t prepare_gabor(nfx_ctx *ctx)
 {
     if (ctx->gabor_tab) return hipSuccess;
-    static GaborTables T;
-    build_tables(T);
-    if (T.n_groups > GB_MAX_GROUPS || T.n_filters > GB_MAX_FILTERS) return hipErrorInvalidValue;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->gabor_tab), sizeof(GaborTables));
+    if (ctx->reserved || stream_capturing(ctx)) return hipErrorNotReady; // tables are built by nfx_ctx_reserve or before a capture
+    const GaborTables &T = gabor_tables();
+    if (T.n_groups < 1 || T.n_groups > GB_MAX_GROUPS || T.n_filters < 1 || T.n_filters > GB_MAX_FILTERS) return hipErrorInvalidValue;
+    float *tab = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&tab), sizeof(GaborTables));
     if (e != hipSuccess) return e;
-    return hipMemcpy(ctx->gabor_tab, &T, sizeof(GaborTables), hipMemcpyHostToDevice);
+    e = hipMemcpy(tab, &T, sizeof(GaborTables), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(tab); return e; }
+    ctx->gabor_tab = tab; // published only once it is complete
+    return hipSuccess;
 }
 
 hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0)
 {
     if (job.n == 0) return hipSuccess;
-    hipError_t e = ensure_tables(ctx);
+    hipError_t e = prepare_gabor(ctx);
     if (e != hipSuccess) return e;
     ScopedTiming t(ctx, KS_GABOR);
     const int64_t maxb = 256 * 2 * 2;
     const unsigned grid = (unsigned)(job.n < maxb ? job.n : maxb);
     const GaborTables *tab = reinterpret_cast<const GaborTables *>(ctx->gabor_tab);
-    const char *dbg_env = getenv("NFX_GABOR_DBG"); // timing experiments only: 1 skip row pass, 2 skip column pass, 4 skip all groups
+#ifdef NFX_EXPERIMENTS // phase-skipping builds for timing experiments only (wrong results): 1 skip row pass, 2 skip column pass, 4 skip all groups
+    const char *dbg_env = getenv("NFX_GABOR_DBG");
     const int dbg = dbg_env ? atoi(dbg_env) : 0;
+#else
+    const int dbg = 0;
+#endif
     if (job.patches_f32)
         hipLaunchKernelGGL(k_gabor<float>, dim3(grid), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps,
                            reinterpret_cast<const float *>(job.patches), job.mask_rows, tab, job.out, job.F, col0, dbg);

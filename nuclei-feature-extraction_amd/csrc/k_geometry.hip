@@ -329,7 +329,7 @@ template <bool SHAPE>
 __global__ __launch_bounds__(256) void k_raster_shape(int64_t n, const uint32_t *__restrict__ poly_off,
                                                       const float *__restrict__ poly_xy, int ps,
                                                       uint64_t *__restrict__ rows_out, float *__restrict__ out, int F,
-                                                      int col0)
+                                                      int col0, int *__restrict__ areas_out)
 {
     __shared__ RasterLds s_raster[4];
     const int lane = threadIdx.x & 63;
@@ -337,6 +337,10 @@ __global__ __launch_bounds__(256) void k_raster_shape(int64_t n, const uint32_t 
     if (i >= n) return; // wave-uniform
     const uint64_t row = raster_row(poly_off, poly_xy, i, ps, lane, s_raster[threadIdx.x >> 6]);
     if (rows_out && lane < ps) rows_out[i * ps + lane] = row;
+    if (areas_out) { // the pixel kernels size their work by the mask's area: handed over instead of re-read from the rows
+        const int K = wave_sum(__popcll(row));
+        if (lane == 0) areas_out[i] = K;
+    }
     if (SHAPE) shape_from_row(row, ps, lane, out + i * (int64_t)F + col0);
 }
 
@@ -378,7 +382,7 @@ size_t polygon_scratch_bytes(int64_t n, int64_t total_vertices)
 }
 
 template <typename IDX, typename VP>
-static __device__ __forceinline__ void polygon_one(VP v, int V, IDX *srt, IDX *hull, float *__restrict__ o)
+static __device__ __forceinline__ void polygon_one(VP v, int V, IDX *srt, IDX *hull, float *__restrict__ o, double *__restrict__ o64)
 {
     auto P = [&](int k) { const float2 f = v[k]; return pt{(double)f.x, (double)f.y}; };
     const double PI = 3.14159265358979323846;
@@ -483,20 +487,25 @@ static __device__ __forceinline__ void polygon_one(VP v, int V, IDX *srt, IDX *h
     }
     const double harea = fabs(hsh) * 0.5;
     const double deviation = (harea - area) / harea;
-    o[0] = (float)area;
-    o[5] = (float)perim;
-    o[6] = (float)eq_perim;
-    o[7] = (float)compacity;
-    o[9] = (float)harea;
-    o[10] = (float)deviation;
-    o[11] = (float)hperim;
+    if (o) { // columns of the geometry block (shape.rs:116-127), rounded once
+        o[0] = (float)area;
+        o[5] = (float)perim;
+        o[6] = (float)eq_perim;
+        o[7] = (float)compacity;
+        o[9] = (float)harea;
+        o[10] = (float)deviation;
+        o[11] = (float)hperim;
+    }
+    if (o64) { // nfx_polygon_features_f64: the same seven values at geometric_features' own width
+        o64[0] = area; o64[1] = perim; o64[2] = eq_perim; o64[3] = compacity; o64[4] = harea; o64[5] = deviation; o64[6] = hperim;
+    }
 }
 
 static constexpr int PG_CAPV = 2432; // vertices of one wave's 64 rings kept in LDS (38 per ring on average)
 
 __global__ __launch_bounds__(64) void k_polygon(int64_t n, const uint32_t *__restrict__ poly_off,
                                                 const float *__restrict__ poly_xy, uint32_t *__restrict__ scratch,
-                                                float *__restrict__ out, int F, int col0)
+                                                float *__restrict__ out, int F, int col0, double *__restrict__ out64)
 {
     // The sort and the hull walk are chains of dependent vertex reads.  From global memory (L1/L2) each link costs a few
     // hundred cycles; the rings of the wave's 64 nuclei are therefore copied once into LDS, packed back to back (a wave
@@ -516,35 +525,36 @@ __global__ __launch_bounds__(64) void k_polygon(int64_t n, const uint32_t *__res
     const int first = incl - V;
     const float2 *gv = reinterpret_cast<const float2 *>(poly_xy) + v0;
     const bool packed = __all(V <= PG_MAXV && incl <= PG_CAPV); // wave-uniform
-    float *o = out + i * (int64_t)F + col0;
+    float *o = out ? out + i * (int64_t)F + col0 : nullptr;
+    double *o64 = out64 ? out64 + i * 7 : nullptr;
     if (packed) {
         for (int k = 0; k < V; ++k) s_xy[first + k] = gv[k];
         if (!live) return;
         uint8_t *srt = s_idx + 3 * first + 8 * lane; // V sort indices, then 2V + 2 hull slots
-        polygon_one<uint8_t, const float2 *>(s_xy + first, V, srt, srt + V, o);
+        polygon_one<uint8_t, const float2 *>(s_xy + first, V, srt, srt + V, o, o64);
     } else {
         if (!live) return;
         if (V <= PG_MAXV) {
             uint8_t *srt = s_raw + lane * PG_SLICE;
-            polygon_one<uint8_t, const float2 *__restrict__>(gv, V, srt, srt + PG_MAXV, o);
+            polygon_one<uint8_t, const float2 *__restrict__>(gv, V, srt, srt + PG_MAXV, o, o64);
         } else {
             uint32_t *srt = scratch + 3 * (size_t)v0 + 4 * (size_t)i;
-            polygon_one<uint32_t, const float2 *__restrict__>(gv, V, srt, srt + V, o);
+            polygon_one<uint32_t, const float2 *__restrict__>(gv, V, srt, srt + V, o, o64);
         }
     }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------
 hipError_t launch_raster_shape(nfx_ctx *ctx, int64_t n, const uint32_t *poly_off, const float *poly_xy, int ps,
-                               uint64_t *rows_out, float *out, int F, int col0)
+                               uint64_t *rows_out, float *out, int F, int col0, int *areas_out)
 {
     if (n == 0) return hipSuccess;
     ScopedTiming t(ctx, KS_RASTER_SHAPE);
     const unsigned grid = (unsigned)((n + 3) / 4);
     if (out)
-        hipLaunchKernelGGL(k_raster_shape<true>, dim3(grid), dim3(256), 0, ctx->stream, n, poly_off, poly_xy, ps, rows_out, out, F, col0);
+        hipLaunchKernelGGL(k_raster_shape<true>, dim3(grid), dim3(256), 0, ctx->stream, n, poly_off, poly_xy, ps, rows_out, out, F, col0, areas_out);
     else
-        hipLaunchKernelGGL(k_raster_shape<false>, dim3(grid), dim3(256), 0, ctx->stream, n, poly_off, poly_xy, ps, rows_out, out, F, col0);
+        hipLaunchKernelGGL(k_raster_shape<false>, dim3(grid), dim3(256), 0, ctx->stream, n, poly_off, poly_xy, ps, rows_out, out, F, col0, areas_out);
     return hipGetLastError();
 }
 
@@ -557,12 +567,12 @@ hipError_t launch_shape_from_rows(nfx_ctx *ctx, int64_t n, const uint64_t *rows,
 }
 
 hipError_t launch_polygon(nfx_ctx *ctx, int64_t n, const uint32_t *poly_off, const float *poly_xy, void *scratch,
-                          float *out, int F, int col0)
+                          float *out, int F, int col0, double *out64)
 {
     if (n == 0) return hipSuccess;
     ScopedTiming t(ctx, KS_POLYGON);
     hipLaunchKernelGGL(k_polygon, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, n, poly_off, poly_xy,
-                       reinterpret_cast<uint32_t *>(scratch), out, F, col0);
+                       reinterpret_cast<uint32_t *>(scratch), out, F, col0, out64);
     return hipGetLastError();
 }
 

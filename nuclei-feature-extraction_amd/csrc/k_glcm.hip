@@ -34,8 +34,9 @@
 //   * the marginal histogram p_x is filled per PIXEL (degree = number of pairs the pixel is in) and only at the
 //     finest nested level; sum s n_s and sum s^2 n_s come out of the sum histogram when it is folded; the
 //     remaining power sums (d, d^2 with d=|a-b|), 1/(1+d^2) and the rank terms are per pair.
-// The ten sums of every (level, offset) combination go to a scratch array; k_glcm_finish evaluates the 14
-// features with one lane per combination.
+// The ten sums of every (level, offset) combination are parked in a 1280-byte slot the wave owns in global memory (one
+// slot per resident wave: 14 MB in all, rewritten for every nucleus, so it lives in the XCD's L2 and never travels to
+// HBM); after the fourth offset sixteen lanes read them back and evaluate the 14 features of their combination.
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -93,22 +94,6 @@ static __device__ __forceinline__ float gray_at(const T *pp, int P, int p)
     return gs / 3.0f; // texture.rs:36
 }
 
-// ---- per-pair update -----------------------------------------------------------------------------------
-// Everything of a pair that does not need the marginal histogram: sum histogram, the four power sums, idm, and the
-// rank terms.  The entropy term is a table look-up by rank; its index is handed back so the load can be issued one
-// loop iteration later, off the LDS dependency chain.
-static __device__ __forceinline__ unsigned pair_sums(unsigned a, unsigned b, unsigned rk, unsigned *hs, LevelAcc &A)
-{
-    const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
-    atomicAdd(&hs[a + b], 1u);
-    const unsigned s = a + b, d = hi - lo;
-    A.S1 += s; A.S2 += s * s; A.D1 += d; A.D2 += d * d;
-    A.idm += __builtin_amdgcn_rcpf(1.0f + (float)(d * d)); // 1/(1+d^2), 1 ulp
-    const bool diag = lo == hi;
-    A.asmn += (diag ? 4u : 2u) * (2u * rk + 1u);
-    return (diag ? (unsigned)GL_RANKS : 0u) + rk; // index into [dO | dD]
-}
-
 // hash key of the unordered cell {a, b}: at most 0xFDFD, below the dummy (0xFFFE) and empty (0xFFFF) keys
 static __device__ __forceinline__ unsigned cell_key(unsigned a, unsigned b)
 {
@@ -120,13 +105,6 @@ static __device__ __forceinline__ unsigned tri_index(unsigned a, unsigned b)
 {
     const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
     return hi * (hi + 1u) / 2u + lo;
-}
-
-// dense triangular table of packed 16-bit counters: returns the pair's rank in its cell
-static __device__ __forceinline__ unsigned dense_rank(unsigned *tab, unsigned idx)
-{
-    const unsigned sh = (idx & 1u) * 16u;
-    return (atomicAdd(&tab[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
 }
 
 // open-addressing hash tables hold one word per cell: key << 16 | count.
@@ -265,17 +243,13 @@ static __device__ __forceinline__ void sweep(unsigned *tab, int words, unsigned 
     for (int k = lane; k < words / 4; k += 64) t4[k] = v;
 }
 
-// histogram counts never leave the x ln x table (GL_COUNTS): no clamp, no fallback
-static __device__ __forceinline__ double xlnx_of(const GlcmLuts *__restrict__, unsigned, double fetched) { return fetched; }
-static __device__ __forceinline__ unsigned lut_slot(unsigned v) { return v; }
-
 // ---- mask-size classes ---------------------------------------------------------------------------------------
 // One list of nucleus indices per hash capacity, filled by k_glcm_classify (order inside a list is irrelevant).
 static constexpr int GL_CLASSES = 4;
 static __device__ __host__ __forceinline__ int glcm_class(int K) { return K <= 512 ? 0 : K <= 1024 ? 1 : K <= 2048 ? 2 : 3; }
 
-__global__ __launch_bounds__(256) void k_glcm_classify(int64_t n, int ps, const uint64_t *__restrict__ mask_rows, int *__restrict__ lists,
-                                                       int *__restrict__ counts)
+__global__ __launch_bounds__(256) void k_glcm_classify(int64_t n, int ps, const uint64_t *__restrict__ mask_rows, const int *__restrict__ areas,
+                                                       int *__restrict__ lists, int *__restrict__ counts)
 {
     // sixteen lanes per nucleus, four nuclei per lane group: 64 nuclei per block.  List slots are handed out inside the
     // block (LDS), so the four global counters see one atomic per block and class, not one per nucleus.
@@ -289,9 +263,13 @@ __global__ __launch_bounds__(256) void k_glcm_classify(int64_t n, int ps, const 
     for (int u = 0; u < PER_GROUP; ++u) {
         const int64_t i = ((int64_t)blockIdx.x * 16 + group) * PER_GROUP + u;
         int K = 0;
-        if (i < n)
-            for (int r = sub; r < ps; r += 16) K += __popcll(mask_rows[i * ps + r]);
-        K += __shfl_xor(K, 1, 64); K += __shfl_xor(K, 2, 64); K += __shfl_xor(K, 4, 64); K += __shfl_xor(K, 8, 64);
+        if (areas) {
+            if (i < n) K = areas[i]; // the rasteriser's count (all sixteen lanes read the same word)
+        } else {
+            if (i < n)
+                for (int r = sub; r < ps; r += 16) K += __popcll(mask_rows[i * ps + r]);
+            K += __shfl_xor(K, 1, 64); K += __shfl_xor(K, 2, 64); K += __shfl_xor(K, 4, 64); K += __shfl_xor(K, 8, 64);
+        }
         cls[u] = glcm_class(K);
         rank[u] = (i < n && sub == 0) ? atomicAdd(&s_cnt[cls[u]], 1) : 0;
     }
@@ -305,13 +283,66 @@ __global__ __launch_bounds__(256) void k_glcm_classify(int64_t n, int ps, const 
     }
 }
 
+// The 14 Haralick features of one (level, offset) combination from its ten sums; one lane per combination.
+// dbg (test hook, nfx_debug_texture_counts): the six exact integers among the sums.
+static __device__ void glcm_features(const double (&a)[GL_NACC], const GlcmLuts *__restrict__ lut, float *__restrict__ o, int64_t *__restrict__ dbg)
+{
+    const double N = a[0], S1 = a[1], S2 = a[2], D1 = a[3], D2 = a[4], IDM = a[5], ASMN = a[6], ENTS = a[7], HXS = a[8], HSS = a[9];
+    if (dbg) {
+        dbg[0] = (int64_t)N; dbg[1] = (int64_t)S1; dbg[2] = (int64_t)S2; dbg[3] = (int64_t)D1; dbg[4] = (int64_t)D2; dbg[5] = (int64_t)ASMN;
+    }
+    if (N == 0.0) {
+        const float qnan = __builtin_nanf("");
+#pragma unroll
+        for (int k = 0; k < 14; ++k) o[k] = qnan;
+        return;
+    }
+    const double T2 = 2.0 * N;
+    const double mu = S1 / T2;
+    const double ei2 = (S2 + D2) / (4.0 * N);
+    const double var = ei2 - mu * mu;
+    const double eij = (S2 - D2) / (4.0 * N);
+    const double con = D2 / N, dis = D1 / N, sa = S1 / N;
+    const double sv = S2 / N - sa * sa;
+    // All pairs in one (diagonal) cell -- a flat nucleus -- is known exactly: sum G^2 == (sum G)^2 in integers.  The three
+    // entropies are then exactly 0, as a sum over cells finds them; the closed forms below would leave ln T - (T ln T)/T,
+    // a rounding residue, and information_measure_correlation1 = 0/0 must come out NaN, not residue/residue.
+    const bool one_cell = ASMN == T2 * T2;
+    // ln of the two integers from the x ln x table (N <= 4032 pairs): two loads instead of two f64 logarithm expansions,
+    // whose registers this spot of the kernel does not have
+    const double lnT = lut->xlnx[(int)T2] / T2;
+    const double se = one_cell ? 0.0 : lut->xlnx[(int)N] / N - HSS / N;
+    const double ent = one_cell ? 0.0 : lnT - ENTS / T2;
+    const double asm_ = ASMN / (T2 * T2);
+    const double dv = D2 / N - dis * dis;
+    const double hx = one_cell ? 0.0 : lnT - HXS / T2;
+    const double hxy1 = 2.0 * hx; // = HXY2 for a symmetric matrix (marginalisation)
+    double a2 = 1.0 - exp(-2.0 * (hxy1 - ent));
+    a2 = a2 > 0.0 ? a2 : 0.0;
+    o[0] = (float)((eij - mu * mu) / var);
+    o[1] = (float)con;
+    o[2] = (float)dis;
+    o[3] = (float)ent;
+    o[4] = (float)asm_;
+    o[5] = (float)sa;
+    o[6] = (float)sv;
+    o[7] = (float)se;
+    o[8] = (float)var;
+    o[9] = (float)(IDM / N);
+    o[10] = (float)dis;
+    o[11] = (float)dv;
+    o[12] = (float)((ent - hxy1) / hx);
+    o[13] = (float)sqrt(a2);
+}
+
 // ---- the kernel -------------------------------------------------------------------------------------------
 // LOG2SLOTS: size class; serves the nuclei of its class list (K <= 2^LOG2SLOTS / 2 mask pixels).
 // NPRE: 16-byte pieces of a u8 patch per lane (3 ps^2 / 1024 rounded up: 3, 7 or 12 for ps <= 32, 48, 64)
 template <typename T, int LOG2SLOTS, int NPRE>
 __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : (LOG2SLOTS <= 12 ? 2 : 1))) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int ps,
                                              const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
-                                             const GlcmLuts *__restrict__ lut, double *__restrict__ sums)
+                                             const GlcmLuts *__restrict__ lut, double *__restrict__ slots, float *__restrict__ out, int F,
+                                             int col0, int64_t *__restrict__ dbg)
 {
     // hash slots per list entry: 11/8 -- the 1.3-10 KB of LDS saved against 2 buy another wave per CU (11, 8, 5 and 3
     // instead of 10, 7, 4 and 2) -- except in the first class of 64x64 patches, whose table memory doubles as the staging
@@ -328,7 +359,7 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : (LOG2SLOT
     __shared__ unsigned char s_memo[QCAP + 64];
     unsigned *const s_tab = s_mem, *const s_hist = s_mem + TAB_WORDS;
 
-    const int lane = threadIdx.x;
+    int lane = threadIdx.x;
     const int P = ps * ps;
     const int cnt = *count;
     int j = blockIdx.x;
@@ -357,15 +388,44 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : (LOG2SLOT
     if (lane < 2) s_rows1[lane ? ps + 1 : 0] = 0ull;
     if (lane < 2) s_rowstart[64 + lane] = 0;
 
+    double *const slot = slots + (size_t)blockIdx.x * 16 * GL_NACC; // this wave's parking slot: [offset][level][GL_NACC]
+    int64_t i_done = -1; // the nucleus whose sums sit in the slot, features not yet evaluated
 #pragma unroll 1
-    for (; j < cnt; j += gridDim.x) {
+    for (;; j += gridDim.x) {
+        const bool more = j < cnt; // wave-uniform
         const int64_t i = i_next;
         const uint64_t myrow = row_next;
-        if (stage) {
+        if (more && stage) {
             u32x4 *dst = reinterpret_cast<u32x4 *>(s_mem);
 #pragma unroll
             for (int k = 0; k < NPRE; ++k) dst[lane + 64 * k] = pre[k]; // s_mem holds NPRE KiB: pieces past the patch land in table memory that is swept below
         }
+        // ---- the 14 features of the PREVIOUS nucleus's 16 combinations (texture.rs:81-157 order: level-major, then offset) ----
+        // evaluated here, between putting down this nucleus's patch and requesting the next one's: the only point of the loop
+        // where the prefetch registers are dead, so the f64 logarithms do not push the kernel over its register budget.
+        // The slot was written by other lanes of this wave: the stores have to be complete (release = s_waitcnt vmcnt(0)) and
+        // the loads must not be served from a line the CU's L1 kept from an earlier nucleus (agent-scope loads bypass L1);
+        // this nucleus's first slot store comes two passes later, after the loads' data has been used.
+        __builtin_amdgcn_sched_barrier(0); // the patch pieces are put down before, the next request is issued after: not across
+        // every lane-derived address and constant of the nucleus below is recomputed per nucleus (a handful of instructions)
+        // instead of sitting in ~100 hoisted registers across this point
+        asm volatile("" : "+v"(lane));
+        if (i_done >= 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 16) {
+                const int lvl = lane >> 2, oi = lane & 3;
+                const double *src = slot + (oi * 4 + lvl) * GL_NACC;
+                double a[GL_NACC];
+#pragma unroll
+                for (int k = 0; k < GL_NACC; ++k)
+                    a[k] = __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long *>(src) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                glcm_features(a, lut, out + i_done * (int64_t)F + col0 + lane * 14, dbg ? dbg + (i_done * 16 + lane) * 6 : nullptr);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!more) break;
+        i_done = i;
         if (j + (int)gridDim.x < cnt) {
             i_next = list[j + gridDim.x];
             NFX_GLCM_REQUEST(i_next);
@@ -412,8 +472,6 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : (LOG2SLOT
         wave_lds_fence();
         sweep(s_hist, GL_HIST_WORDS, 0u, lane);
         if (lane < 8) s_dummy[lane] = GL_DUMMY;
-        double *sums_i = sums + i * 16 * GL_NACC; // [offset][level][GL_NACC]
-
 #pragma unroll 1
         for (int oi = 0; oi < 4; ++oi) {
             const int dy = kGlcmOffsets[oi][0], dx = kGlcmOffsets[oi][1];
@@ -479,20 +537,20 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : (LOG2SLOT
                 const unsigned n64 = h2.x + h2.y;                       // hx64[lane]
                 const unsigned n32 = n64 + (unsigned)__shfl_down((int)n64, 1, 64); // hx32[lane / 2] on even lanes
                 const unsigned n32e = (lane & 1) ? 0u : n32;
-                const double f0 = lut->xlnx[lut_slot(h2.x)], f1 = lut->xlnx[lut_slot(h2.y)];
-                const double f64_ = lut->xlnx[lut_slot(n64)], f32_ = lut->xlnx[lut_slot(n32e)];
+                const double f0 = lut->xlnx[h2.x], f1 = lut->xlnx[h2.y];
+                const double f64_ = lut->xlnx[n64], f32_ = lut->xlnx[n32e];
                 double fs[7];
 #pragma unroll
-                for (int m = 0; m < 7; ++m) fs[m] = lut->xlnx[lut_slot(hv[m])];
+                for (int m = 0; m < 7; ++m) fs[m] = lut->xlnx[hv[m]];
                 sweep(s_hist, 576, 0u, lane);
                 sweep(s_tab, TAB_WORDS, GL_EMPTY, lane); // pass B's hash table is the WHOLE table memory (d32, d64 and h128 are
                                                           // done): 2.3-2.7 slots per entry, so fewer searches need a second probe
                                                           // and the wave's iteration -- as slow as its unluckiest key -- ends sooner
-                const double hx128 = xlnx_of(lut, h2.x, f0) + xlnx_of(lut, h2.y, f1);
-                const double hx64 = xlnx_of(lut, n64, f64_), hx32 = xlnx_of(lut, n32e, f32_);
+                const double hx128 = f0 + f1;
+                const double hx64 = f64_, hx32 = f32_;
                 double e[7];
 #pragma unroll
-                for (int m = 0; m < 7; ++m) e[m] = xlnx_of(lut, hv[m], fs[m]);
+                for (int m = 0; m < 7; ++m) e[m] = fs[m];
                 const double hs32 = e[0], hs64 = e[1] + e[2], hs128 = (e[3] + e[4]) + (e[5] + e[6]);
                 {   // sum s n_s and sum s^2 n_s: word 128 + lane + 64 m holds n_s of s = lane (level 32), lane + 64 (m - 1), lane + 64 (m - 3)
                     const unsigned s0 = (unsigned)lane, s1 = s0 + 64u, s2 = s0 + 128u, s3 = s0 + 192u;
@@ -554,11 +612,11 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : (LOG2SLOT
                 for (int m = 0; m < 12; ++m) hv[m] = s_hist[lane + 64 * m];
                 double fs[12];
 #pragma unroll
-                for (int m = 0; m < 12; ++m) fs[m] = lut->xlnx[lut_slot(hv[m])];
+                for (int m = 0; m < 12; ++m) fs[m] = lut->xlnx[hv[m]];
                 sweep(s_hist, GL_HIST_WORDS, 0u, lane);
                 double e[12];
 #pragma unroll
-                for (int m = 0; m < 12; ++m) e[m] = xlnx_of(lut, hv[m], fs[m]);
+                for (int m = 0; m < 12; ++m) e[m] = fs[m];
                 A3.S1 = 0u; A3.S2 = 0u;
 #pragma unroll
                 for (int m = 4; m < 12; ++m) { const unsigned sv = (unsigned)lane + 64u * (unsigned)(m - 4); A3.S1 += sv * hv[m]; A3.S2 += sv * sv * hv[m]; }
@@ -579,73 +637,23 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : (LOG2SLOT
             }
             wave_lds_fence();
             // lane-0 stores straight to memory would touch five partial lines per combination
-            if (lane < 4 * GL_NACC) sums_i[oi * 4 * GL_NACC + lane] = s_sums[lane];
+            if (lane < 4 * GL_NACC) slot[oi * 4 * GL_NACC + lane] = s_sums[lane];
         }
     }
 }
 
-// One lane per (nucleus, level, offset): the 14 Haralick features from the ten sums.
-__global__ __launch_bounds__(256) void k_glcm_finish(int64_t n, const double *__restrict__ sums, float *__restrict__ out, int F, int col0)
-{
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= n * 16) return;
-    const int64_t i = g >> 4;
-    const int comb_idx = (int)(g & 15);
-    const double *a = sums + (i * 16 + (comb_idx & 3) * 4 + (comb_idx >> 2)) * GL_NACC; // stored [offset][level]
-    const double N = a[0], S1 = a[1], S2 = a[2], D1 = a[3], D2 = a[4], IDM = a[5], ASMN = a[6], ENTS = a[7], HXS = a[8], HSS = a[9];
-    float *o = out + i * (int64_t)F + col0 + comb_idx * 14;
-    if (N == 0.0) {
-        const float qnan = __builtin_nanf("");
-#pragma unroll
-        for (int k = 0; k < 14; ++k) o[k] = qnan;
-        return;
-    }
-    const double T2 = 2.0 * N;
-    const double mu = S1 / T2;
-    const double ei2 = (S2 + D2) / (4.0 * N);
-    const double var = ei2 - mu * mu;
-    const double eij = (S2 - D2) / (4.0 * N);
-    const double con = D2 / N, dis = D1 / N, sa = S1 / N;
-    const double sv = S2 / N - sa * sa;
-    // All pairs in one (diagonal) cell -- a flat nucleus -- is known exactly: sum G^2 == (sum G)^2 in integers.  The three
-    // entropies are then exactly 0, as a sum over cells finds them; the closed forms below would leave ln T - (T ln T)/T,
-    // a rounding residue, and information_measure_correlation1 = 0/0 must come out NaN, not residue/residue.
-    const bool one_cell = ASMN == T2 * T2;
-    const double lnT = log(T2);
-    const double se = one_cell ? 0.0 : log(N) - HSS / N;
-    const double ent = one_cell ? 0.0 : lnT - ENTS / T2;
-    const double asm_ = ASMN / (T2 * T2);
-    const double dv = D2 / N - dis * dis;
-    const double hx = one_cell ? 0.0 : lnT - HXS / T2;
-    const double hxy1 = 2.0 * hx; // = HXY2 for a symmetric matrix (marginalisation)
-    double a2 = 1.0 - exp(-2.0 * (hxy1 - ent));
-    a2 = a2 > 0.0 ? a2 : 0.0;
-    o[0] = (float)((eij - mu * mu) / var);
-    o[1] = (float)con;
-    o[2] = (float)dis;
-    o[3] = (float)ent;
-    o[4] = (float)asm_;
-    o[5] = (float)sa;
-    o[6] = (float)sv;
-    o[7] = (float)se;
-    o[8] = (float)var;
-    o[9] = (float)(IDM / N);
-    o[10] = (float)dis;
-    o[11] = (float)dv;
-    o[12] = (float)((ent - hxy1) / hx);
-    o[13] = (float)sqrt(a2);
-}
-
-static size_t glcm_sums_bytes(int64_t n) { return sizeof(double) * 16 * GL_NACC * (size_t)(n > 0 ? n : 1); }
+static constexpr int GL_MAX_GRID = 256 * 11 * 4; // resident single-wave workgroups of the largest launch = parking slots
+static size_t glcm_slots_bytes() { return sizeof(double) * 16 * GL_NACC * (size_t)GL_MAX_GRID; }
 size_t glcm_scratch_bytes(const Job &job)
 {
     const size_t n = (size_t)(job.n > 0 ? job.n : 1);
-    return glcm_sums_bytes(job.n) + sizeof(int) * (GL_CLASSES * n + 64);
+    return glcm_slots_bytes() + sizeof(int) * (GL_CLASSES * n + 64);
 }
 
-static hipError_t ensure_luts(nfx_ctx *ctx)
+hipError_t prepare_glcm(nfx_ctx *ctx)
 {
     if (ctx->glcm_lut) return hipSuccess;
+    if (ctx->reserved || stream_capturing(ctx)) return hipErrorNotReady; // tables are built by nfx_ctx_reserve or before a capture
     std::vector<double> h(2 * GL_RANKS + GL_COUNTS);
     auto xl = [](double x) { return x > 0.0 ? x * std::log(x) : 0.0; };
     for (int k = 0; k < GL_RANKS; ++k) {
@@ -654,46 +662,53 @@ static hipError_t ensure_luts(nfx_ctx *ctx)
     }
     for (int k = 0; k < GL_COUNTS; ++k) h[2 * GL_RANKS + k] = xl((double)k); // x ln x
     static_assert(sizeof(GlcmLuts) == sizeof(double) * (2 * GL_RANKS + GL_COUNTS), "table layout");
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->glcm_lut), sizeof(double) * h.size());
+    double *d = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), sizeof(double) * h.size());
     if (e != hipSuccess) return e;
-    return hipMemcpy(ctx->glcm_lut, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
+    e = hipMemcpy(d, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return e; }
+    ctx->glcm_lut = d; // published only once it is complete
+    return hipSuccess;
 }
 
 template <typename T, int NPRE>
-static void launch_classes(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *sums, const int *lists, const int *counts)
+static void launch_classes(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *slots, const int *lists, const int *counts, int col0)
 {
     const T *p = reinterpret_cast<const T *>(job.patches);
     const int P = job.ps * job.ps;
     auto grid = [&](int wgs_per_cu) { const int64_t m = 256ll * wgs_per_cu * 4; return (unsigned)(job.n < m ? job.n : m); };
+    static_assert(256 * 11 * 4 <= GL_MAX_GRID, "every launch's waves have a parking slot");
     // Smaller classes keep more nuclei in flight per CU (15-16 KB of LDS per wave for masks up to 512 pixels, 20 KB up
     // to 1024, 31 KB up to 2048, 53 KB up to 4096).  Blocks beyond a list's length exit at once.
     const int64_t n = job.n;
-    hipLaunchKernelGGL((k_glcm<T, 10, NPRE>), dim3(grid(NPRE <= 7 ? 11 : 10)), dim3(64), 0, ctx->stream, lists + 0 * n, counts + 0, job.ps, p, job.mask_rows, lut, sums);
-    if (P > 512) hipLaunchKernelGGL((k_glcm<T, 11, NPRE>), dim3(grid(8)), dim3(64), 0, ctx->stream, lists + 1 * n, counts + 1, job.ps, p, job.mask_rows, lut, sums);
-    if (P > 1024) hipLaunchKernelGGL((k_glcm<T, 12, NPRE>), dim3(grid(5)), dim3(64), 0, ctx->stream, lists + 2 * n, counts + 2, job.ps, p, job.mask_rows, lut, sums);
-    if (P > 2048) hipLaunchKernelGGL((k_glcm<T, 13, NPRE>), dim3(grid(3)), dim3(64), 0, ctx->stream, lists + 3 * n, counts + 3, job.ps, p, job.mask_rows, lut, sums);
+#define NFX_GLCM_LAUNCH(LOG2, WGS, CLS)                                                                                        \
+    hipLaunchKernelGGL((k_glcm<T, LOG2, NPRE>), dim3(grid(WGS)), dim3(64), 0, ctx->stream, lists + CLS * n, counts + CLS, job.ps, p, \
+                       job.mask_rows, lut, slots, job.out, job.F, col0, job.dbg_glcm)
+    NFX_GLCM_LAUNCH(10, (NPRE <= 7 ? 11 : 10), 0);
+    if (P > 512) NFX_GLCM_LAUNCH(11, 8, 1);
+    if (P > 1024) NFX_GLCM_LAUNCH(12, 5, 2);
+    if (P > 2048) NFX_GLCM_LAUNCH(13, 3, 3);
+#undef NFX_GLCM_LAUNCH
 }
 
 hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
 {
     if (job.n == 0) return hipSuccess;
     if (job.n > 0x7FFFFFFFll) return hipErrorInvalidValue; // class lists hold 32-bit nucleus indices
-    hipError_t e = ensure_luts(ctx);
+    hipError_t e = prepare_glcm(ctx);
     if (e != hipSuccess) return e;
     ScopedTiming t(ctx, KS_GLCM);
-    double *sums = reinterpret_cast<double *>(scratch);
-    int *lists = reinterpret_cast<int *>(reinterpret_cast<char *>(scratch) + glcm_sums_bytes(job.n));
+    double *slots = reinterpret_cast<double *>(scratch);
+    int *lists = reinterpret_cast<int *>(reinterpret_cast<char *>(scratch) + glcm_slots_bytes());
     int *counts = lists + GL_CLASSES * job.n;
     const GlcmLuts *lut = reinterpret_cast<const GlcmLuts *>(ctx->glcm_lut);
     e = hipMemsetAsync(counts, 0, sizeof(int) * GL_CLASSES, ctx->stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_glcm_classify, dim3((unsigned)((job.n + 63) / 64)), dim3(256), 0, ctx->stream, job.n, job.ps, job.mask_rows, lists, counts);
-    if (job.patches_f32) launch_classes<float, 1>(ctx, job, lut, sums, lists, counts);
-    else if (job.ps <= 32) launch_classes<uint8_t, 3>(ctx, job, lut, sums, lists, counts);
-    else if (job.ps <= 48) launch_classes<uint8_t, 7>(ctx, job, lut, sums, lists, counts);
-    else launch_classes<uint8_t, 12>(ctx, job, lut, sums, lists, counts);
-    const int64_t items = job.n * 16;
-    hipLaunchKernelGGL(k_glcm_finish, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, ctx->stream, job.n, sums, job.out, job.F, col0);
+    hipLaunchKernelGGL(k_glcm_classify, dim3((unsigned)((job.n + 63) / 64)), dim3(256), 0, ctx->stream, job.n, job.ps, job.mask_rows, job.areas, lists, counts);
+    if (job.patches_f32) launch_classes<float, 1>(ctx, job, lut, slots, lists, counts, col0);
+    else if (job.ps <= 32) launch_classes<uint8_t, 3>(ctx, job, lut, slots, lists, counts, col0);
+    else if (job.ps <= 48) launch_classes<uint8_t, 7>(ctx, job, lut, slots, lists, counts, col0);
+    else launch_classes<uint8_t, 12>(ctx, job, lut, slots, lists, counts, col0);
     return hipGetLastError();
 }
 

@@ -56,7 +56,7 @@ static __device__ __forceinline__ unsigned eq16(const unsigned (&a)[4], unsigned
 template <typename T>
 __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__restrict__ patches,
                                               const uint64_t *__restrict__ mask_rows, float *__restrict__ out, int F,
-                                              int col0)
+                                              int col0, uint32_t *__restrict__ dbg_bins)
 {
     constexpr int QS = 68; // byte-map row stride: lane = row reads of one column spread over the banks
     __shared__ uint8_t s_q_all[4][NFX_MAX_PATCH_SIZE * QS];
@@ -282,8 +282,10 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
             double srmge = 0, lrmge = 0, srege = 0, lrege = 0, rlm = 0, gln = 0, colsum = 0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                const double v = (double)s_R[lane + 64 * k];
+                const unsigned bin = s_R[lane + 64 * k];
+                const double v = (double)bin;
                 s_R[lane + 64 * k] = 0u;
+                if (dbg_bins) dbg_bins[(i * 4 + d) * RL_BINS + lane + 64 * k] = bin; // test hook (nfx_debug_texture_counts): [level][length]
                 nr += v;
                 const double vs = v * il2, vl = v * l2;
                 sre += vs; lre += vl;
@@ -330,10 +332,10 @@ hipError_t launch_glrlm(nfx_ctx *ctx, const Job &job, int col0)
     const unsigned grid = (unsigned)(need < maxb ? need : maxb);
     if (job.patches_f32)
         hipLaunchKernelGGL(k_glrlm<float>, dim3(grid), dim3(256), 0, ctx->stream, job.n, job.ps,
-                           reinterpret_cast<const float *>(job.patches), job.mask_rows, job.out, job.F, col0);
+                           reinterpret_cast<const float *>(job.patches), job.mask_rows, job.out, job.F, col0, job.dbg_glrlm);
     else
         hipLaunchKernelGGL(k_glrlm<uint8_t>, dim3(grid), dim3(256), 0, ctx->stream, job.n, job.ps,
-                           reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, job.out, job.F, col0);
+                           reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, job.out, job.F, col0, job.dbg_glrlm);
     return hipGetLastError();
 }
 

@@ -80,6 +80,15 @@ __global__ __launch_bounds__(256) void k_unpack_masks(int64_t nrows, const uint6
     if (lane < ps) masks[r * ps + lane] = ((w >> lane) & 1ull) ? 1.0f : 0.0f;
 }
 
+// Rust's `f32 as i64` (utils.rs:159-162): truncates, saturates, NaN -> 0 (a C cast of such values is undefined).  The result
+// is further clamped to +-2^40: no image is that large, so the window arithmetic below behaves the same and cannot overflow.
+static __device__ __forceinline__ int64_t rust_f32_as_i64(float v)
+{
+    if (v != v) return 0;
+    const float lim = 1099511627776.0f; // 2^40
+    return v >= lim ? (int64_t)1 << 40 : (v <= -lim ? -((int64_t)1 << 40) : (int64_t)v);
+}
+
 // utils.rs:159-191: top/left/bottom/right = trunc(c -/+ ps/2) as i64, clipped to the image; the
 // crop is pasted at (-min(top,0), -min(left,0)) into a zeroed [3,ps,ps] patch.
 __global__ __launch_bounds__(1024) void k_gather_patches(int64_t n, const float *__restrict__ centroids,
@@ -102,8 +111,8 @@ __global__ __launch_bounds__(1024) void k_gather_patches(int64_t n, const float 
         ox = 0;
     } else {
         // load_image_dataset, utils.rs:159-191
-        const int64_t top = (int64_t)(cy - half), left = (int64_t)(cx - half);
-        const int64_t bottom = (int64_t)(cy + half), right = (int64_t)(cx + half);
+        const int64_t top = rust_f32_as_i64(cy - half), left = rust_f32_as_i64(cx - half);
+        const int64_t bottom = rust_f32_as_i64(cy + half), right = rust_f32_as_i64(cx + half);
         t0 = top > 0 ? top : 0, l0 = left > 0 ? left : 0;
         b0 = bottom < H ? bottom : H, r0 = right < W ? right : W;
         oy = -(top < 0 ? top : 0), ox = -(left < 0 ? left : 0);

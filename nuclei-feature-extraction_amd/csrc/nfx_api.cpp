@@ -101,6 +101,15 @@ int nfx_feature_set_column_name(int set, int j, char *buf, size_t buflen)
     return (int)s.size();
 }
 
+int nfx_feature_set_column_dtype(int set, int j)
+{
+    if (set < 0 || set >= NFX_SET_COUNT || j < 0 || j >= kNumCols[set]) return -1;
+    // shape.rs:116-127: area, perimeter, equivalent_perimeter, compacity, convex_hull_area, convex_deffect, convex_perimeter
+    // are geometric_features' return values; everything else in every set was read out of an f32 tensor
+    static const bool poly[12] = {true, false, false, false, false, true, true, true, false, true, true, true};
+    return (set == NFX_SET_GEOMETRY && poly[j]) ? NFX_DTYPE_F64 : NFX_DTYPE_F32;
+}
+
 int nfx_parse_feature_sets(const char *const *names, int n_names, int *out_sets, int cap)
 {
     int m = 0;
@@ -152,12 +161,18 @@ static nfx_status fail(nfx_ctx *ctx, nfx_status st, const std::string &msg)
 
 namespace nfx {
 
-bool ws_reserve(nfx_ctx *ctx, size_t bytes)
+bool stream_capturing(nfx_ctx *ctx)
 {
-    ctx->ws_off = 0;
-    if (bytes <= ctx->ws_cap) return true;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+
+static nfx_status ws_grow(nfx_ctx *ctx, size_t bytes)
+{
     if (ctx->ws) {
         (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
         (void)hipFree(ctx->ws);
         ctx->ws = nullptr;
         ctx->ws_cap = 0;
@@ -165,10 +180,31 @@ bool ws_reserve(nfx_ctx *ctx, size_t bytes)
     const size_t cap = bytes + (bytes >> 3) + (1u << 20);
     if (hipMalloc(reinterpret_cast<void **>(&ctx->ws), cap) != hipSuccess) {
         (void)hipGetLastError();
-        return false;
+        ctx->err = "device workspace: out of memory";
+        return NFX_ERR_OUT_OF_MEMORY;
     }
     ctx->ws_cap = cap;
-    return true;
+    return NFX_OK;
+}
+
+nfx_status ws_reserve(nfx_ctx *ctx, size_t bytes, nfx_mem mem)
+{
+    ctx->ws_off = 0;
+    if (bytes <= ctx->ws_cap) return NFX_OK;
+    if (mem == NFX_MEM_DEVICE) {
+        // stream-ordered calls promise not to synchronise or allocate (nfx.h): honoured strictly once the caller has made a
+        // reservation, and always during a capture (a hipMalloc there would invalidate the capture anyway)
+        if (ctx->reserved) {
+            ctx->err = "device-memory call exceeds the context's reservation (" + std::to_string(bytes) + " > " + std::to_string(ctx->ws_cap) +
+                       " bytes): call nfx_ctx_reserve for this shape first";
+            return NFX_ERR_OUT_OF_MEMORY;
+        }
+        if (stream_capturing(ctx)) {
+            ctx->err = "device-memory call during stream capture needs a workspace that is not there yet: call nfx_ctx_reserve before capturing";
+            return NFX_ERR_INVALID_ARGUMENT;
+        }
+    }
+    return ws_grow(ctx, bytes);
 }
 
 static size_t al(size_t b) { return (b + 255) & ~size_t(255); }
@@ -333,6 +369,16 @@ static nfx_status check_common(nfx_ctx *ctx, int64_t n, int64_t nv, int ps)
     return NFX_OK;
 }
 
+// host-memory offsets are validated before anything is launched: the kernels index the vertex array with them
+static nfx_status check_offsets(nfx_ctx *ctx, const uint32_t *off, int64_t n, int64_t nv, const char *what)
+{
+    if (off[0] != 0u) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, std::string(what) + "[0] != 0");
+    for (int64_t i = 0; i < n; ++i)
+        if (off[i + 1] < off[i]) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, std::string(what) + " is not non-decreasing at " + std::to_string(i + 1));
+    if (off[n] != (uint32_t)nv) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, std::string(what) + "[n] != n_vertices");
+    return NFX_OK;
+}
+
 // A synchronous (host-memory) call runs on the context's own stream.  It first waits for whatever the caller still has in
 // flight on the device-call stream: both kinds of call share the context's workspace.
 struct StreamScope {
@@ -365,14 +411,14 @@ static bool any_pixel_set(const int *sets, int n_sets)
     return false;
 }
 
-static bool has_set(const int *sets, int n_sets, int which)
+static int count_set(const int *sets, int n_sets, int which)
 {
-    for (int s = 0; s < n_sets; ++s)
-        if (sets[s] == which) return true;
-    return false;
+    int c = 0;
+    for (int s = 0; s < n_sets; ++s) c += sets[s] == which;
+    return c;
 }
 
-// workspace bytes needed by extract_device (excluding host staging)
+// workspace bytes needed by extract_device (excluding host staging): mirrors its ws_alloc calls one for one
 static size_t extract_ws_bytes(const int *sets, int n_sets, int64_t n, int64_t nv, int ps, int batch_size, bool need_centroids,
                                bool gather)
 {
@@ -380,23 +426,27 @@ static size_t extract_ws_bytes(const int *sets, int n_sets, int64_t n, int64_t n
     b += al(sizeof(float) * 2 * (size_t)nv);                     // centred polygons
     if (need_centroids) b += al(sizeof(float) * 2 * (size_t)n);
     if (any_pixel_set(sets, n_sets)) b += al(sizeof(uint64_t) * (size_t)n * ps);
-    if (has_set(sets, n_sets, NFX_SET_GEOMETRY)) b += al(polygon_scratch_bytes(n, nv));
+    if (count_set(sets, n_sets, NFX_SET_GLCM)) b += al(sizeof(int) * (size_t)n); // mask areas
+    if (count_set(sets, n_sets, NFX_SET_GEOMETRY)) b += al(polygon_scratch_bytes(n, nv));
     if (gather) b += al((size_t)n * 3 * ps * ps);
-    if (has_set(sets, n_sets, NFX_SET_COLOR)) {
-        Job j; j.n = n; j.ps = ps; j.batch_size = batch_size;
-        b += al(color_scratch_bytes(j));
-    }
-    if (has_set(sets, n_sets, NFX_SET_GLCM)) {
-        Job j; j.n = n; j.ps = ps;
-        b += al(glcm_scratch_bytes(j));
-    }
+    Job j; j.n = n; j.ps = ps; j.batch_size = batch_size;
+    b += (size_t)count_set(sets, n_sets, NFX_SET_COLOR) * al(color_scratch_bytes(j)); // a repeated "color" gets scratch of its own
+    if (count_set(sets, n_sets, NFX_SET_GLCM)) b += al(glcm_scratch_bytes(j));
     return b + 4096;
 }
 
-// everything on the device; ws already reserved
-static nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_off,
-                                 const float *ring_xy, const uint8_t *patches_u8, const uint8_t *image, int64_t H, int64_t W,
-                                 int ps, int batch_size, float *out_rows, float *out_centroids)
+static nfx_status prepare_sets(nfx_ctx *ctx, const int *sets, int n_sets)
+{
+    if (count_set(sets, n_sets, NFX_SET_COLOR)) NFX_HIP(ctx, prepare_color(ctx));
+    if (count_set(sets, n_sets, NFX_SET_GLCM)) NFX_HIP(ctx, prepare_glcm(ctx));
+    if (count_set(sets, n_sets, NFX_SET_GABOR)) NFX_HIP(ctx, prepare_gabor(ctx));
+    return NFX_OK;
+}
+
+// everything on the device; ws already reserved.  `forked` tells the caller that the side stream holds work to be joined.
+static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_off,
+                                      const float *ring_xy, const uint8_t *patches_u8, const uint8_t *image, int64_t H, int64_t W,
+                                      int ps, int batch_size, float *out_rows, float *out_centroids, bool &forked)
 {
     const int F = sets_total_columns(sets, n_sets);
     float *centred = (float *)ws_alloc(ctx, sizeof(float) * 2 * (size_t)nv);
@@ -405,18 +455,22 @@ static nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int6
     uint64_t *rows = nullptr;
     const bool pix = any_pixel_set(sets, n_sets);
     if (pix) rows = (uint64_t *)ws_alloc(ctx, sizeof(uint64_t) * (size_t)n * ps);
-    if (!centred || (pix && !rows) || (image && !centroids)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
+    int *areas = count_set(sets, n_sets, NFX_SET_GLCM) ? (int *)ws_alloc(ctx, sizeof(int) * (size_t)n) : nullptr;
+    if (!centred || (pix && !rows) || (image && !centroids) || (count_set(sets, n_sets, NFX_SET_GLCM) && !areas))
+        return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
+    // a missing table is built here, before anything is enqueued (refused on a reserved context and during capture)
+    const nfx_status pst = prepare_sets(ctx, sets, n_sets);
+    if (pst != NFX_OK) return fail(ctx, pst, "device tables of the selected sets are not built: call nfx_ctx_reserve first (" + ctx->err + ")");
 
     NFX_HIP(ctx, launch_preprocess(ctx, n, ring_off, ring_xy, centroids, centred));
-    // fork: the polygon columns only need the centred rings, and their kernel is bound by the latency of 64 serial programs
-    // per wave, not by issue slots or bandwidth -- it runs on the side stream next to everything below and is joined at the end
-    bool forked = false;
+    // fork: the polygon columns only need the centred rings; their kernel runs on the side stream next to everything below
+    // and is joined at the end of the call
     hipStream_t const main_stream = ctx->stream;
-    for (int s = 0; s < n_sets; ++s) forked = forked || sets[s] == NFX_SET_GEOMETRY;
-    forked = forked && pix; // next to the rasteriser alone (geometry only) the two f64-heavy kernels just share the issue slots: no gain
-    if (forked) {
+    const bool want_fork = count_set(sets, n_sets, NFX_SET_GEOMETRY) && pix; // next to the rasteriser alone (geometry only) the two f64-heavy kernels just share the issue slots: no gain
+    if (want_fork) {
         NFX_HIP(ctx, hipEventRecord(ctx->ev_fork, main_stream));
         NFX_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+        forked = true;
     }
     if (image && pix) {
         uint8_t *gp = (uint8_t *)ws_alloc(ctx, (size_t)n * 3 * ps * ps);
@@ -433,11 +487,11 @@ static nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int6
             col += kNumCols[sets[s]];
         }
     }
-    NFX_HIP(ctx, launch_raster_shape(ctx, n, ring_off, centred, ps, rows, geo_col >= 0 ? out_rows : nullptr, F, geo_col >= 0 ? geo_col : 0));
+    NFX_HIP(ctx, launch_raster_shape(ctx, n, ring_off, centred, ps, rows, geo_col >= 0 ? out_rows : nullptr, F, geo_col >= 0 ? geo_col : 0, areas));
 
     Job job;
     job.n = n; job.ps = ps; job.batch_size = batch_size; job.poly_off = ring_off; job.poly_xy = centred;
-    job.patches = patches_u8; job.patches_f32 = false; job.mask_rows = rows; job.out = out_rows; job.F = F;
+    job.patches = patches_u8; job.patches_f32 = false; job.mask_rows = rows; job.areas = areas; job.out = out_rows; job.F = F;
 
     int col = 0;
     bool geo_done = false;
@@ -474,11 +528,24 @@ static nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int6
         }
         col += kNumCols[sets[s]];
     }
-    if (forked) { // join
-        NFX_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
-        NFX_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
-    }
     return NFX_OK;
+}
+
+static nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_off,
+                                 const float *ring_xy, const uint8_t *patches_u8, const uint8_t *image, int64_t H, int64_t W,
+                                 int ps, int batch_size, float *out_rows, float *out_centroids)
+{
+    bool forked = false;
+    hipStream_t const main_stream = ctx->stream;
+    const nfx_status st = extract_device_body(ctx, sets, n_sets, n, nv, ring_off, ring_xy, patches_u8, image, H, W, ps, batch_size,
+                                              out_rows, out_centroids, forked);
+    ctx->stream = main_stream;
+    if (forked) { // join on every path: an error return must not leave the side stream dangling off the caller's stream (or capture)
+        const hipError_t e1 = hipEventRecord(ctx->ev_join, ctx->side_stream);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(main_stream, ctx->ev_join, 0) : e1;
+        if (st == NFX_OK && e2 != hipSuccess) return fail(ctx, NFX_ERR_DEVICE, std::string("joining the side stream: ") + hipGetErrorString(e2));
+    }
+    return st;
 }
 
 // host staging helper: copies src (host) into the workspace
@@ -490,7 +557,42 @@ static T *stage_in(nfx_ctx *ctx, const T *src, size_t count)
     return d;
 }
 
+// workspace of one trait-entry call in device memory
+static size_t trait_ws_bytes(int set, int64_t n, int64_t nv, int ps)
+{
+    Job job;
+    job.n = n; job.ps = ps; job.batch_size = (int)(n > 0 ? n : 1);
+    size_t need = al(8 * (size_t)n * ps + 8) + 4096;
+    if (set == NFX_SET_GEOMETRY) need += al(polygon_scratch_bytes(n, nv));
+    if (set == NFX_SET_COLOR) need += al(color_scratch_bytes(job));
+    if (set == NFX_SET_GLCM) need += al(glcm_scratch_bytes(job));
+    return need;
+}
+
 extern "C" {
+
+nfx_status nfx_ctx_reserve(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, int ps, int batch_size)
+{
+    nfx_status st = check_common(ctx, n, nv, ps);
+    if (st != NFX_OK) return st;
+    if (!sets || n_sets <= 0 || sets_total_columns(sets, n_sets) < 0) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "unknown feature set");
+    if (batch_size < 1) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "batch_size must be >= 1");
+    NFX_HIP(ctx, hipSetDevice(ctx->device));
+    if (stream_capturing(ctx)) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "nfx_ctx_reserve during stream capture");
+    // the largest of: the fused entries (tile variant: gathered patches + centroids), one trait-entry call per listed set,
+    // the rasteriser's private row words
+    size_t need = extract_ws_bytes(sets, n_sets, n, nv, ps, batch_size, true, any_pixel_set(sets, n_sets));
+    for (int s = 0; s < n_sets; ++s) {
+        const size_t t = trait_ws_bytes(sets[s], n, nv, ps);
+        need = t > need ? t : need;
+    }
+    const bool was = ctx->reserved;
+    ctx->reserved = false; // the builders below are the one place allowed to allocate
+    st = prepare_sets(ctx, sets, n_sets);
+    if (st == NFX_OK && need > ctx->ws_cap) st = ws_grow(ctx, need);
+    ctx->reserved = was || st == NFX_OK;
+    return st;
+}
 
 nfx_status nfx_preprocess_polygons(nfx_ctx *ctx, int64_t n, int64_t nv, const uint32_t *ring_offsets, const float *ring_xy,
                                    float *centroids_xy, float *centred_xy, nfx_mem mem)
@@ -504,8 +606,8 @@ nfx_status nfx_preprocess_polygons(nfx_ctx *ctx, int64_t n, int64_t nv, const ui
         NFX_HIP(ctx, launch_preprocess(ctx, n, ring_offsets, ring_xy, centroids_xy, centred_xy));
         return NFX_OK;
     }
-    if (ring_offsets[n] != (uint32_t)nv) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "ring_offsets[n] != n_vertices");
-    if (!ws_reserve(ctx, al(4 * (n + 1)) + 2 * al(8 * nv) + al(8 * n) + 4096)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    if ((st = check_offsets(ctx, ring_offsets, n, nv, "ring_offsets")) != NFX_OK) return st;
+    if ((st = ws_reserve(ctx, al(4 * (n + 1)) + 2 * al(8 * nv + 8) + al(8 * n + 8) + 4096, mem)) != NFX_OK) return st;
     uint32_t *d_off = stage_in(ctx, ring_offsets, (size_t)n + 1);
     float *d_xy = stage_in(ctx, ring_xy, 2 * (size_t)nv);
     float *d_cen = (float *)ws_alloc(ctx, 8 * (size_t)n + 8);
@@ -530,15 +632,16 @@ nfx_status nfx_rasterize_polygons(nfx_ctx *ctx, int64_t n, int64_t nv, const uin
     if (mem == NFX_MEM_DEVICE) {
         uint64_t *rows = mask_rows;
         if (!rows) {
-            if (!ws_reserve(ctx, al(rows_b) + 4096)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
-            rows = (uint64_t *)ws_alloc(ctx, rows_b);
+            if ((st = ws_reserve(ctx, al(rows_b + 8) + 4096, mem)) != NFX_OK) return st;
+            rows = (uint64_t *)ws_alloc(ctx, rows_b + 8);
+            if (!rows) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
         }
         NFX_HIP(ctx, launch_raster_shape(ctx, n, poly_offsets, poly_xy, ps, rows, nullptr, 0, 0));
         if (masks_f32) NFX_HIP(ctx, launch_unpack_masks(ctx, n, rows, ps, masks_f32));
         return NFX_OK;
     }
-    if (poly_offsets[n] != (uint32_t)nv) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "poly_offsets[n] != n_vertices");
-    if (!ws_reserve(ctx, al(4 * (n + 1)) + al(8 * nv) + al(rows_b) + al(mask_b) + 4096)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    if ((st = check_offsets(ctx, poly_offsets, n, nv, "poly_offsets")) != NFX_OK) return st;
+    if ((st = ws_reserve(ctx, al(4 * (n + 1)) + al(8 * nv + 8) + al(rows_b + 8) + al(mask_b + 8) + 4096, mem)) != NFX_OK) return st;
     uint32_t *d_off = stage_in(ctx, poly_offsets, (size_t)n + 1);
     float *d_xy = stage_in(ctx, poly_xy, 2 * (size_t)nv);
     uint64_t *d_rows = (uint64_t *)ws_alloc(ctx, rows_b + 8);
@@ -551,6 +654,37 @@ nfx_status nfx_rasterize_polygons(nfx_ctx *ctx, int64_t n, int64_t nv, const uin
     }
     if (mask_rows && n) NFX_HIP(ctx, hipMemcpyAsync(mask_rows, d_rows, rows_b, hipMemcpyDeviceToHost, ctx->stream));
     NFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NFX_OK;
+}
+
+nfx_status nfx_polygon_features_f64(nfx_ctx *ctx, int64_t n, int64_t nv, const uint32_t *poly_offsets, const float *poly_xy,
+                                    double *out_f64, nfx_mem mem)
+{
+    nfx_status st = check_common(ctx, n, nv, 1);
+    if (st != NFX_OK) return st;
+    if (!poly_offsets || (nv && !poly_xy) || !out_f64) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null input");
+    NFX_HIP(ctx, hipSetDevice(ctx->device));
+    StreamScope stream_scope(ctx, mem);
+    size_t need = al(polygon_scratch_bytes(n, nv)) + 4096;
+    if (mem == NFX_MEM_HOST) {
+        if ((st = check_offsets(ctx, poly_offsets, n, nv, "poly_offsets")) != NFX_OK) return st;
+        need += al(4 * (n + 1)) + al(8 * nv + 8) + al(56 * (size_t)n + 8);
+    }
+    if ((st = ws_reserve(ctx, need, mem)) != NFX_OK) return st;
+    double *d_out = out_f64;
+    if (mem == NFX_MEM_HOST) {
+        poly_offsets = stage_in(ctx, poly_offsets, (size_t)n + 1);
+        poly_xy = stage_in(ctx, poly_xy, 2 * (size_t)nv);
+        d_out = (double *)ws_alloc(ctx, 56 * (size_t)n + 8);
+        if (!poly_offsets || !poly_xy || !d_out) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    }
+    void *scr = ws_alloc(ctx, polygon_scratch_bytes(n, nv));
+    if (!scr) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    NFX_HIP(ctx, launch_polygon(ctx, n, poly_offsets, poly_xy, scr, nullptr, 0, 0, d_out));
+    if (mem == NFX_MEM_HOST) {
+        if (n) NFX_HIP(ctx, hipMemcpyAsync(out_f64, d_out, 56 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        NFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return NFX_OK;
 }
 
@@ -571,15 +705,14 @@ nfx_status nfx_compute_features_batched(nfx_ctx *ctx, int set, int64_t n, int64_
     const size_t P = (size_t)ps * ps;
     Job job;
     job.n = n; job.ps = ps; job.batch_size = (int)(n > 0 ? n : 1); job.patches_f32 = true; job.F = F;
-    size_t need = al(8 * (size_t)n * ps) + 4096;
-    if (set == NFX_SET_GEOMETRY) need += al(polygon_scratch_bytes(n, nv));
-    if (set == NFX_SET_COLOR) need += al(color_scratch_bytes(job));
-    if (set == NFX_SET_GLCM) need += al(glcm_scratch_bytes(job));
+    size_t need = trait_ws_bytes(set, n, nv, ps);
     if (mem == NFX_MEM_HOST) {
-        if (poly_offsets[n] != (uint32_t)nv) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "poly_offsets[n] != n_vertices");
-        need += al(4 * (n + 1)) + al(8 * nv) + al(4 * n * P) + al(12 * n * P) + al(4 * (size_t)n * F);
+        if ((st = check_offsets(ctx, poly_offsets, n, nv, "poly_offsets")) != NFX_OK) return st;
+        need += al(4 * (n + 1)) + al(8 * nv + 8) + al(4 * n * P + 8) + al(12 * n * P + 8) + al(4 * (size_t)n * F + 8);
     }
-    if (!ws_reserve(ctx, need)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    if ((st = ws_reserve(ctx, need, mem)) != NFX_OK) return st;
+    if ((st = prepare_sets(ctx, &set, 1)) != NFX_OK)
+        return fail(ctx, st, "device tables of this set are not built: call nfx_ctx_reserve first (" + ctx->err + ")");
     float *d_out = out;
     if (mem == NFX_MEM_HOST) {
         poly_offsets = stage_in(ctx, poly_offsets, (size_t)n + 1);
@@ -643,11 +776,11 @@ static nfx_status extract_common(nfx_ctx *ctx, const int *sets, int n_sets, int6
     const size_t P = (size_t)ps * ps;
     size_t need = extract_ws_bytes(sets, n_sets, n, nv, ps, batch_size, image && !out_centroids, image && pix);
     if (mem == NFX_MEM_HOST) {
-        if (ring_offsets[n] != (uint32_t)nv) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "ring_offsets[n] != n_vertices");
-        need += al(4 * (n + 1)) + al(8 * nv) + al(4 * (size_t)n * F) + al(8 * n);
-        if (pix) need += image ? al(3 * (size_t)H * W) : al(3 * (size_t)n * P);
+        if ((st = check_offsets(ctx, ring_offsets, n, nv, "ring_offsets")) != NFX_OK) return st;
+        need += al(4 * (n + 1)) + al(8 * nv + 8) + al(4 * (size_t)n * F + 8) + al(8 * n + 8);
+        if (pix) need += image ? al(3 * (size_t)H * W) : al(3 * (size_t)n * P + 8);
     }
-    if (!ws_reserve(ctx, need)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    if ((st = ws_reserve(ctx, need, mem)) != NFX_OK) return st;
     if (mem == NFX_MEM_DEVICE)
         return extract_device(ctx, sets, n_sets, n, nv, ring_offsets, ring_xy, patches_u8, image, H, W, ps, batch_size, out_rows, out_centroids);
 
@@ -660,7 +793,7 @@ static nfx_status extract_common(nfx_ctx *ctx, const int *sets, int n_sets, int6
     float *d_cen = (float *)ws_alloc(ctx, 8 * (size_t)n + 8);
     if (!d_off || !d_xy || (pix && !d_p && !d_img) || !d_out || !d_cen) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
     st = extract_device(ctx, sets, n_sets, n, nv, d_off, d_xy, d_p, d_img, H, W, ps, batch_size, d_out, d_cen);
-    if (st != NFX_OK) return st;
+    if (st != NFX_OK) { (void)hipStreamSynchronize(ctx->stream); return st; }
     if (n) NFX_HIP(ctx, hipMemcpyAsync(out_rows, d_out, 4 * (size_t)n * F, hipMemcpyDeviceToHost, ctx->stream));
     if (out_centroids && n) NFX_HIP(ctx, hipMemcpyAsync(out_centroids, d_cen, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     NFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -697,7 +830,7 @@ nfx_status nfx_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids_xy
         return NFX_OK;
     }
     const size_t pb = (size_t)n * 3 * ps * ps;
-    if (!ws_reserve(ctx, al(8 * n) + al(3 * (size_t)H * W) + al(pb) + 4096)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    if ((st = ws_reserve(ctx, al(8 * n + 8) + al(3 * (size_t)H * W) + al(pb + 8) + 4096, mem)) != NFX_OK) return st;
     float *d_c = stage_in(ctx, centroids_xy, 2 * (size_t)n);
     uint8_t *d_i = stage_in(ctx, image_u8, 3 * (size_t)H * W);
     uint8_t *d_p = (uint8_t *)ws_alloc(ctx, pb + 8);
@@ -705,6 +838,56 @@ nfx_status nfx_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids_xy
     NFX_HIP(ctx, launch_gather_patches(ctx, n, d_c, d_i, H, W, ps, d_p));
     if (n) NFX_HIP(ctx, hipMemcpyAsync(patches_u8, d_p, pb, hipMemcpyDeviceToHost, ctx->stream));
     NFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return NFX_OK;
+}
+
+// test hook: the integers behind the GLCM / GLRLM columns (nfx.h)
+nfx_status nfx_debug_texture_counts(nfx_ctx *ctx, int64_t n, int64_t nv, const uint32_t *ring_offsets, const float *ring_xy,
+                                    const uint8_t *patches_u8, int ps, int64_t *glcm_sums, uint32_t *glrlm_bins, nfx_mem mem)
+{
+    nfx_status st = check_common(ctx, n, nv, ps);
+    if (st != NFX_OK) return st;
+    if (!ring_offsets || (nv && !ring_xy) || !patches_u8) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null input");
+    NFX_HIP(ctx, hipSetDevice(ctx->device));
+    StreamScope stream_scope(ctx, mem);
+    const size_t P = (size_t)ps * ps;
+    const size_t gb = sizeof(int64_t) * 96 * (size_t)n, rb = sizeof(uint32_t) * 4 * 384 * (size_t)n, fb = sizeof(float) * 224 * (size_t)n;
+    Job job;
+    job.n = n; job.ps = ps; job.batch_size = 100;
+    size_t need = al(8 * nv + 8) + al(8 * (size_t)n * ps + 8) + al(glcm_scratch_bytes(job)) + al(fb + 8) + 4096;
+    if (mem == NFX_MEM_HOST) {
+        if ((st = check_offsets(ctx, ring_offsets, n, nv, "ring_offsets")) != NFX_OK) return st;
+        need += al(4 * (n + 1)) + al(8 * nv + 8) + al(3 * n * P + 8) + al(gb + 8) + al(rb + 8);
+    }
+    if ((st = ws_reserve(ctx, need, mem)) != NFX_OK) return st;
+    int64_t *d_g = glcm_sums;
+    uint32_t *d_r = glrlm_bins;
+    if (mem == NFX_MEM_HOST) {
+        ring_offsets = stage_in(ctx, ring_offsets, (size_t)n + 1);
+        ring_xy = stage_in(ctx, ring_xy, 2 * (size_t)nv);
+        patches_u8 = stage_in(ctx, patches_u8, 3 * (size_t)n * P);
+        if (glcm_sums) d_g = (int64_t *)ws_alloc(ctx, gb + 8);
+        if (glrlm_bins) d_r = (uint32_t *)ws_alloc(ctx, rb + 8);
+        if (!ring_offsets || !ring_xy || !patches_u8 || (glcm_sums && !d_g) || (glrlm_bins && !d_r)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    }
+    float *centred = (float *)ws_alloc(ctx, 8 * (size_t)nv + 8);
+    uint64_t *rows = (uint64_t *)ws_alloc(ctx, 8 * (size_t)n * ps + 8);
+    float *feat = (float *)ws_alloc(ctx, fb + 8); // the feature columns themselves are computed and dropped
+    void *scr = ws_alloc(ctx, glcm_scratch_bytes(job));
+    if (!centred || !rows || !feat || !scr) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    const int glcm_set = NFX_SET_GLCM;
+    if ((st = prepare_sets(ctx, &glcm_set, 1)) != NFX_OK) return st;
+    NFX_HIP(ctx, launch_preprocess(ctx, n, ring_offsets, ring_xy, nullptr, centred));
+    NFX_HIP(ctx, launch_raster_shape(ctx, n, ring_offsets, centred, ps, rows, nullptr, 0, 0));
+    job.poly_off = ring_offsets; job.poly_xy = centred; job.patches = patches_u8; job.patches_f32 = false; job.mask_rows = rows;
+    job.out = feat; job.F = 224; job.dbg_glcm = d_g; job.dbg_glrlm = d_r;
+    if (d_g) NFX_HIP(ctx, launch_glcm(ctx, job, 0, scr));
+    if (d_r) NFX_HIP(ctx, launch_glrlm(ctx, job, 0));
+    if (mem == NFX_MEM_HOST) {
+        if (glcm_sums && n) NFX_HIP(ctx, hipMemcpyAsync(glcm_sums, d_g, gb, hipMemcpyDeviceToHost, ctx->stream));
+        if (glrlm_bins && n) NFX_HIP(ctx, hipMemcpyAsync(glrlm_bins, d_r, rb, hipMemcpyDeviceToHost, ctx->stream));
+        NFX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return NFX_OK;
 }
 

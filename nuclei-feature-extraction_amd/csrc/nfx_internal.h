@@ -46,6 +46,7 @@ struct nfx_ctx {
     // grow-only device workspace with a bump pointer, reset at the start of every API call
     char *ws = nullptr;
     size_t ws_cap = 0, ws_off = 0;
+    bool reserved = false; // nfx_ctx_reserve was called: device-memory calls never grow the workspace or build tables
     // timing
     bool timing = false;
     std::vector<nfx::Timing> pending;
@@ -72,12 +73,19 @@ struct Job {
     const void *patches = nullptr;      // [n,3,ps,ps] u8 or f32
     bool patches_f32 = false;
     const uint64_t *mask_rows = nullptr; // [n,ps]
+    const int *areas = nullptr;          // [n] mask pixel counts when the rasteriser produced them (else counted from the rows)
     float *out = nullptr;               // [n,F]
     int F = 0;
+    // test hooks (nfx_debug_texture_counts); nullptr on every product path
+    int64_t *dbg_glcm = nullptr;        // [n][4 levels][4 offsets][6]
+    uint32_t *dbg_glrlm = nullptr;      // [n][4 directions][24][16]
 };
 
 // RAII-less helpers ---------------------------------------------------------------------------
-bool ws_reserve(nfx_ctx *ctx, size_t bytes);       // make capacity >= bytes (may reallocate: only before ws_alloc calls)
+// make capacity >= bytes and rewind the bump pointer (only before ws_alloc calls).  Growing reallocates (synchronise +
+// free + malloc): refused for device-memory calls on a reserved context or during stream capture
+nfx_status ws_reserve(nfx_ctx *ctx, size_t bytes, nfx_mem mem);
+bool stream_capturing(nfx_ctx *ctx);
 void *ws_alloc(nfx_ctx *ctx, size_t bytes);        // 256-B aligned bump allocation; nullptr when exhausted
 void timing_begin(nfx_ctx *ctx, int slot);
 void timing_end(nfx_ctx *ctx);
@@ -93,12 +101,13 @@ hipError_t launch_preprocess(nfx_ctx *ctx, int64_t n, const uint32_t *ring_off, 
                              float *centred);
 // rasterise (+ the mask-derived geometry columns when out != nullptr).  rows_out may be nullptr.
 hipError_t launch_raster_shape(nfx_ctx *ctx, int64_t n, const uint32_t *poly_off, const float *poly_xy, int ps,
-                               uint64_t *rows_out, float *out, int F, int col0);
+                               uint64_t *rows_out, float *out, int F, int col0, int *areas_out = nullptr);
 // geometry columns from existing mask rows (trait entry: masks are given, not rasterised)
 hipError_t launch_shape_from_rows(nfx_ctx *ctx, int64_t n, const uint64_t *rows, int ps, float *out, int F, int col0);
 // polygon-derived geometry columns; scratch: 3*total_vertices+2n+... doubles pairs (see k_geometry.hip)
+// out (f32 rows, columns 0,5,6,7,9,10,11 of the geometry block) and out64 ([n][7] f64) may each be nullptr
 hipError_t launch_polygon(nfx_ctx *ctx, int64_t n, const uint32_t *poly_off, const float *poly_xy, void *scratch,
-                          float *out, int F, int col0);
+                          float *out, int F, int col0, double *out64 = nullptr);
 size_t polygon_scratch_bytes(int64_t n, int64_t total_vertices);
 hipError_t launch_pack_masks(nfx_ctx *ctx, int64_t n, const float *masks_f32, int ps, uint64_t *rows);
 hipError_t launch_unpack_masks(nfx_ctx *ctx, int64_t n, const uint64_t *rows, int ps, float *masks_f32);
@@ -111,5 +120,10 @@ hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch);
 size_t glcm_scratch_bytes(const Job &job);
 hipError_t launch_glrlm(nfx_ctx *ctx, const Job &job, int col0);
 hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0);
+// device tables of a feature set (no-ops once built).  Building allocates and copies synchronously: nfx_ctx_reserve does it
+// up front; a launcher that finds its table missing builds it on the spot unless the stream is capturing
+hipError_t prepare_color(nfx_ctx *ctx);
+hipError_t prepare_glcm(nfx_ctx *ctx);
+hipError_t prepare_gabor(nfx_ctx *ctx);
 
 }  // namespace nfx

@@ -4,12 +4,21 @@ The reference's multi-GPU mode is `gpus[rayon_thread_idx % gpu_count]` per batch
 `vstack_mut` under a mutex (utils.rs:215-221, main.rs:96-108).  Here: one process per GPU, each rank
 extracts a contiguous index shard whose boundaries are multiples of the reference batch size (the
 hue statistics couple the nuclei of a batch, color.rs:144-155, so a batch must live on one rank),
-with no data-path collective; the rows are then gathered to one rank with a single collective
-(`torch.distributed`, backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+with no data-path collective; the rows are then gathered to one rank (`torch.distributed`, backend
+"nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+`ShardedExtraction` is the one implementation of that step: `bench.py` drives it with the HIP engine
+as the per-slice extractor, `tests/test_distributed.py` drives it (gloo, world size 2) with the CPU
+oracle in the engine's place.  `launch_ranks` starts one child process per GPU for a bare
+`python bench.py --gpus N`.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+import os
+import socket
+import subprocess
+import sys
+from typing import Callable, List, Optional, Sequence, Tuple
 
 
 def shard_range(n: int, batch_size: int, rank: int, world: int) -> Tuple[int, int]:
@@ -27,34 +36,147 @@ def shard_counts(n: int, batch_size: int, world: int) -> List[int]:
     return [shard_range(n, batch_size, r, world)[1] - shard_range(n, batch_size, r, world)[0] for r in range(world)]
 
 
-def gather_rows(local_rows, counts: List[int], dst: int = 0, group=None, out=None):
-    """Gathers per-rank row blocks [counts[r], F] to `dst` in rank (= index) order.
+def slice_bounds(rows: int, batch_size: int, n_slices: int) -> List[int]:
+    """Cuts [0, rows) into at most n_slices pieces whose inner boundaries are multiples of batch_size."""
+    nb = (rows + batch_size - 1) // batch_size
+    n_slices = max(1, min(n_slices, nb))
+    return [min(rows, (nb * k // n_slices) * batch_size) for k in range(n_slices)] + [rows]
 
-    Ragged shards are padded to the largest count for the collective; `out` ([sum(counts), F]) may be
-    preallocated on dst.  Returns the gathered matrix on dst, None elsewhere.
-    """
+
+def row_checksum(rows):
+    """Order-sensitive checksum of a [m, F] f32 block from its bit patterns (NaN payloads included):
+    sum over elements of bits * (1 + flat index mod 65521), in wrapping int64.  Tensor in, python int out."""
     import torch
-    import torch.distributed as dist
 
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    assert len(counts) == world and local_rows.shape[0] == counts[rank]
-    F = local_rows.shape[1]
-    m = max(counts)
-    if local_rows.shape[0] != m:
-        pad = torch.zeros((m, F), dtype=local_rows.dtype, device=local_rows.device)
-        pad[: local_rows.shape[0]] = local_rows
-        local_rows = pad
-    local_rows = local_rows.contiguous()
-    if rank == dst:
-        bufs = [torch.empty((m, F), dtype=local_rows.dtype, device=local_rows.device) for _ in range(world)]
-        dist.gather(local_rows, bufs, dst=dst, group=group)
-        if out is None:
-            out = torch.empty((sum(counts), F), dtype=local_rows.dtype, device=local_rows.device)
-        o = 0
-        for r in range(world):
-            out[o:o + counts[r]] = bufs[r][: counts[r]]
-            o += counts[r]
-        return out
-    dist.gather(local_rows, None, dst=dst, group=group)
-    return None
+    flat = rows.contiguous().view(torch.int32).reshape(-1).to(torch.int64)
+    w = torch.arange(flat.numel(), dtype=torch.int64, device=flat.device) % 65521 + 1
+    return int((flat * w).sum().item())
+
+
+class ShardedExtraction:
+    """One rank's part of an index-sharded extraction of `n_total` nuclei and the gather of its rows to `dst`.
+
+    Every rank extracts its shard [i0, i1) in a few batch-aligned slices; each slice's rows start their way to
+    `dst` (one asynchronous gather per slice) while the next slice is computed, and two row buffers alternate
+    between steps so the last gathers of step k overlap the first slices of step k+1.  Ragged shards are padded
+    to the largest shard for the collective (the padding rows are never read).  Rows land on `dst` in rank, i.e.
+    index, order: `result()` is the [n_total, F] matrix a single process would have produced.
+
+    extract_fn(b0, b1, out): computes the LOCAL rows [b0, b1) (nuclei i0+b0 .. i0+b1) into `out` ([b1-b0, F]).
+    wire_device: where the collective's buffers live (None = the compute device; "cpu" for a gloo group fed
+                 from a GPU, the one-GPU rehearsal of bench.py).
+    """
+
+    def __init__(self, n_total: int, F: int, batch_size: int, n_slices: int = 4, device=None, group=None, dst: int = 0,
+                 wire_device=None):
+        import torch
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.dst = dst
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n_total, self.F, self.batch_size = n_total, F, batch_size
+        self.i0, self.i1 = shard_range(n_total, batch_size, self.rank, self.world)
+        self.counts = shard_counts(n_total, batch_size, self.world)
+        self.n_local = self.i1 - self.i0
+        self.m = max(self.counts)                      # rows per rank in the collective
+        self.bounds = slice_bounds(self.m, batch_size, n_slices)
+        self.device = device if device is not None else torch.device("cpu")
+        self.wire = torch.device(wire_device) if wire_device is not None else self.device
+        self.bufs = [torch.empty((self.m, F), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.full = None
+        self.blocks = None
+        if self.rank == dst:
+            self.full = torch.empty((self.world * self.m, F), dtype=torch.float32, device=self.wire)
+            self.blocks = [self.full[r * self.m:(r + 1) * self.m] for r in range(self.world)]
+        self.pending: list = []
+        self.steps = 0
+        self.last_buf = None
+
+    def step(self, extract_fn: Callable[[int, int, object], None]):
+        buf = self.bufs[self.steps & 1]
+        works = []
+        for k in range(len(self.bounds) - 1):
+            b0, b1 = self.bounds[k], self.bounds[k + 1]
+            e1 = min(b1, self.n_local)
+            if e1 > b0:
+                extract_fn(b0, e1, buf[b0:e1])
+            send = buf[b0:b1] if self.wire == self.device else buf[b0:b1].to(self.wire)
+            recv = [blk[b0:b1] for blk in self.blocks] if self.rank == self.dst else None
+            works.append(self.dist.gather(send, recv, dst=self.dst, group=self.group, async_op=True))
+        # the gathers of the previous step stayed in flight during this step's compute; their buffer is written again
+        # in the NEXT step, so they are waited for here (stream-ordered on RCCL, host-side on gloo)
+        for w in self.pending:
+            w.wait()
+        self.pending = works
+        self.last_buf = buf
+        self.steps += 1
+
+    def finish(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    def local_rows(self):
+        """This rank's rows of the last step ([n_local, F])."""
+        return self.last_buf[:self.n_local]
+
+    def result(self):
+        """On dst: the gathered [n_total, F] matrix in index order (a view when the shards are equal)."""
+        if self.rank != self.dst:
+            return None
+        self.finish()
+        if all(c == self.m for c in self.counts):
+            return self.full[:self.n_total]
+        import torch
+        return torch.cat([self.blocks[r][:self.counts[r]] for r in range(self.world)], dim=0)
+
+    def verify_transport(self) -> Optional[List[bool]]:
+        """Every rank checksums the rows it sent, dst checksums the rows it received: per-rank equality on dst."""
+        import torch
+
+        self.finish()
+        mine = torch.tensor([row_checksum(self.local_rows())], dtype=torch.int64, device=self.wire)
+        got = [torch.zeros(1, dtype=torch.int64, device=self.wire) for _ in range(self.world)] if self.rank == self.dst else None
+        self.dist.gather(mine, got, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None
+        return [int(got[r].item()) == row_checksum(self.blocks[r][:self.counts[r]]) for r in range(self.world)]
+
+
+# ---- process launch -----------------------------------------------------------------------------------------------
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def rank_command(script: str, n_ranks: int, argv: Sequence[str], port: Optional[int] = None) -> List[str]:
+    """The command line that runs `script argv` as n_ranks ranks of one node (the form the driver itself uses)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), script, *argv]
+
+
+def launch_ranks(script: str, n_ranks: int, argv: Sequence[str]) -> int:
+    """Starts `script` as n_ranks CHILD processes and relays their output; returns the launcher's exit code.
+
+    Must be called before the calling process has touched the GPU (no HIP call, no torch.cuda.is_available()):
+    the children are started with subprocess -- never exec'd over a process that holds a GPU context."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL peer access across processes on this host driver
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    proc = subprocess.run(rank_command(script, n_ranks, argv), env=env, stdout=subprocess.PIPE, text=True)
+    # rank 0's one JSON line is the contract; whatever else reached the children's stdout goes to stderr
+    json_lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and ln.rstrip().endswith("}")]
+    for ln in proc.stdout.splitlines():
+        if ln not in json_lines:
+            print(ln, file=sys.stderr)
+    if proc.returncode == 0 and len(json_lines) == 1:
+        print(json_lines[0], flush=True)
+        return 0
+    print(f"launch_ranks: {n_ranks} ranks exited with code {proc.returncode}, {len(json_lines)} result lines", file=sys.stderr)
+    return proc.returncode or 1

@@ -290,6 +290,10 @@ void orc_raster_ellipse(int ps, float xc, float yc, float a, float b, float angl
  * S2/S3/S4/S6  (shape.rs:137-226), per nucleus.  mask: [ps*ps] f32, nonzero == inside.
  * aux (optional, 8 doubles): K, sum_r, sum_c, xor_count, p, q, r, -  for exact-integer checks.
  * ---------------------------------------------------------------------------------------- */
+/* the seven polygon columns at geometric_features' own width (shape.rs:89-97): area, perimeter, equivalent_perimeter,
+   compacity, convex_hull_area, convex_deffect, convex_perimeter */
+void orc_polygon_features_f64(const float *centred_xy, int V, double out7[7]) { orc_polygon_features(centred_xy, V, out7); }
+
 void orc_shape_one(const float *centred_xy, int V, const float *mask, int ps, float out[12], double *aux)
 {
     /* center_of_mass, shape.rs:219-226: nonzero() -> mean(dim0, Float).  Sums of integer
@@ -898,13 +902,23 @@ void orc_crop_patch_slide(const uint8_t *image, int H, int W, float cx, float cy
                 patch[((size_t)ch * ps + pr) * ps + pc] = image[((size_t)ch * H + (y0 + pr)) * W + (x0 + pc)];
 }
 
+/* Rust's `f32 as i64` (utils.rs:159-162): truncates, saturates, NaN -> 0; clamped further to +-2^40 (no image is that
+   large), so the window arithmetic cannot overflow */
+static int64_t orc_as_i64(float v)
+{
+    if (v != v) return 0;
+    if (v >= 1099511627776.0f) return (int64_t)1 << 40;
+    if (v <= -1099511627776.0f) return -((int64_t)1 << 40);
+    return (int64_t)v;
+}
+
 /* §8f-1 patch addressing, load_image_dataset (utils.rs:141-206): crop a [3,H,W] u8 planar image at the
    truncated box around the centroid, zero-padded, into [3,ps,ps] u8. */
 void orc_crop_patch(const uint8_t *image, int H, int W, float cx, float cy, int ps, uint8_t *patch)
 {
     float half = (float)ps / 2.0f;
-    int64_t top = (int64_t)(cy - half), left = (int64_t)(cx - half);       /* utils.rs:159-160 (as i64: trunc) */
-    int64_t bottom = (int64_t)(cy + half), right = (int64_t)(cx + half);   /* utils.rs:161-162 */
+    int64_t top = orc_as_i64(cy - half), left = orc_as_i64(cx - half);       /* utils.rs:159-160 (as i64: trunc, saturating) */
+    int64_t bottom = orc_as_i64(cy + half), right = orc_as_i64(cx + half);   /* utils.rs:161-162 */
     int64_t t0 = top > 0 ? top : 0, l0 = left > 0 ? left : 0;
     int64_t b0 = bottom < H ? bottom : H, r0 = right < W ? right : W;
     int64_t oy = -(top < 0 ? top : 0), ox = -(left < 0 ? left : 0);         /* utils.rs:180-181 */

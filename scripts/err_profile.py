@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Error profile of the HIP path against the oracle (run on the GPU box): per feature set and column, the worst absolute
+error, the column's median |value| and their ratio -- what a data-driven tolerance floor (tests/_parity.py) can be.
+    python scripts/err_profile.py [nuclei] > gpurun_out/err_profile.txt"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _oracle as orc   # noqa: E402
+import _parity as par   # noqa: E402
+
+nfx = importlib.import_module("nuclei-feature-extraction_amd")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+ctx = nfx.Context(0)
+sets = [0, 1, 2, 3, 4]
+names = nfx.all_column_names(sets)[1:]
+for seed, ps in ((1, 32), (2, 48), (4, 64)):
+    off, xy, pu8 = par.make_inputs(seed, n, ps)
+    got, _ = ctx.extract(sets, off, xy, pu8, ps, batch_size=100)
+    want, _ = orc.extract(sets, off, xy, pu8, ps, batch_size=100, threads=16)
+    g, w = got.astype(np.float64), want.astype(np.float64)
+    ok = np.isfinite(g) & np.isfinite(w)
+    err = np.where(ok, np.abs(g - w), 0.0)
+    med = np.array([np.median(np.abs(w[ok[:, c], c])) if ok[:, c].any() else 0.0 for c in range(w.shape[1])])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rel_to_med = err.max(0) / med
+        pure_rel = np.where(ok & (w != 0), err / np.abs(w), 0.0).max(0)
+    col = 0
+    print(f"== ps {ps}, {n} nuclei")
+    for s in sets:
+        k = nfx.num_columns(s)
+        sl = slice(col, col + k)
+        order = np.argsort(-rel_to_med[sl])[:6]
+        print(f"  set {nfx.feature_set_cli_name(s)}: worst err/median {np.nanmax(rel_to_med[sl]):.3e}, worst pure relative {pure_rel[sl].max():.3e}")
+        for j in order:
+            c = col + j
+            print(f"     {names[c]:55s} max|err| {err[:, c].max():.3e}  median|v| {med[c]:.3e}  err/median {rel_to_med[c]:.3e}  pure rel {pure_rel[c]:.3e}")
+        col += k
+ctx.close()

@@ -65,6 +65,14 @@ def shape_one(centred_xy, mask):
     return out, aux
 
 
+def polygon_features_f64(centred_xy):
+    """geometric_features::* on one centred polygon (shape.rs:89-97): 7 doubles, order as nfx_polygon_features_f64."""
+    centred_xy = np.ascontiguousarray(centred_xy, np.float32)
+    out = np.zeros(7, np.float64)
+    lib().orc_polygon_features_f64(_p(centred_xy, C.c_float), C.c_int(centred_xy.shape[0]), _p(out, C.c_double))
+    return out
+
+
 def compute_features_batched(set_id, poly_offsets, poly_xy, patches, masks):
     """FeatureSet::compute_features_batched for ONE reference batch (features/mod.rs:21-27)."""
     poly_offsets = np.ascontiguousarray(poly_offsets, np.uint32)
@@ -129,3 +137,39 @@ def crop_patch(image, cx, cy, ps, slide=False):
     out = np.zeros((3, ps, ps), np.uint8)
     (lib().orc_crop_patch_slide if slide else lib().orc_crop_patch)(_p(image, C.c_uint8), C.c_int(H), C.c_int(W), C.c_float(cx), C.c_float(cy), C.c_int(ps), _p(out, C.c_uint8))
     return out
+
+
+GLCM_LEVELS = (32, 64, 128, 254)                  # texture.rs:19
+GLCM_OFFSETS = ((0, 1), (1, 1), (1, 0), (1, -1))  # texture.rs:20 (dy, dx)
+GLRLM_DIRS = ((1, 0), (1, 1), (0, 1), (-1, 1))    # texture.rs:176 (dx, dy)
+
+
+def glcm_invariants(G):
+    """The six exact integers nfx_debug_texture_counts reports, from a dense symmetric count matrix G (int64 [L,L])."""
+    L = G.shape[0]
+    a = np.arange(L, dtype=np.int64)[:, None]
+    b = np.arange(L, dtype=np.int64)[None, :]
+    s, d = a + b, np.abs(a - b)
+    tot = int(G.sum())
+    assert tot % 2 == 0
+    return np.array([tot // 2, int((s * G).sum()) // 2, int((s * s * G).sum()) // 2, int((d * G).sum()) // 2,
+                     int((d * d * G).sum()) // 2, int((G * G).sum())], np.int64)
+
+
+def texture_counts(ring_offsets, ring_xy, patches_u8, ps):
+    """Count-level oracle for the texture sets on packed u8 patches: masks as the pipeline makes them (R1 + R2), then
+    (glcm_sums int64 [n,4,4,6], glrlm_bins uint32 [n,4,24,16]) in the layout of nfx_debug_texture_counts."""
+    ring_offsets = np.asarray(ring_offsets, np.int64)
+    n = len(ring_offsets) - 1
+    g = np.zeros((n, 4, 4, 6), np.int64)
+    r = np.zeros((n, 4, 24, 16), np.uint32)
+    for i in range(n):
+        _, ctr = preprocess_polygon(ring_xy[ring_offsets[i]:ring_offsets[i + 1]])
+        mask = raster_polygon(ctr, ps)
+        patch = patches_u8[i].astype(np.float32) / np.float32(255.0)      # utils.rs:172
+        for li, L in enumerate(GLCM_LEVELS):
+            for oi, (dy, dx) in enumerate(GLCM_OFFSETS):
+                g[i, li, oi] = glcm_invariants(glcm_counts(patch, mask, L, dy, dx))
+        for di, (dx, dy) in enumerate(GLRLM_DIRS):
+            r[i, di] = glrlm_counts(patch, mask, dx, dy).astype(np.uint32)
+    return g, r

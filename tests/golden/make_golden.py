@@ -35,7 +35,9 @@ def build(ps, n=14, seed=77):
     pu8 = np.concatenate([pu8, pu8[:ne]])
     rows, cen = orc.extract(SETS, off, xy, pu8, ps, batch_size=BATCH)
     masks = np.stack([orc.raster_polygon(orc.preprocess_polygon(xy[off[i]:off[i + 1]])[1], ps) for i in range(len(off) - 1)])
-    return dict(ring_offsets=off, ring_xy=xy, patches_u8=pu8, ps=np.int32(ps), batch_size=np.int32(BATCH),
+    # the integers behind the texture columns (layout of nfx_debug_texture_counts): compared == with the HIP kernels' own
+    glcm_sums, glrlm_bins = orc.texture_counts(off, xy, pu8, ps)
+    return dict(glcm_sums=glcm_sums, glrlm_bins=glrlm_bins, ring_offsets=off, ring_xy=xy, patches_u8=pu8, ps=np.int32(ps), batch_size=np.int32(BATCH),
                 sets=np.asarray(SETS, np.int32), rows=rows, centroids=cen, mask_bits=np.packbits(masks.astype(bool), axis=-1))
 
 

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol(nfx):
     L = nfx.lib()
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.nfx_version() == 100
+    assert L.nfx_version() == 200
 
 
 def test_registry_names_and_counts(nfx):
@@ -73,3 +73,12 @@ def test_no_cpu_fallback_without_gpu(nfx):
         pytest.skip("GPU present")
     with pytest.raises(nfx.NfxError):
         nfx.Context(0)
+
+
+def test_column_dtypes_follow_the_reference_frame(nfx):
+    """shape.rs:116-127: the seven polygon columns are geometric_features' f64 return values, every other column of
+    every set was read out of an f32 tensor."""
+    assert nfx.column_dtypes(0) == ["f64", "f32", "f32", "f32", "f32", "f64", "f64", "f64", "f32", "f64", "f64", "f64"]
+    for s in range(1, 5):
+        assert set(nfx.column_dtypes(s)) == {"f32"}
+    assert nfx.lib().nfx_feature_set_column_dtype(0, 12) == -1 and nfx.lib().nfx_feature_set_column_dtype(5, 0) == -1

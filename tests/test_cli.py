@@ -130,6 +130,10 @@ def test_two_contexts_in_one_process_match_one(nfx, tmp_path):
     assert run("-g", "0", *common, str(a), "color", "geometry").returncode == 0
     assert run("-g", "0", "-g", "0", *common, str(b), "color", "geometry").returncode == 0
     assert open(a).read() == open(b).read()
+    # every set: both contexts build their device tables (Gabor bank, stain look-up, GLCM tables) at the same moment
+    assert run("-o", "-g", "0", *common, str(a), "all").returncode == 0
+    assert run("-o", "-g", "0", "-g", "0", *common, str(b), "all").returncode == 0
+    assert open(a).read() == open(b).read()
 
 
 @pytest.mark.gpu

@@ -1,13 +1,13 @@
-"""N>1 path on CPU: world-size-2 gloo.  Each rank extracts its index shard (the CPU oracle stands in for
-the GPU engine here -- this test is about sharding and the gather, not the kernels) and the gathered
-matrix must equal the single-process result row for row, including the batch-coupled mean_h."""
+"""N>1 path on CPU: world-size-2 gloo through `distributed.ShardedExtraction` -- the class bench.py runs on the
+GPUs.  The CPU oracle stands in for the HIP engine as the per-slice extractor (this test is about sharding, slicing,
+double-buffered gathers and row order, not the kernels); the gathered matrix must equal the single-process result
+row for row, including the batch-coupled mean_h."""
 import importlib
+import json
 import os
-import socket
 import sys
 
 import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -16,15 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = "nuclei-feature-extraction_amd"
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def _worker(rank, world, port, n, ps, batch, aligned, q):
+def _worker(rank, world, port, n, ps, batch, shard_batch, n_slices, steps, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -34,31 +26,36 @@ def _worker(rank, world, port, n, ps, batch, aligned, q):
     import _parity as par
     D = importlib.import_module(PKG + ".distributed")
     off, xy, pu8 = par.make_inputs(31, n, ps)
-    if aligned:
-        i0, i1 = D.shard_range(n, batch, rank, world)
-        counts = D.shard_counts(n, batch, world)
-    else:  # deliberately cut in the middle of a reference batch
-        cut = batch + batch // 2
-        i0, i1 = (0, cut) if rank == 0 else (cut, n)
-        counts = [cut, n - cut]
-    so = (off[i0:i1 + 1] - off[i0]).astype(np.uint32)
-    rows, _ = orc.extract([0, 1], so, xy[off[i0]:off[i1]], pu8[i0:i1], ps, batch_size=batch)
-    full = D.gather_rows(torch.from_numpy(rows), counts, dst=0)
+    sets = [0, 1]
+    sx = D.ShardedExtraction(n, 30, shard_batch, n_slices=n_slices)
+
+    def extract(b0, b1, out):   # local rows [b0, b1) of this rank's shard
+        i0, i1 = sx.i0 + b0, sx.i0 + b1
+        # the reference batch partition restarts at the shard's first nucleus (a rank sees only its shard)
+        assert b0 % batch == 0 or shard_batch % batch != 0
+        so = (off[i0:i1 + 1] - off[i0]).astype(np.uint32)
+        rows, _ = orc.extract(sets, so, xy[off[i0]:off[i1]], pu8[i0:i1], ps, batch_size=batch)
+        out.copy_(torch.from_numpy(rows))
+
+    for _ in range(steps):      # several steps: the two row buffers alternate and gathers stay in flight across steps
+        sx.step(extract)
+    ok = sx.verify_transport()
+    full = sx.result()
     if rank == 0:
-        q.put(full.numpy())
+        q.put((full.numpy().copy(), ok, sx.counts, sx.bounds))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(aligned):
-    n, ps, batch = 70, 32, 16
+def _run(n=70, ps=32, batch=16, shard_batch=16, n_slices=2, steps=3, world=2):
+    D = importlib.import_module(PKG + ".distributed")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, ps, batch, aligned, q)) for r in range(2)]
+    port = D.free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, ps, batch, shard_batch, n_slices, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got, ok, counts, bounds = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -67,18 +64,28 @@ def _run(aligned):
     import _parity as par
     off, xy, pu8 = par.make_inputs(31, n, ps)
     want, _ = orc.extract([0, 1], off, xy, pu8, ps, batch_size=batch)
-    return got, want
+    return got, want, ok, counts, bounds
 
 
 def test_sharded_gather_equals_single_process():
-    got, want = _run(aligned=True)
+    got, want, ok, counts, bounds = _run()
+    assert counts == [48, 22] and bounds == [0, 16, 48]      # ragged shards, two slices
+    assert ok == [True, True]
     assert got.shape == want.shape
     assert np.array_equal(got, want, equal_nan=True)
 
 
+def test_equal_shards_single_slice():
+    got, want, ok, counts, _ = _run(n=64, n_slices=1, steps=1)
+    assert counts == [32, 32] and ok == [True, True]
+    assert np.array_equal(got, want, equal_nan=True)
+
+
 def test_shard_cut_inside_a_batch_changes_mean_h():
-    """Why shard boundaries must be batch multiples: mean_h (column 12+6) couples a batch."""
-    got, want = _run(aligned=False)
+    """Why shard boundaries must be multiples of the reference batch: mean_h (column 12+6) couples a batch.
+    Shards aligned to 20 nuclei cut the reference batches of 16."""
+    got, want, ok, counts, _ = _run(shard_batch=20, n_slices=1, steps=1)
+    assert counts == [40, 30] and ok == [True, True]
     col = 12 + 6
     assert not np.allclose(got[:, col], want[:, col], rtol=1e-6, atol=1e-6, equal_nan=True)
     other = [c for c in range(got.shape[1]) if c not in (col, 12 + 9)]
@@ -95,3 +102,43 @@ def test_shard_ranges_cover_in_order():
             prev = i1
         assert prev == n
         assert sum(D.shard_counts(n, B, R)) == n
+    for rows, B, k in [(125_000, 100, 4), (70, 16, 4), (48, 16, 8), (0, 100, 4), (1, 100, 4)]:
+        b = D.slice_bounds(rows, B, k)
+        assert b[0] == 0 and b[-1] == rows and all(x <= y for x, y in zip(b, b[1:]))
+        assert all(x % B == 0 for x in b[:-1])
+
+
+def test_row_checksum_sees_order_and_nan_payload():
+    D = importlib.import_module(PKG + ".distributed")
+    a = torch.tensor([[1.0, 2.0], [float("nan"), 4.0]])
+    b = a.flip(0)
+    assert D.row_checksum(a) == D.row_checksum(a.clone())
+    assert D.row_checksum(a) != D.row_checksum(b)
+
+
+def test_rank_command_is_the_drivers_form():
+    D = importlib.import_module(PKG + ".distributed")
+    cmd = D.rank_command("bench.py", 4, ["--gpus", "4", "--steps", "3"], port=29511)
+    assert cmd[1:] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+                       "--master-port", "29511", "bench.py", "--gpus", "4", "--steps", "3"]
+
+
+def test_launch_ranks_relays_one_json_line(tmp_path):
+    """The self-launch path of `python bench.py --gpus N` (no GPU needed: the child is a stub that reports its rank env)."""
+    D = importlib.import_module(PKG + ".distributed")
+    stub = tmp_path / "stub.py"
+    stub.write_text(
+        "import json, os, sys\n"
+        "print('noise from a library')\n"
+        "if os.environ['RANK'] == '0':\n"
+        "    print(json.dumps({'world': int(os.environ['WORLD_SIZE']), 'argv': sys.argv[1:]}))\n"
+        "sys.exit(int(sys.argv[1]))\n")
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import importlib; D = importlib.import_module(%r + '.distributed'); "
+            "sys.exit(D.launch_ranks(%r, 2, sys.argv[1:]))" % (ROOT, PKG, str(stub)))
+    r = subprocess.run([sys.executable, "-c", code, "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout.strip()) == {"world": 2, "argv": ["0"]}
+    assert "noise from a library" in r.stderr and "noise" not in r.stdout
+    r = subprocess.run([sys.executable, "-c", code, "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""

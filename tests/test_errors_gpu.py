@@ -101,3 +101,138 @@ def test_repeated_calls_of_changing_size_do_not_leak_device_memory(nfx):
         c.extract([0, 2], off[:51], xy[:off[50]], pu8[:50], ps)
         c.close()
     assert free_bytes() >= before_close - (8 << 20), "closed contexts still hold device memory"
+
+
+def test_offsets_are_validated_before_anything_is_launched(nfx):
+    """NFX_MEM_HOST offsets index the vertex array inside the kernels: a non-monotonic or shifted array is refused up front."""
+    ctx = nfx.Context(0)
+    ps = 32
+    off, xy, pu8 = par.make_inputs(3, 20, ps)
+    off = off.astype(np.uint32)
+    bad = off.copy()
+    bad[7], bad[8] = off[8], off[7]                              # still ends at n_vertices
+    st, msg = _extract(nfx, ctx, [0, 1], bad, xy, pu8, ps, 100)
+    assert st == INVALID and "not non-decreasing" in msg, (st, msg)
+    bad = off.copy()
+    bad[0] = 3
+    st, msg = _extract(nfx, ctx, [0, 1], bad, xy, pu8, ps, 100)
+    assert st == INVALID and "[0] != 0" in msg, (st, msg)
+    rows, _ = ctx.extract([0, 1], off, xy, pu8, ps)              # the context is still usable
+    assert np.isfinite(rows[:, 0]).all()
+    ctx.close()
+
+
+def test_repeated_sets_get_their_own_columns_and_scratch(nfx):
+    """args.rs:38-49 does not de-duplicate: `color color glcm color` is four blocks; every occurrence needs scratch of its own."""
+    ctx = nfx.Context(0)
+    ps = 48
+    off, xy, pu8 = par.make_inputs(5, 230, ps)
+    rows, _ = ctx.extract([1, 1, 2, 1, 0, 0], off, xy, pu8, ps, batch_size=100)
+    one, _ = ctx.extract([1, 2, 0], off, xy, pu8, ps, batch_size=100)
+    c, g, s = one[:, :18], one[:, 18:242], one[:, 242:]
+    want = np.concatenate([c, c, g, c, s, s], axis=1)
+    assert np.array_equal(rows, want, equal_nan=True)
+    ctx.close()
+
+
+def test_reserved_context_never_grows_and_says_so(nfx):
+    """nfx_ctx_reserve: after it, device-memory calls neither allocate nor synchronise; one that does not fit fails."""
+    import torch
+    ps = 48
+    off, xy, pu8 = par.make_inputs(6, 400, ps)
+    dev = torch.device("cuda", 0)
+    d_off = torch.from_numpy(off.astype(np.int32)).to(dev)
+    d_xy = torch.from_numpy(xy).to(dev)
+    d_p = torch.from_numpy(pu8).to(dev)
+    sets = [0, 1, 2, 3, 4]
+    ctx = nfx.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    n_small = 100
+    ctx.reserve(sets, n_small, int(off[n_small]), ps, batch_size=100)
+    free0 = torch.cuda.mem_get_info()[0]
+    small, _ = ctx.extract(sets, d_off[:n_small + 1].contiguous(), d_xy[:int(off[n_small])], d_p[:n_small], ps, want_centroids=False)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (1 << 20)      # the FIRST device call after a reservation allocates nothing (rows aside)
+    with pytest.raises(nfx.NfxError, match="reservation"):
+        ctx.extract(sets, d_off, d_xy, d_p, ps, want_centroids=False)
+    ctx.reserve(sets, 400, int(off[-1]), ps, batch_size=100)      # reservations grow on request
+    big, _ = ctx.extract(sets, d_off, d_xy, d_p, ps, want_centroids=False)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(big[:n_small]), torch.nan_to_num(small))
+    ctx.set_stream(0)
+    ctx.close()
+
+
+def test_capture_needs_a_reservation_and_works_with_one(nfx):
+    """A first device-memory call inside a stream capture cannot allocate: without a reservation it is refused (and the
+    capture survives); with nfx_ctx_reserve the very first call of the context can be captured and replayed."""
+    import torch
+    ps, n = 48, 300
+    off, xy, pu8 = par.make_inputs(8, n, ps)
+    dev = torch.device("cuda", 0)
+    d_off = torch.from_numpy(off.astype(np.int32)).to(dev)
+    d_xy = torch.from_numpy(xy).to(dev)
+    d_p = torch.from_numpy(pu8).to(dev)
+    sets = [0, 1, 2, 3, 4]
+    out = torch.zeros((n, 418), dtype=torch.float32, device=dev)
+    side = torch.cuda.Stream()
+    for reserve in (False, True):
+        ctx = nfx.Context(0)
+        try:
+            if reserve:
+                ctx.reserve(sets, n, len(xy), ps, batch_size=100)
+            g = torch.cuda.CUDAGraph()
+            side.wait_stream(torch.cuda.current_stream())
+            err = None
+            with torch.cuda.stream(side):
+                ctx.set_stream(side.cuda_stream)
+                with torch.cuda.graph(g, stream=side):
+                    try:
+                        ctx.extract(sets, d_off, d_xy, d_p, ps, out=out, want_centroids=False)
+                    except nfx.NfxError as e:
+                        err = str(e)
+            torch.cuda.current_stream().wait_stream(side)
+            if not reserve:
+                assert err is not None and "nfx_ctx_reserve" in err, err
+            else:
+                assert err is None, err
+                out.zero_()
+                g.replay()
+                torch.cuda.synchronize()
+                ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                want, _ = ctx.extract(sets, d_off, d_xy, d_p, ps, want_centroids=False)
+                torch.cuda.synchronize()
+                assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(want))
+        finally:
+            ctx.set_stream(0)
+            ctx.close()
+
+
+def test_contexts_first_used_concurrently_from_threads_agree(nfx):
+    """One context per host thread, first call made by all threads at once (the reference calls its feature sets from every
+    rayon worker, main.rs:146-151): lazily built device tables (Gabor bank, stain look-up, GLCM tables) must not be shared
+    half-built between contexts."""
+    import threading
+    ps = 64
+    off, xy, pu8 = par.make_inputs(9, 120, ps)
+    sets = [0, 1, 2, 3, 4]
+    n_threads = 4
+    ctxs = [nfx.Context(0) for _ in range(n_threads)]
+    results = [None] * n_threads
+    start = threading.Barrier(n_threads)
+
+    def work(k):
+        start.wait()
+        results[k] = ctxs[k].extract(sets, off, xy, pu8, ps, batch_size=40)[0]
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for c in ctxs:
+        c.close()
+    ref = nfx.Context(0)
+    want = ref.extract(sets, off, xy, pu8, ps, batch_size=40)[0]
+    ref.close()
+    for k in range(n_threads):
+        assert np.array_equal(results[k], want, equal_nan=True), f"thread {k} differs"

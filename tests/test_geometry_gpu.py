@@ -94,3 +94,40 @@ def test_unsupported_patch_size_is_an_error(nfx, ctx):
 def test_empty_call(nfx, ctx):
     got, cen = ctx.extract([0], np.zeros(1, np.uint32), np.zeros((0, 2), np.float32), None, 32)
     assert got.shape == (0, 12)
+
+
+def test_polygon_columns_at_f64_width(nfx):
+    """shape.rs:89-97 pushes geometric_features' own (f64) values into the frame: nfx_polygon_features_f64 returns the seven
+    polygon columns unrounded, nfx_feature_set_column_dtype says which columns those are, and the f32 rows hold them rounded once."""
+    ctx = nfx.Context(0)
+    ps = 64
+    off, xy, _ = par.make_inputs(12, 300, ps, with_patches=False)
+    e_off, e_xy = par.edge_case_rings(ps)
+    off, xy = par.concat_rings((off, xy), (e_off, e_xy))
+    cen, ctr = ctx.preprocess_polygons(off, xy)
+    p64 = ctx.polygon_features_f64(off, ctr)
+    assert p64.dtype == np.float64 and p64.shape == (len(off) - 1, 7)
+    rows, _ = ctx.extract([0], off, xy, None, ps)
+    dt = nfx.column_dtypes(0)
+    cols = [j for j, d in enumerate(dt) if d == "f64"]
+    assert [nfx.column_names(0)[j] for j in cols] == ["area", "perimeter", "equivalent_perimeter", "compacity", "convex_hull_area",
+                                                     "convex_deffect", "convex_perimeter"]
+    assert all(d == "f32" for s in range(1, 5) for d in nfx.column_dtypes(s))
+    with np.errstate(invalid="ignore", over="ignore"):
+        assert np.array_equal(p64.astype(np.float32), rows[:, cols], equal_nan=True)
+    # against the oracle at f64 width: same expression trees, -ffp-contract=off on both sides; sqrt is correctly rounded on
+    # both, so only libm-free arithmetic is involved and the doubles agree to the last bits
+    want64 = np.stack([orc.polygon_features_f64(ctr[off[i]:off[i + 1]]) for i in range(len(off) - 1)])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rel = np.abs(p64 - want64) / np.maximum(np.abs(want64), 1e-300)
+    assert np.array_equal(np.isnan(p64), np.isnan(want64))
+    assert np.nanmax(np.where(np.isfinite(rel), rel, 0.0)) < 1e-12
+    # more digits than f32 holds: the values are not f32 numbers widened
+    finite = np.isfinite(p64[:300, 1])
+    assert (p64[:300, 1][finite] != p64[:300, 1][finite].astype(np.float32).astype(np.float64)).mean() > 0.9
+    # device memory, same numbers
+    import torch
+    d64 = ctx.polygon_features_f64(torch.from_numpy(off.astype(np.int32)).cuda(), torch.from_numpy(ctr).cuda())
+    ctx.synchronize()
+    assert np.array_equal(d64.cpu().numpy(), p64, equal_nan=True)
+    ctx.close()

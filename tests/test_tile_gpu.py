@@ -87,3 +87,32 @@ def test_tile_entry_device_memory(nfx, synth, ctx):
     torch.cuda.synchronize()
     ctx.set_stream(0)
     assert np.array_equal(dev.cpu().numpy(), host, equal_nan=True)
+
+
+def test_image_addressing_of_nan_and_huge_centroids_follows_rust_casts(synth, ctx):
+    """utils.rs:159-162 casts with `as i64`: NaN -> 0, +-huge saturate (a C cast would be undefined).  A NaN centroid -- the
+    vertex mean of an EMPTY ring is 0/0 -- gives the empty box [0,0) x [0,0): an all-zero patch; saturated boxes lie outside."""
+    ps = 32
+    off, xy, img = _scene(synth, ps, n=12)
+    cen = np.array([[np.nan, np.nan], [np.nan, 40.0], [1e30, 20.0], [-1e30, -1e30], [20.0, 3e38], [np.inf, -np.inf], [50.5, 60.25]], np.float32)
+    got = ctx.gather_patches(cen, img, ps)
+    for i in range(len(cen)):
+        assert np.array_equal(got[i], orc.crop_patch(img, cen[i, 0], cen[i, 1], ps)), f"centroid {cen[i]}"
+    assert not got[:6].any() and got[6].any()
+
+
+def test_tile_entry_with_an_empty_ring(nfx, synth, ctx):
+    """An empty ring through the tile entry: NaN centroid, empty mask, all-zero patch -> the row the reference's arithmetic
+    gives (NaN where it divides by the empty mask's area), and the neighbours' rows untouched."""
+    ps = 48
+    off, xy, img = _scene(synth, ps, n=40)
+    off2 = np.concatenate([off[:11], off[10:]]).astype(np.uint32)     # nucleus 10 becomes an empty ring; 41 nuclei
+    sets = [0, 1, 2, 3, 4]
+    rows, cen = ctx.extract_tile(sets, off2, xy, img, ps, batch_size=16)
+    assert np.isnan(cen[10]).all()
+    patches = np.stack([orc.crop_patch(img, c[0], c[1], ps) for c in cen])
+    assert not patches[10].any()
+    want, wcen = orc.extract(sets, off2, xy, patches, ps, batch_size=16)
+    assert np.array_equal(wcen, cen, equal_nan=True)
+    par.assert_rows_close(rows, want, par.column_scales(nfx, sets, ps), what="tile entry, empty ring")
+    assert np.isnan(rows[10, 1]) and np.isnan(rows[10, 12])           # major_axis, mean_r: 0/0
