@@ -101,6 +101,12 @@ def parse_args():
     ap.add_argument("--chunk", type=int, default=100_000, help="nuclei per streamed chunk (--h2d stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements of the `also` object")
+    ap.add_argument("--strong-nuclei", type=int, default=0,
+                    help="N>1: total nuclei of the strong-scaling (configs[3]) measurement; default: the workload's size when the headline "
+                         "runs at full size, else skipped")
+    ap.add_argument("--full-set-nuclei", type=int, default=0,
+                    help="nuclei per GPU of the full-feature-set (configs[4] shard) measurement; default: 1.25M when the headline runs at "
+                         "full size, else skipped")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
@@ -249,7 +255,7 @@ def main():
     full_size = n_local == n_def and not args.sets
 
     res = Resident(nfx, synth, torch, dev, args.workload, n_local, rank * n_local, set_names)
-    sets, F = res.sets, res.F
+    sets, F, gen_s = res.sets, res.F, res.gen_s
     ctx = nfx.Context(dev.index)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
@@ -327,8 +333,34 @@ def main():
                "parity_spot_check_worst_scaled_err": float(f"{worst:.3g}")}
 
     # ---- also: the figures the metric names, under the same clock --------------------------------------------------------
-    if not args.no_also and full_size and args.workload == "config3" and not stream_mode:
-        if world == 1:
+    n_strong = args.strong_nuclei or (n_def if full_size else 0)
+    n_strong = (n_strong // B) * B
+    if not args.no_also and not stream_mode and world > 1 and use_dist and 0 < n_strong <= n_local:
+        # configs[3]: the SAME n_strong nuclei cut into `world` batch-aligned shards (strong scaling); rank 0's weak-scaling
+        # inputs start with exactly those nuclei, so it can check the gathered matrix against its own single-GPU result
+        ssx = D.ShardedExtraction(n_strong, F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if rehearsal else None)
+        rs = Resident(nfx, synth, torch, dev, args.workload, ssx.n_local, ssx.i0, set_names)
+        el_s, _ = timed(torch, dist, True, ctx, args.steps, 1, lambda: ssx.step(lambda b0, b1, out: rs.extract(ctx, b0, b1, out, B)),
+                        lambda: fence(ssx))
+        ok = ssx.verify_transport()
+        full = ssx.result()
+        if rank == 0:
+            single = torch.empty((n_strong, F), dtype=torch.float32, device=dev)
+            res.extract(ctx, 0, n_strong, single, B)
+            torch.cuda.synchronize()
+            same = bool(torch.equal(full.to(dev).view(torch.int32), single.view(torch.int32)))
+            also["strong_scaling_config4"] = {
+                "value": round(n_strong * args.steps / el_s, 1), "unit": "nuclei/s", "ms_per_step": round(el_s / args.steps * 1e3, 3),
+                "scaling": "strong", "what": f"BASELINE.json configs[3]: the first {n_strong} nuclei of {wl_desc} index-sharded x{world} "
+                "(batch-aligned shards), rows gathered to rank 0",
+                "shard_nuclei": ssx.counts, "gather_checksums_match": bool(all(ok)), "gathered_equals_single_gpu": same,
+                "gathered_checksum": D.row_checksum(full)}
+            single = None
+        dist.barrier()
+        ssx = rs = full = None
+    n5 = ((args.full_set_nuclei or (WORKLOADS["config5"][0] if full_size else 0)) // B) * B
+    if not args.no_also and args.workload == "config3" and not args.sets and not stream_mode and (full_size or n5 > 0):
+        if world == 1 and full_size:
             # (ii) PCIe-inclusive rate of the headline workload: first H2D byte to last row in pinned host memory
             pipeline = importlib.import_module(PKG + ".pipeline")
             hp = torch.empty(res.d_patches.shape, dtype=torch.uint8, pin_memory=True)
@@ -346,42 +378,30 @@ def main():
                         "byte to the last row on the host (SURVEY.md §8d); never the headline value",
                 "host_rows_equal_resident_rows": same}
             del hp, hr
-            # (i) the metric's "full feature set": configs[4] per-GPU shard
-            res = None
-            d_out = None
-            torch.cuda.empty_cache()
-            r5 = Resident(nfx, synth, torch, dev, "config5", WORKLOADS["config5"][0], 0, WORKLOADS["config5"][2])
-            ctx.reserve(r5.sets, r5.n, len(r5.xy), r5.ps, batch_size=B)
+        # (i) the metric's "full feature set": configs[4] per-GPU shard on every rank (weak scaling, rows gathered to rank 0 for N > 1)
+        res = d_out = sx = None
+        torch.cuda.empty_cache()
+        r5 = Resident(nfx, synth, torch, dev, "config5", n5, rank * n5, WORKLOADS["config5"][2])
+        ctx.reserve(r5.sets, r5.n, len(r5.xy), r5.ps, batch_size=B)
+        k5 = max(2, args.steps // 2)
+        if use_dist:
+            sx5 = D.ShardedExtraction(world * n5, r5.F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if rehearsal else None)
+            el5, t5 = timed(torch, dist, True, ctx, k5, 1, lambda: sx5.step(lambda b0, b1, out: r5.extract(ctx, b0, b1, out, B)), lambda: fence(sx5))
+            ok5 = sx5.verify_transport()
+        else:
             o5 = torch.empty((r5.n, r5.F), dtype=torch.float32, device=dev)
-            el5, t5 = timed(torch, dist, False, ctx, max(2, args.steps // 2), 1, lambda: r5.extract(ctx, 0, r5.n, o5, B), fence)
-            k5 = max(2, args.steps // 2)
+            el5, t5 = timed(torch, dist, False, ctx, k5, 1, lambda: r5.extract(ctx, 0, r5.n, o5, B), fence)
+            ok5 = None
+        if rank == 0:
             also["full_feature_set"] = {
-                "value": round(r5.n * k5 / el5, 1), "unit": "nuclei/s", "steps": k5, "ms_per_step": round(el5 / k5 * 1e3, 3),
+                "value": round(world * r5.n * k5 / el5, 1), "unit": "nuclei/s", "n_gpus": world, "steps": k5, "ms_per_step": round(el5 / k5 * 1e3, 3),
+                "scaling": "weak",
                 "config": {"workload": WORKLOADS["config5"][3], "nuclei_per_gpu": r5.n, "patch_size": r5.ps, "feature_sets": ["all"],
                            "columns": r5.F, "batch_size": B, "gen_seconds": round(r5.gen_s, 1)},
-                "roofline": roofline_of(t5, k5, r5, "config5", True)}
-            del r5, o5
-        elif use_dist:
-            # configs[3]: the SAME 1M nuclei cut into `world` batch-aligned shards (strong scaling); rank 0's weak-scaling
-            # inputs are exactly those 1M nuclei, so it can check the gathered matrix against its own single-GPU result
-            ssx = D.ShardedExtraction(n_def, F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if rehearsal else None)
-            rs = Resident(nfx, synth, torch, dev, args.workload, ssx.n_local, ssx.i0, set_names)
-            el_s, _ = timed(torch, dist, True, ctx, args.steps, 1, lambda: ssx.step(lambda b0, b1, out: rs.extract(ctx, b0, b1, out, B)),
-                            lambda: fence(ssx))
-            ok = ssx.verify_transport()
-            full = ssx.result()
-            if rank == 0:
-                single = torch.empty((n_def, F), dtype=torch.float32, device=dev)
-                res.extract(ctx, 0, n_def, single, B)
-                torch.cuda.synchronize()
-                same = bool(torch.equal(full.to(dev).view(torch.int32), single.view(torch.int32)))
-                also["strong_scaling_config4"] = {
-                    "value": round(n_def * args.steps / el_s, 1), "unit": "nuclei/s", "ms_per_step": round(el_s / args.steps * 1e3, 3),
-                    "scaling": "strong", "what": f"BASELINE.json configs[3]: the {n_def} nuclei of configs[2] index-sharded x{world} "
-                    "(batch-aligned shards), rows gathered to rank 0",
-                    "shard_nuclei": ssx.counts, "gather_checksums_match": bool(all(ok)), "gathered_equals_single_gpu": same,
-                    "gathered_checksum": D.row_checksum(full)}
-            dist.barrier()
+                "roofline": roofline_of(t5, k5, r5, "config5", n5 == WORKLOADS["config5"][0])}
+            if ok5 is not None:
+                also["full_feature_set"]["gather_checksums_match"] = bool(all(ok5))
+        r5 = None
 
     if rank == 0:
         sharding = "single GPU"
@@ -397,7 +417,7 @@ def main():
                        "inputs": "packed u8 patches + polygons resident in HBM" if not stream_mode else
                                  f"patches streamed from pinned host memory every step in chunks of {args.chunk}, rows copied back to "
                                  "pinned host memory (PCIe-inclusive; NOT the headline metric)",
-                       "csrc_stamp": csrc_stamp()},
+                       "gen_seconds": round(gen_s, 1), "csrc_stamp": csrc_stamp()},
             "roofline": roofline, "cpu_baseline": cpu, "also": also or None,
         }
         print(json.dumps(line), flush=True)

@@ -355,12 +355,9 @@ __global__ __launch_bounds__(256) void k_shape_from_rows(int64_t n, const uint64
 }
 
 // ---- polygon-derived columns (geometric_features::*, shape.rs:89-97) -----------------------------
-// ONE LANE PER NUCLEUS: shoelace area, ring perimeter and Andrew's monotone chain are short
-// sequential f64 loops over ~30 vertices; 64 independent nuclei per wave keep every lane busy where a
-// wave-per-nucleus hull would idle most of them.  The vertices are f32 in global memory (L1-resident, 250 B
-// per nucleus) and are widened to f64 on the fly -- exact; the sort permutation and the hull stack are BYTE
-// INDICES in a per-lane LDS slice (66 + 132 bytes), so nothing but the twelve results goes back to HBM.
-// Rings with more than 64 vertices take the same code with a global scratch slice instead.
+// polygon_one is the serial program for ONE ring (shoelace area, ring perimeter, natural merge sort, Andrew's monotone
+// chain in f64 over f32 vertices widened on the fly -- exact): the reference statement of the columns and the path of
+// rings longer than PG_MAXV vertices.  Typical rings go through k_polygon's group-parallel form below.
 struct pt { double x, y; };
 
 static __device__ __forceinline__ bool pt_less(const pt &a, const pt &b)
@@ -373,7 +370,6 @@ static __device__ __forceinline__ double cross3(const pt &o, const pt &a, const 
 }
 
 static constexpr int PG_MAXV = 64;                 // ring length served from LDS
-static constexpr int PG_SLICE = 3 * PG_MAXV + 8;   // sort permutation (V) + hull stack (2V+2), one byte each
 
 size_t polygon_scratch_bytes(int64_t n, int64_t total_vertices)
 {
@@ -501,46 +497,169 @@ static __device__ __forceinline__ void polygon_one(VP v, int V, IDX *srt, IDX *h
     }
 }
 
-static constexpr int PG_CAPV = 2432; // vertices of one wave's 64 rings kept in LDS (38 per ring on average)
+// ---- LPR lanes per ring --------------------------------------------------------------------------------------------
+// One lane per ring ran 64 different serial programs per wave (sort merges, hull pops: every lane on its own control path)
+// at 1.5 waves per SIMD: 92 % of the wave's time was waiting.  Here a ring belongs to a GROUP of LPR lanes (64 / LPR rings per
+// wave, four waves per block), so the chip holds 4-16x as many waves for the same rings and most of the work is lane-parallel:
+//   * the vertices go to LDS once (ring stride padded so the groups' rings start on different banks) and stay in the
+//     lanes' registers (lane `sub` holds vertices sub, sub + LPR, ...);
+//   * shoelace and perimeter are per-edge terms summed over the group (f64; DPP butterflies inside the row of 16);
+//   * the lexicographic sort is a RANK sort: vertex t is broadcast from LDS and every lane counts, for each of its own
+//     vertices, whether t sorts before it (ties by ring index: the permutation a stable sort gives) -- V steps of
+//     independent compares instead of a dependent merge chain; the permutation is scattered to LDS as byte indices;
+//   * only Andrew's monotone chain stays serial: the group's first lane walks it, with the top two hull points in
+//     registers (a push costs no LDS read, a pop one);
+//   * hull area and perimeter are again per-edge terms over the group.
+// Rings longer than PG_MAXV keep the serial program (polygon_one on global memory), run by their group's first lane.
+#ifndef NFX_PG_LPR
+#define NFX_PG_LPR 8
+#endif
 
-__global__ __launch_bounds__(64) void k_polygon(int64_t n, const uint32_t *__restrict__ poly_off,
-                                                const float *__restrict__ poly_xy, uint32_t *__restrict__ scratch,
-                                                float *__restrict__ out, int F, int col0, double *__restrict__ out64)
+template <int LPR>
+static __device__ __forceinline__ double group_total_f64(double v)
 {
-    // The sort and the hull walk are chains of dependent vertex reads.  From global memory (L1/L2) each link costs a few
-    // hundred cycles; the rings of the wave's 64 nuclei are therefore copied once into LDS, packed back to back (a wave
-    // scan of the ring lengths gives every lane its slice of the vertex and of the index arrays), and all further reads
-    // are LDS reads.  A wave whose rings do not all fit (more than PG_CAPV vertices in total, or a ring longer than
-    // PG_MAXV) reads them in place, with per-lane index slices of the maximum size.
-    __shared__ __attribute__((aligned(8))) uint8_t s_raw[PG_CAPV * 8 + 3 * PG_CAPV + 64 * 8];
-    static_assert(sizeof(s_raw) >= 64 * PG_SLICE, "the in-place path's index slices fit too");
-    float2 *s_xy = reinterpret_cast<float2 *>(s_raw);
-    uint8_t *s_idx = s_raw + PG_CAPV * 8;
-    const int lane = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    v += xchg<1>(v);
+    v += xchg<2>(v);
+    if constexpr (LPR >= 8) v += xchg<4>(v);
+    if constexpr (LPR >= 16) v += xchg<8>(v);
+    return v;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void k_polygon(int64_t n, const uint32_t *__restrict__ poly_off,
+                                                 const float *__restrict__ poly_xy, uint32_t *__restrict__ scratch,
+                                                 float *__restrict__ out, int F, int col0, double *__restrict__ out64)
+{
+    static_assert(LPR == 4 || LPR == 8 || LPR == 16, "a group is an aligned part of a DPP row");
+    constexpr int R = 64 / LPR;           // rings per wave
+    constexpr int E = PG_MAXV / LPR;      // vertex slots per lane
+    constexpr int RSTRIDE = PG_MAXV + 1;  // float2 per ring: 130 words, so ring g starts on bank 2g (8-byte reads: 64 banks)
+    __shared__ float2 s_pts[4][R * RSTRIDE];
+    __shared__ uint8_t s_ord[4][R][PG_MAXV];
+    __shared__ uint8_t s_hull[4][R][2 * PG_MAXV + 8];
+    __shared__ int s_m[4][R];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g = lane / LPR, sub = lane % LPR;
+    const int64_t i = ((int64_t)blockIdx.x * 4 + wv) * R + g;
     const bool live = i < n;
     const uint32_t v0 = live ? poly_off[i] : 0u;
-    const int V = live ? (int)(poly_off[i + 1] - v0) : 0;
-    const int incl = wave_inclusive_scan_i32(V);
-    const int first = incl - V;
+    const int Vraw = live ? (int)(poly_off[i + 1] - v0) : 0;
+    const bool big = Vraw > PG_MAXV;
+    const int V = big ? 0 : Vraw; // a long ring takes no part in the group work below
     const float2 *gv = reinterpret_cast<const float2 *>(poly_xy) + v0;
-    const bool packed = __all(V <= PG_MAXV && incl <= PG_CAPV); // wave-uniform
-    float *o = out ? out + i * (int64_t)F + col0 : nullptr;
-    double *o64 = out64 ? out64 + i * 7 : nullptr;
-    if (packed) {
-        for (int k = 0; k < V; ++k) s_xy[first + k] = gv[k];
-        if (!live) return;
-        uint8_t *srt = s_idx + 3 * first + 8 * lane; // V sort indices, then 2V + 2 hull slots
-        polygon_one<uint8_t, const float2 *>(s_xy + first, V, srt, srt + V, o, o64);
-    } else {
-        if (!live) return;
-        if (V <= PG_MAXV) {
-            uint8_t *srt = s_raw + lane * PG_SLICE;
-            polygon_one<uint8_t, const float2 *__restrict__>(gv, V, srt, srt + PG_MAXV, o, o64);
-        } else {
-            uint32_t *srt = scratch + 3 * (size_t)v0 + 4 * (size_t)i;
-            polygon_one<uint32_t, const float2 *__restrict__>(gv, V, srt, srt + V, o, o64);
+    float2 *pts = s_pts[wv] + g * RSTRIDE;
+    uint8_t *ord = s_ord[wv][g], *hull = s_hull[wv][g];
+    float *o = (live && out) ? out + i * (int64_t)F + col0 : nullptr;
+    double *o64 = (live && out64) ? out64 + i * 7 : nullptr;
+    const double PI = 3.14159265358979323846;
+
+    // ---- vertices: registers and LDS --------------------------------------------------------------------------------
+    float px[E], py[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int k = sub + LPR * j;
+        float2 p = make_float2(0.0f, 0.0f);
+        if (k < V) { p = gv[k]; pts[k] = p; }
+        px[j] = p.x; py[j] = p.y;
+        ord[k] = 0; // a ring with NaN coordinates has no total order: every slot of the permutation still holds a vertex index
+    }
+    wave_lds_fence();
+    // ---- shoelace + perimeter: the edge that leaves each own vertex ----------------------------------------------------
+    double sh = 0.0, perim = 0.0;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int k = sub + LPR * j;
+        if (k < V) {
+            const float2 nb = pts[k + 1 == V ? 0 : k + 1];
+            const double ax = (double)px[j], ay = (double)py[j], bx = (double)nb.x, by = (double)nb.y;
+            sh += ax * by - bx * ay;
+            const double dx = bx - ax, dy = by - ay;
+            perim += sqrt(dx * dx + dy * dy);
         }
+    }
+    sh = group_total_f64<LPR>(sh);
+    perim = group_total_f64<LPR>(perim);
+    // ---- rank sort: lexicographic (x, then y), ties by ring index ------------------------------------------------------
+    int rank[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) rank[j] = 0;
+#pragma unroll 1
+    for (int t = 0; __any(t < V); ++t) {
+        const bool valid = t < V;
+        const float2 q = pts[valid ? t : 0];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const int k = sub + LPR * j;
+            const bool before = (q.x < px[j]) || (q.x == px[j] && ((q.y < py[j]) || (q.y == py[j] && t < k)));
+            rank[j] += (valid && before) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int k = sub + LPR * j;
+        if (k < V) ord[rank[j] < V ? rank[j] : 0] = (uint8_t)k;
+    }
+    wave_lds_fence();
+    // ---- Andrew's monotone chain, one lane per ring (collinear points dropped: cross <= 0 pops) -----------------------------
+    if (sub == 0 && V > 0) {
+        auto P = [&](int idx) { const float2 f = pts[idx < V ? idx : 0]; return pt{(double)f.x, (double)f.y}; };
+        int m = 0;
+        pt h2 = {0.0, 0.0}, h1 = {0.0, 0.0}; // hull[m-2], hull[m-1] while m >= 2 / m >= 1
+        auto take = [&](int idx, int floor_m) {
+            const pt c = P(idx);
+            while (m >= floor_m && cross3(h2, h1, c) <= 0.0) {
+                --m;
+                h1 = h2;
+                if (m >= 2) h2 = P(hull[m - 2]);
+            }
+            hull[m++] = (uint8_t)idx;
+            h2 = h1;
+            h1 = c;
+        };
+        for (int k = 0; k < V; ++k) take(ord[k], 2);
+        const int lower = m + 1;
+        for (int k = V - 2; k >= 0; --k) take(ord[k], lower);
+        if (m > 1) --m;
+        s_m[wv][g] = m;
+    } else if (sub == 0) {
+        s_m[wv][g] = 0;
+    }
+    wave_lds_fence();
+    // ---- hull area and perimeter: per-edge terms over the group ------------------------------------------------------------
+    const int m = s_m[wv][g];
+    double hsh = 0.0, hperim = 0.0;
+    for (int e = sub; e < m; e += LPR) {
+        const int ia = hull[e], ib = hull[e + 1 == m ? 0 : e + 1];
+        const float2 fa = pts[ia < V ? ia : 0], fb = pts[ib < V ? ib : 0];
+        const double ax = (double)fa.x, ay = (double)fa.y, bx = (double)fb.x, by = (double)fb.y;
+        hsh += ax * by - bx * ay;
+        const double dx = bx - ax, dy = by - ay;
+        hperim += sqrt(dx * dx + dy * dy);
+    }
+    hsh = group_total_f64<LPR>(hsh);
+    hperim = group_total_f64<LPR>(hperim);
+    if (sub != 0 || !live) return;
+    if (big) { // the serial program on global memory, index scratch of the ring's own
+        uint32_t *srt = scratch + 3 * (size_t)v0 + 4 * (size_t)i;
+        polygon_one<uint32_t, const float2 *__restrict__>(gv, Vraw, srt, srt + Vraw, o, o64);
+        return;
+    }
+    const double area = fabs(sh) * 0.5;
+    const double eq_perim = 2.0 * sqrt(PI * area);
+    const double compacity = 4.0 * PI * area / (perim * perim);
+    const double harea = fabs(hsh) * 0.5;
+    const double deviation = (harea - area) / harea;
+    if (o) { // columns of the geometry block (shape.rs:116-127), rounded once
+        o[0] = (float)area;
+        o[5] = (float)perim;
+        o[6] = (float)eq_perim;
+        o[7] = (float)compacity;
+        o[9] = (float)harea;
+        o[10] = (float)deviation;
+        o[11] = (float)hperim;
+    }
+    if (o64) { // nfx_polygon_features_f64: the same seven values at geometric_features' own width
+        o64[0] = area; o64[1] = perim; o64[2] = eq_perim; o64[3] = compacity; o64[4] = harea; o64[5] = deviation; o64[6] = hperim;
     }
 }
 
@@ -571,8 +690,9 @@ hipError_t launch_polygon(nfx_ctx *ctx, int64_t n, const uint32_t *poly_off, con
 {
     if (n == 0) return hipSuccess;
     ScopedTiming t(ctx, KS_POLYGON);
-    hipLaunchKernelGGL(k_polygon, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, n, poly_off, poly_xy,
-                       reinterpret_cast<uint32_t *>(scratch), out, F, col0, out64);
+    constexpr int rings_per_block = 4 * (64 / NFX_PG_LPR);
+    hipLaunchKernelGGL(k_polygon<NFX_PG_LPR>, dim3((unsigned)((n + rings_per_block - 1) / rings_per_block)), dim3(256), 0, ctx->stream, n,
+                       poly_off, poly_xy, reinterpret_cast<uint32_t *>(scratch), out, F, col0, out64);
     return hipGetLastError();
 }
 

@@ -31,14 +31,19 @@ for seed, ps in ((1, 32), (2, 48), (4, 64)):
         rel_to_med = err.max(0) / med
         pure_rel = np.where(ok & (w != 0), err / np.abs(w), 0.0).max(0)
     col = 0
-    print(f"== ps {ps}, {n} nuclei")
+    print(f"== ps {ps}, {n} nuclei; scaled error under tests/_parity.py: {par.assert_rows_close(got, want, par.column_scales(nfx, sets, ps)):.3e} (limit 1e-5)")
     for s in sets:
         k = nfx.num_columns(s)
         sl = slice(col, col + k)
-        order = np.argsort(-rel_to_med[sl])[:6]
+        order = np.argsort(-rel_to_med[sl])[:4]
         print(f"  set {nfx.feature_set_cli_name(s)}: worst err/median {np.nanmax(rel_to_med[sl]):.3e}, worst pure relative {pure_rel[sl].max():.3e}")
         for j in order:
             c = col + j
             print(f"     {names[c]:55s} max|err| {err[:, c].max():.3e}  median|v| {med[c]:.3e}  err/median {rel_to_med[c]:.3e}  pure rel {pure_rel[c]:.3e}")
+        if s == 4:
+            for tag, sel in (("mean", slice(col, col + k, 2)), ("variance", slice(col + 1, col + k, 2))):
+                e = err[:, sel].max(0)
+                j = int(np.argmax(e))
+                print(f"     gabor {tag} columns: worst abs err {e.max():.3e} (column median {med[sel][j]:.3e}); worst err/median {np.nanmax(rel_to_med[sel]):.3e}")
         col += k
 ctx.close()

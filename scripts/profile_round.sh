@@ -1,55 +1,72 @@
 #!/bin/bash
-# Regenerates the judged evidence for one round on the GPU box (everything lands in gpurun_out/prof/):
-#   bench JSON lines (config3 default with cpu_baseline, config5, config2), rocprofv3 kernel-trace stats of the
-#   default bench command, and the FETCH_SIZE / WRITE_SIZE PMC passes (separate, as MI355X_MICROARCH.md prescribes).
-# usage: bash scripts/profile_round.sh r01
+# Regenerates the judged evidence for one round on the GPU box (everything lands in gpurun_out/prof/; copy into profiles/):
+#   <tag>_bench_default.json / <tag>_config2_bench.json   bench.py lines (default incl. `also`; configs[1])
+#   <tag>_config{3,5}_kernel_stats.csv                     rocprofv3 --kernel-trace --stats of bench.py (nfx kernels)
+#   <tag>_config{3,5}_pmc.csv                              per-kernel means of FETCH_SIZE, WRITE_SIZE and the SQ counters
+#                                                          (separate --pmc passes, as MI355X_MICROARCH.md prescribes)
+#   pmc_current.json                                       what bench.py reads: traffic per launch and VALU instructions per
+#                                                          nucleus of each workload's dominant kernel + the csrc/ stamp they
+#                                                          were taken on (bench.py prints null when the stamp does not match)
+# usage: bash scripts/profile_round.sh r02
 set -e
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 cd $ROOT
-python3 bench.py --steps 3 --warmup 1 > $OUT/${TAG}_config3_bench.json 2> $OUT/bench3.err
-python3 bench.py --workload config5 --steps 2 --warmup 1 > $OUT/${TAG}_config5_bench.json 2> $OUT/bench5.err
+python3 bench.py --steps 5 --warmup 2 > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
 python3 bench.py --workload config2 --steps 20 --warmup 3 > $OUT/${TAG}_config2_bench.json 2> $OUT/bench2.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/kt.log 2>&1
-cp "$(find $OUT/kt -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_config3_kernel_stats_full.csv
-for WL in config3; do   # config5 under --pmc spends minutes in the data generator's thousands of small dispatches
-  for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C -d $OUT/pmc_${WL}_$C --output-format csv -- python3 $ROOT/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_${WL}_$C.log 2>&1
-  done
+SQ="SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_ANY"
+for WL in config3 config5; do
+  ARGS="--workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-also"
+  rocprofv3 --kernel-trace --stats -d $OUT/kt_$WL --output-format csv -- python3 $ROOT/bench.py $ARGS > $OUT/kt_$WL.log 2>&1
+  cp "$(find $OUT/kt_$WL -name '*kernel_stats.csv' | head -1)" $OUT/${TAG}_${WL}_kernel_stats_full.csv
+  # counters only on this engine's kernels: the data generator's thousands of torch dispatches run unprofiled
+  rocprofv3 --pmc FETCH_SIZE --kernel-include-regex nfx -d $OUT/pmc_${WL}_fetch --output-format csv -- python3 $ROOT/bench.py $ARGS > $OUT/pmc_${WL}_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-include-regex nfx -d $OUT/pmc_${WL}_write --output-format csv -- python3 $ROOT/bench.py $ARGS > $OUT/pmc_${WL}_write.log 2>&1
+  rocprofv3 --pmc $SQ --kernel-include-regex nfx -d $OUT/pmc_${WL}_sq --output-format csv -- python3 $ROOT/bench.py $ARGS > $OUT/pmc_${WL}_sq.log 2>&1
+  echo "profiled $WL"
 done
 python3 - <<PY
-import csv, glob, json, collections
-out = "$OUT"; tag = "$TAG"
-# kernel stats: nfx kernels only
-rows = [r for r in csv.DictReader(open(f"{out}/{tag}_config3_kernel_stats_full.csv")) if "nfx" in r["Name"]]
-with open(f"{out}/{tag}_config3_kernel_stats.csv", "w") as f:
-    f.write("kernel,calls,total_ns,average_ns,min_ns,max_ns\n")
-    for r in rows: f.write(f"\"{r['Name'].split('(')[0]}\",{r['Calls']},{r['TotalDurationNs']},{r['AverageNs']},{r['MinNs']},{r['MaxNs']}\n")
-steps = 3  # warmup 1 + steps 2
-traffic = {}
-for wl, dom in (("config3", "glcm"),):
-    # PMC passes: mean value per launch per kernel
-    acc = collections.defaultdict(lambda: [0.0, 0])
-    for C in ("FETCH_SIZE", "WRITE_SIZE"):
-        for fn in glob.glob(f"{out}/pmc_{wl}_{C}/**/*counter_collection.csv", recursive=True):
-            per_dispatch = collections.defaultdict(float)
+import collections, csv, glob, json, sys
+sys.path.insert(0, "$ROOT")
+import bench
+out, tag = "$OUT", "$TAG"
+NUCLEI = {"config3": 1_000_000, "config5": 1_250_000}
+DOM = {"config3": "glcm", "config5": "gabor"}
+LAUNCH_SETS = 3  # warmup 1 + steps 2: every kernel ran three times per class
+doc = {"csrc_stamp": bench.csrc_stamp(),
+       "source": f"rocprofv3 --pmc (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_*) of `bench.py --workload W --steps 2 --warmup 1`, "
+                 f"scripts/profile_round.sh {tag}; traffic = (2*FETCH_SIZE + WRITE_SIZE) KB summed over every launch of the dominant kernel "
+                 "in one step (FETCH_SIZE doubled per MI355X_MICROARCH.md: gfx950 counts half of wide streaming reads; narrower reads are "
+                 "uncalibrated), valu = SQ_INSTS_VALU per nucleus"}
+for wl in ("config3", "config5"):
+    rows = [r for r in csv.DictReader(open(f"{out}/{tag}_{wl}_kernel_stats_full.csv")) if "nfx" in r["Name"]]
+    with open(f"{out}/{tag}_{wl}_kernel_stats.csv", "w") as f:
+        f.write("kernel,calls,total_ns,average_ns,min_ns,max_ns\n")
+        for r in rows:
+            f.write(f"\"{r['Name'].split('(')[0]}\",{r['Calls']},{r['TotalDurationNs']},{r['AverageNs']},{r['MinNs']},{r['MaxNs']}\n")
+    acc = collections.defaultdict(lambda: [0.0, 0])   # (counter, kernel) -> [sum, dispatches]
+    for sub in ("fetch", "write", "sq"):
+        for fn in glob.glob(f"{out}/pmc_{wl}_{sub}/**/*counter_collection.csv", recursive=True):
+            per = collections.defaultdict(float)
             for r in csv.DictReader(open(fn)):
-                if r["Counter_Name"] == C and "nfx" in r["Kernel_Name"]:
-                    per_dispatch[(r["Dispatch_Id"], r["Kernel_Name"].split("(")[0])] += float(r["Counter_Value"])
-            for (d, k), v in per_dispatch.items():
-                acc[(C, k)][0] += v; acc[(C, k)][1] += 1
-    with open(f"{out}/{tag}_{wl}_pmc_fetch_write.csv", "w") as f:
-        f.write("counter,kernel,launches,\"mean_value_per_launch (KB; rocprofv3 --pmc, separate passes)\"\n")
-        for (C, k), (v, n) in sorted(acc.items()): f.write(f"{C},\"{k}\",{n},{v / n}\n")
-    # the dominant kernel's traffic per step (every launch that belongs to it); FETCH doubled per the gfx950 note
-    fetch = sum(v for (C, k), (v, n) in acc.items() if C == "FETCH_SIZE" and dom in k) / steps
-    write = sum(v for (C, k), (v, n) in acc.items() if C == "WRITE_SIZE" and dom in k) / steps
-    traffic[wl] = {"kernel": "k_" + dom, "traffic_bytes_per_launch": int((2 * fetch + write) * 1024),
-        "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), profiles/{tag}_{wl}_pmc_fetch_write.csv; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over every k_{dom}* launch of one step; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts half of 16-B/lane streams; narrower reads are uncalibrated)"}
-json.dump(traffic, open(f"{out}/{tag}_pmc_traffic.json", "w"), indent=1)
-print(open(f"{out}/{tag}_config3_kernel_stats.csv").read()); print(json.dumps(traffic)[:600])
+                per[(r["Counter_Name"], r["Dispatch_Id"], r["Kernel_Name"].split("(")[0])] += float(r["Counter_Value"])
+            for (c, d, k), v in per.items():
+                acc[(c, k)][0] += v
+                acc[(c, k)][1] += 1
+    with open(f"{out}/{tag}_{wl}_pmc.csv", "w") as f:
+        f.write("counter,kernel,dispatches,mean_per_dispatch,per_nucleus_per_step\n")
+        for (c, k), (v, n) in sorted(acc.items()):
+            f.write(f"{c},\"{k}\",{n},{v / n:.6g},{v / LAUNCH_SETS / NUCLEI[wl]:.6g}\n")
+    dom = DOM[wl]
+    tot = lambda c: sum(v for (cc, k), (v, n) in acc.items() if cc == c and ("k_" + dom) in k) / LAUNCH_SETS
+    doc[wl] = {"kernel": "k_" + dom, "traffic_bytes_per_launch": int((2 * tot("FETCH_SIZE") + tot("WRITE_SIZE")) * 1024),
+               "valu_insts_per_nucleus": round(tot("SQ_INSTS_VALU") / NUCLEI[wl], 1),
+               "lds_addr_conflict_over_idx_active": round(tot("SQ_LDS_ADDR_CONFLICT") / max(1.0, tot("SQ_LDS_IDX_ACTIVE")), 4),
+               "lds_bank_conflict_over_idx_active": round(tot("SQ_LDS_BANK_CONFLICT") / max(1.0, tot("SQ_LDS_IDX_ACTIVE")), 4)}
+json.dump(doc, open(f"{out}/pmc_current.json", "w"), indent=1)
+print(json.dumps(doc, indent=1))
 PY
-tail -n 1 $OUT/${TAG}_config3_bench.json $OUT/${TAG}_config5_bench.json $OUT/${TAG}_config2_bench.json
+tail -c 400 $OUT/${TAG}_bench_default.json; echo; tail -c 300 $OUT/${TAG}_config2_bench.json

@@ -7,12 +7,25 @@ import _oracle as orc
 
 PKG = "nuclei-feature-extraction_amd"
 
-# natural magnitude of each column, used as the absolute floor of the relative tolerance
-# (|a-b| <= RTOL * max(|b|, scale)); north_star: 1e-5 relative for float features.
+# Tolerance: north_star asks for 1e-5 RELATIVE on float features, bit-exact on integer/count features.
+#   |got - want| <= RTOL * max(|want|, floor_c)
+# floor_c keeps a column's near-zero entries from demanding more digits than its arithmetic has.  It is the SMALLER of
+#   * the column's natural magnitude (`column_scales`, from the feature's definition: an upper bound, never raised), and
+#   * the column's median |value| over the batch under test (data-driven; batches of >= 16 rows), but not less than
+#     GUARD x the natural magnitude (an all-zero column of a degenerate batch would otherwise have no floor at all).
+# Measured on MI355X (scripts/err_profile.py, 3 x 3000 nuclei): geometry and GLRLM columns agree with the oracle bit for
+# bit; colour and GLCM columns to <= 6.5e-7 of the VALUE itself; Gabor means carry an absolute error of <= 5.2e-7 whatever
+# their size -- they are f32 correlations of 900 taps with sum |w| = 163 (orc_gabor_bank), whose own rounding noise
+# (eps x sum |w||x| ~ 5e-6; the reference's f32 conv2d has it too) is ten times that -- so their floor is an absolute one:
+# 0.5 for the means (tolerance 5e-6), 5 for the variances.
+# Integer-derived columns are additionally compared with == (exact_cols) and the texture counts in test_counts_gpu.py.
 RTOL = 1e-5
+GUARD = 1e-3
+MIN_ROWS_FOR_DATA_FLOOR = 16
 
 
 def column_scales(nfx, sets, ps):
+    """natural magnitude of every column (upper bound of the tolerance floor)"""
     sc = []
     for s in sets:
         names = nfx.column_names(s)
@@ -35,9 +48,26 @@ def column_scales(nfx, sets, ps):
                 if nm.startswith("long_run"): v *= 4.0
                 if "nonuniformity" in nm: v = 10.0
             else:
-                v = 50.0 if nm.endswith("_mean") else 2500.0
+                v = 0.5 if nm.endswith("_mean") else 5.0
             sc.append(v)
     return np.asarray(sc, np.float64)
+
+
+def tolerance_floors(want, scales, gabor_cols=None):
+    """per-column floor of the relative tolerance: min(natural magnitude, max(median |want|, GUARD x natural magnitude));
+    columns flagged in gabor_cols keep their absolute floor (see the header)."""
+    want = np.asarray(want, np.float64)
+    floors = np.array(scales, np.float64, copy=True)
+    if want.shape[0] < MIN_ROWS_FOR_DATA_FLOOR:
+        return floors
+    for c in range(want.shape[1]):
+        if gabor_cols is not None and gabor_cols[c]:
+            continue
+        col = np.abs(want[:, c])
+        col = col[np.isfinite(col)]
+        if col.size >= MIN_ROWS_FOR_DATA_FLOOR:
+            floors[c] = min(floors[c], max(float(np.median(col)), GUARD * floors[c]))
+    return floors
 
 
 def make_inputs(seed_idx, n, ps, with_patches=True):
@@ -48,7 +78,9 @@ def make_inputs(seed_idx, n, ps, with_patches=True):
     return off, xy, pu8
 
 
-def assert_rows_close(got, want, scales, exact_cols=(), rtol=RTOL, what=""):
+def assert_rows_close(got, want, scales, exact_cols=(), rtol=RTOL, what="", labels=None):
+    """Every finite entry within rtol * max(|want|, floor); NaN patterns identical; exact_cols bit-identical.
+    Returns the worst error in units of the tolerance floor ("scaled") -- `worst_relative` gives the unscaled figure."""
     got = np.asarray(got, np.float64)
     want = np.asarray(want, np.float64)
     assert got.shape == want.shape, (got.shape, want.shape)
@@ -56,13 +88,32 @@ def assert_rows_close(got, want, scales, exact_cols=(), rtol=RTOL, what=""):
     assert np.array_equal(nan_g, nan_w), f"{what}: NaN pattern differs at {np.argwhere(nan_g != nan_w)[:5]}"
     g = np.where(nan_g, 0.0, got)
     w = np.where(nan_w, 0.0, want)
-    err = np.abs(g - w) / np.maximum(np.abs(w), scales[None, :])
+    scales = np.asarray(scales, np.float64)
+    gabor = np.isin(scales, (0.5, 5.0)) if scales.size >= 96 else None   # the Gabor block's absolute floors (column_scales)
+    floors = tolerance_floors(want, scales, gabor)
+    with np.errstate(invalid="ignore"):
+        err = np.abs(g - w) / np.maximum(np.abs(w), floors[None, :])
+    err = np.where(np.isfinite(err), err, np.where(g == w, 0.0, np.inf))     # +-inf on both sides is agreement
     bad = np.argwhere(err > rtol)
-    assert bad.size == 0, f"{what}: {len(bad)} mismatches, worst {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}; first {bad[:5].tolist()}"
+    if bad.size:
+        r, c = np.unravel_index(err.argmax(), err.shape)
+        where = f" ({labels[r]})" if labels is not None else ""
+        raise AssertionError(f"{what}: {len(bad)} mismatches, worst {err.max():.3e} at row {r}{where} col {c}: got {got[r, c]!r} want {want[r, c]!r} "
+                             f"floor {floors[c]:.3g}; first {bad[:5].tolist()}")
     for c in exact_cols:
         neq = np.argwhere(~((got[:, c] == want[:, c]) | (nan_g[:, c] & nan_w[:, c])))
         assert neq.size == 0, f"{what}: exact column {c} differs at rows {neq[:5].ravel().tolist()}"
     return float(err.max()) if err.size else 0.0
+
+
+def worst_relative(got, want):
+    """worst |got - want| / |want| over finite, non-zero reference entries: the UNSCALED relative error"""
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    ok = np.isfinite(got) & np.isfinite(want) & (want != 0.0)
+    if not ok.any():
+        return 0.0
+    return float((np.abs(got[ok] - want[ok]) / np.abs(want[ok])).max())
 
 
 def edge_case_rings(ps):

@@ -76,9 +76,7 @@ def test_boundary_rings_match_the_oracle(nfx, ctx, ps):
     want, wcen = orc.extract(sets, off, xy, pu8, ps, batch_size=16)
     got, gcen = ctx.extract(sets, off, xy, pu8, ps, batch_size=16)
     assert np.array_equal(gcen, wcen, equal_nan=True)
-    scales = par.column_scales(nfx, sets, ps)
-    for i, nm in enumerate(names):
-        par.assert_rows_close(got[i:i + 1], want[i:i + 1], scales, exact_cols=(0,), what=f"ps={ps} {nm}")
+    par.assert_rows_close(got, want, par.column_scales(nfx, sets, ps), exact_cols=(1, 2, 3, 8), what=f"ps={ps}", labels=names)
 
 
 @pytest.mark.parametrize("ps", [32, 48, 64])
@@ -111,6 +109,5 @@ def test_random_rings_of_any_shape(nfx, ctx, ps):
     want, wcen = orc.extract(sets, off, xy, pu8, ps, batch_size=50, threads=8)
     got, gcen = ctx.extract(sets, off, xy, pu8, ps, batch_size=50)
     assert np.array_equal(gcen, wcen, equal_nan=True)
-    scales = par.column_scales(nfx, sets, ps)
-    for i in range(n):
-        par.assert_rows_close(got[i:i + 1], want[i:i + 1], scales, exact_cols=(0,), what=f"ps={ps} random ring {i} (V={len(ring_list[i])})")
+    par.assert_rows_close(got, want, par.column_scales(nfx, sets, ps), exact_cols=(1, 2, 3, 8), what=f"ps={ps} random rings",
+                          labels=[f"ring {i}, V={len(ring_list[i])}" for i in range(n)])

@@ -69,9 +69,7 @@ def test_extreme_textures_match_the_oracle(nfx, ctx, ps):
     want, wcen = orc.extract(sets, off, xy, pu8, ps, batch_size=batch)
     got, gcen = ctx.extract(sets, off, xy, pu8, ps, batch_size=batch)
     assert np.array_equal(gcen, wcen, equal_nan=True)
-    scales = par.column_scales(nfx, sets, ps)
-    for i, nm in enumerate(names):  # report by texture
-        par.assert_rows_close(got[i:i + 1], want[i:i + 1], scales, what=f"ps={ps} {nm}")
+    par.assert_rows_close(got, want, par.column_scales(nfx, sets, ps), what=f"ps={ps}", labels=names)  # failures name the texture
     # the counting features of a constant patch under the full mask are known in closed form: one cell, p = 1
     cols = nfx.all_column_names(sets)[1:]
     i = names.index("constant 127 / ring 0")
@@ -105,6 +103,4 @@ def test_extreme_textures_through_the_trait_entry(nfx, ctx, ps):
     for set_id in range(5):
         want = orc.compute_features_batched(set_id, off, ctr, patchs, masks[:, 0])
         got = ctx.compute_features_batched(set_id, off, ctr, patchs, masks)
-        scales = par.column_scales(nfx, [set_id], ps)
-        for i, nm in enumerate(names):
-            par.assert_rows_close(got[i:i + 1], want[i:i + 1], scales, what=f"trait {nfx.feature_set_cli_name(set_id)} ps={ps} {nm}")
+        par.assert_rows_close(got, want, par.column_scales(nfx, [set_id], ps), what=f"trait {nfx.feature_set_cli_name(set_id)} ps={ps}", labels=names)
