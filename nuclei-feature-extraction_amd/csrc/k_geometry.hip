@@ -16,6 +16,8 @@
 // Compiled with -ffp-contract=off: the mask bits and the ellipse XOR count are integer results
 // that must match the CPU oracle bit for bit, so the f64/f32 expression trees below are
 // evaluated exactly as written.
+#include <type_traits>
+
 #include "nfx_internal.h"
 #include "wave_ops.h"
 
@@ -507,8 +509,8 @@ static __device__ __forceinline__ void polygon_one(VP v, int V, IDX *srt, IDX *h
 //   * the lexicographic sort is a RANK sort: vertex t is broadcast from LDS and every lane counts, for each of its own
 //     vertices, whether t sorts before it (ties by ring index: the permutation a stable sort gives) -- V steps of
 //     independent compares instead of a dependent merge chain; the permutation is scattered to LDS as byte indices;
-//   * only Andrew's monotone chain stays serial: the group's first lane walks it, with the top two hull points in
-//     registers (a push costs no LDS read, a pop one);
+//   * only Andrew's monotone chain stays serial: two lanes of the group walk its lower and its upper chain side by side,
+//     with the top two hull points in registers (a push costs no LDS read, a pop one);
 //   * hull area and perimeter are again per-edge terms over the group.
 // Rings longer than PG_MAXV keep the serial program (polygon_one on global memory), run by their group's first lane.
 #ifndef NFX_PG_LPR
@@ -536,8 +538,8 @@ __global__ __launch_bounds__(256) void k_polygon(int64_t n, const uint32_t *__re
     constexpr int RSTRIDE = PG_MAXV + 1;  // float2 per ring: 130 words, so ring g starts on bank 2g (8-byte reads: 64 banks)
     __shared__ float2 s_pts[4][R * RSTRIDE];
     __shared__ uint8_t s_ord[4][R][PG_MAXV];
-    __shared__ uint8_t s_hull[4][R][2 * PG_MAXV + 8];
-    __shared__ int s_m[4][R];
+    __shared__ uint8_t s_hull[4][R][2][PG_MAXV + 4]; // lower chain | upper chain
+    __shared__ int s_m[4][R][2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int g = lane / LPR, sub = lane % LPR;
     const int64_t i = ((int64_t)blockIdx.x * 4 + wv) * R + g;
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(256) void k_polygon(int64_t n, const uint32_t *__re
     const int V = big ? 0 : Vraw; // a long ring takes no part in the group work below
     const float2 *gv = reinterpret_cast<const float2 *>(poly_xy) + v0;
     float2 *pts = s_pts[wv] + g * RSTRIDE;
-    uint8_t *ord = s_ord[wv][g], *hull = s_hull[wv][g];
+    uint8_t *ord = s_ord[wv][g];
     float *o = (live && out) ? out + i * (int64_t)F + col0 : nullptr;
     double *o64 = (live && out64) ? out64 + i * 7 : nullptr;
     const double PI = 3.14159265358979323846;
@@ -564,50 +566,67 @@ __global__ __launch_bounds__(256) void k_polygon(int64_t n, const uint32_t *__re
         ord[k] = 0; // a ring with NaN coordinates has no total order: every slot of the permutation still holds a vertex index
     }
     wave_lds_fence();
-    // ---- shoelace + perimeter: the edge that leaves each own vertex ----------------------------------------------------
+    // Most rings are short: when every ring of the wave fits into half of the slots, the per-slot loops below run over that half
+    const bool half = !__any(V > LPR * (E / 2)); // wave-uniform
     double sh = 0.0, perim = 0.0;
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const int k = sub + LPR * j;
-        if (k < V) {
-            const float2 nb = pts[k + 1 == V ? 0 : k + 1];
-            const double ax = (double)px[j], ay = (double)py[j], bx = (double)nb.x, by = (double)nb.y;
-            sh += ax * by - bx * ay;
-            const double dx = bx - ax, dy = by - ay;
-            perim += sqrt(dx * dx + dy * dy);
-        }
-    }
-    sh = group_total_f64<LPR>(sh);
-    perim = group_total_f64<LPR>(perim);
-    // ---- rank sort: lexicographic (x, then y), ties by ring index ------------------------------------------------------
     int rank[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) rank[j] = 0;
-#pragma unroll 1
-    for (int t = 0; __any(t < V); ++t) {
-        const bool valid = t < V;
-        const float2 q = pts[valid ? t : 0];
+    auto slots = [&](auto ee_tag) {
+        constexpr int EE = decltype(ee_tag)::value;
+        // ---- shoelace + perimeter: the edge that leaves each own vertex ------------------------------------------------
 #pragma unroll
-        for (int j = 0; j < E; ++j) {
+        for (int j = 0; j < EE; ++j) {
             const int k = sub + LPR * j;
-            const bool before = (q.x < px[j]) || (q.x == px[j] && ((q.y < py[j]) || (q.y == py[j] && t < k)));
-            rank[j] += (valid && before) ? 1 : 0;
+            if (k < V) {
+                const float2 nb = pts[k + 1 == V ? 0 : k + 1];
+                const double ax = (double)px[j], ay = (double)py[j], bx = (double)nb.x, by = (double)nb.y;
+                sh += ax * by - bx * ay;
+                const double dx = bx - ax, dy = by - ay;
+                perim += sqrt(dx * dx + dy * dy);
+            }
         }
-    }
+        // ---- rank sort: lexicographic (x, then y), ties by ring index --------------------------------------------------
+#pragma unroll 1
+        for (int t = 0; __any(t < V); ++t) {
+            const bool valid = t < V;
+            const float2 q = pts[valid ? t : 0];
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const int k = sub + LPR * j;
-        if (k < V) ord[rank[j] < V ? rank[j] : 0] = (uint8_t)k;
-    }
+            for (int j = 0; j < EE; ++j) {
+                const int k = sub + LPR * j;
+                const bool before = (q.x < px[j]) || (q.x == px[j] && ((q.y < py[j]) || (q.y == py[j] && t < k)));
+                rank[j] += (valid && before) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < EE; ++j) {
+            const int k = sub + LPR * j;
+            if (k < V) ord[rank[j] < V ? rank[j] : 0] = (uint8_t)k;
+        }
+    };
+    if (half) slots(std::integral_constant<int, E / 2>{});
+    else slots(std::integral_constant<int, E>{});
+    sh = group_total_f64<LPR>(sh);
+    perim = group_total_f64<LPR>(perim);
     wave_lds_fence();
-    // ---- Andrew's monotone chain, one lane per ring (collinear points dropped: cross <= 0 pops) -----------------------------
-    if (sub == 0 && V > 0) {
+    // ---- Andrew's monotone chain (collinear points dropped: cross <= 0 pops) ---------------------------------------------
+    // Two lanes per ring: lane 0 walks the lower chain over the sorted points first -> last, lane 1 the upper chain last -> first.
+    // The single-stack form (polygon_one) never pops its upper chain below the lower chain's last point, so the two chains are
+    // independent stacks: the hull is lower + upper without the upper chain's two end points, and its edges are the consecutive
+    // pairs of the two chains.  Top two hull points in registers (a push costs no LDS read, a pop one); the next sorted point is
+    // requested before the current one is worked on.
+    if (sub < 2 && V > 0) {
+        uint8_t *hull = s_hull[wv][g][sub];
         auto P = [&](int idx) { const float2 f = pts[idx < V ? idx : 0]; return pt{(double)f.x, (double)f.y}; };
+        const int first = sub == 0 ? 0 : V - 1, step = sub == 0 ? 1 : -1;
         int m = 0;
-        pt h2 = {0.0, 0.0}, h1 = {0.0, 0.0}; // hull[m-2], hull[m-1] while m >= 2 / m >= 1
-        auto take = [&](int idx, int floor_m) {
-            const pt c = P(idx);
-            while (m >= floor_m && cross3(h2, h1, c) <= 0.0) {
+        pt h2 = {0.0, 0.0}, h1 = {0.0, 0.0}; // hull[m-2], hull[m-1]
+        int idx = ord[first];
+        pt c = P(idx);
+        for (int k = 0; k < V; ++k) {
+            const int idx_next = ord[k + 1 < V ? first + step * (k + 1) : first];
+            const pt c_next = P(idx_next);
+            while (m >= 2 && cross3(h2, h1, c) <= 0.0) {
                 --m;
                 h1 = h2;
                 if (m >= 2) h2 = P(hull[m - 2]);
@@ -615,26 +634,28 @@ __global__ __launch_bounds__(256) void k_polygon(int64_t n, const uint32_t *__re
             hull[m++] = (uint8_t)idx;
             h2 = h1;
             h1 = c;
-        };
-        for (int k = 0; k < V; ++k) take(ord[k], 2);
-        const int lower = m + 1;
-        for (int k = V - 2; k >= 0; --k) take(ord[k], lower);
-        if (m > 1) --m;
-        s_m[wv][g] = m;
-    } else if (sub == 0) {
-        s_m[wv][g] = 0;
+            idx = idx_next;
+            c = c_next;
+        }
+        s_m[wv][g][sub] = m;
+    } else if (sub < 2) {
+        s_m[wv][g][sub] = 0;
     }
     wave_lds_fence();
-    // ---- hull area and perimeter: per-edge terms over the group ------------------------------------------------------------
-    const int m = s_m[wv][g];
+    // ---- hull area and perimeter: per-edge terms of both chains over the group ----------------------------------------------
     double hsh = 0.0, hperim = 0.0;
-    for (int e = sub; e < m; e += LPR) {
-        const int ia = hull[e], ib = hull[e + 1 == m ? 0 : e + 1];
-        const float2 fa = pts[ia < V ? ia : 0], fb = pts[ib < V ? ib : 0];
-        const double ax = (double)fa.x, ay = (double)fa.y, bx = (double)fb.x, by = (double)fb.y;
-        hsh += ax * by - bx * ay;
-        const double dx = bx - ax, dy = by - ay;
-        hperim += sqrt(dx * dx + dy * dy);
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        const int m = s_m[wv][g][ch];
+        const uint8_t *hull = s_hull[wv][g][ch];
+        for (int e = sub; e + 1 < m; e += LPR) {
+            const int ia = hull[e], ib = hull[e + 1];
+            const float2 fa = pts[ia < V ? ia : 0], fb = pts[ib < V ? ib : 0];
+            const double ax = (double)fa.x, ay = (double)fa.y, bx = (double)fb.x, by = (double)fb.y;
+            hsh += ax * by - bx * ay;
+            const double dx = bx - ax, dy = by - ay;
+            hperim += sqrt(dx * dx + dy * dy);
+        }
     }
     hsh = group_total_f64<LPR>(hsh);
     hperim = group_total_f64<LPR>(hperim);

@@ -118,6 +118,15 @@ void append_float(std::string &s, float v, bool json)
     s.append(buf, r.ptr);
 }
 
+void append_double(std::string &s, double v, bool json)
+{
+    if (std::isnan(v)) { s += json ? "null" : "NaN"; return; }
+    if (std::isinf(v)) { s += json ? "null" : (v < 0 ? "-inf" : "inf"); return; }
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof buf, v); // shortest round-trip of the f64
+    s.append(buf, r.ptr);
+}
+
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 }  // namespace
@@ -201,6 +210,21 @@ int main(int argc, char **argv)
         for (int s : sets) F += nfx_feature_set_num_columns(s);
         const int64_t n = (int64_t)poly.size();
         std::vector<float> rows((size_t)n * F), cen((size_t)n * 2);
+        // columns the reference's frame holds as f64 (shape.rs:116-127: geometric_features' own return values): kept at that
+        // width in every output format.  wide[j] = column of `wide_rows` that feature column j comes from, -1 for f32 columns
+        std::vector<int> wide((size_t)F, -1);
+        bool any_wide = false;
+        {
+            int col = 0;
+            for (int s : sets) {
+                int k = 0;
+                for (int j = 0; j < nfx_feature_set_num_columns(s); ++j)
+                    if (nfx_feature_set_column_dtype(s, j) == NFX_DTYPE_F64) { wide[(size_t)(col + j)] = k++; any_wide = true; } // a repeated geometry set shares the seven
+                col += nfx_feature_set_num_columns(s);
+            }
+        }
+        const int W = 7;
+        std::vector<double> wide_rows(any_wide ? (size_t)n * W : 0);
         log_info("Extracting features");
         t0 = now_s();
         // index shards on reference-batch boundaries, one per GPU
@@ -218,7 +242,15 @@ int main(int argc, char **argv)
                 const nfx_status st = nfx_extract_tile(ctxs[(size_t)r], sets.data(), n_sets, i1 - i0, off.back(), off.data(),
                                                        poly.ring_xy.data() + 2 * (size_t)base, img.data.data(), img.H, img.W, args.patch_size,
                                                        args.batch_size, rows.data() + (size_t)i0 * F, cen.data() + 2 * (size_t)i0, NFX_MEM_HOST);
-                if (st != NFX_OK) errs[(size_t)r] = nfx_last_error(ctxs[(size_t)r]);
+                if (st != NFX_OK) { errs[(size_t)r] = nfx_last_error(ctxs[(size_t)r]); return; }
+                if (any_wide) { // the polygon columns once more, unrounded (preprocess_polygon + geometric_features::*, utils.rs:54-74, shape.rs:89-97)
+                    std::vector<float> centred(2 * (size_t)off.back());
+                    nfx_status s2 = nfx_preprocess_polygons(ctxs[(size_t)r], i1 - i0, off.back(), off.data(), poly.ring_xy.data() + 2 * (size_t)base,
+                                                            nullptr, centred.data(), NFX_MEM_HOST);
+                    if (s2 == NFX_OK)
+                        s2 = nfx_polygon_features_f64(ctxs[(size_t)r], i1 - i0, off.back(), off.data(), centred.data(), wide_rows.data() + (size_t)i0 * W, NFX_MEM_HOST);
+                    if (s2 != NFX_OK) errs[(size_t)r] = nfx_last_error(ctxs[(size_t)r]);
+                }
             });
         }
         for (auto &t : th) t.join();
@@ -254,11 +286,19 @@ int main(int argc, char **argv)
                     nfx_centroid_key(cen[2 * (size_t)i], cen[2 * (size_t)i + 1], key, sizeof key);
                     if (json) { // json lines: one object per row
                         text += "{\"centroid\":\""; text += key; text += '"';
-                        for (int j = 0; j < F; ++j) { text += ",\""; text += header[(size_t)j + 1]; text += "\":"; append_float(text, rows[(size_t)i * F + j], true); }
+                        for (int j = 0; j < F; ++j) {
+                            text += ",\""; text += header[(size_t)j + 1]; text += "\":";
+                            if (wide[(size_t)j] >= 0) append_double(text, wide_rows[(size_t)i * W + wide[(size_t)j]], true);
+                            else append_float(text, rows[(size_t)i * F + j], true);
+                        }
                         text += "}\n";
                     } else {
                         text += '"'; text += key; text += '"'; // the key contains a comma
-                        for (int j = 0; j < F; ++j) { text += ','; append_float(text, rows[(size_t)i * F + j], false); }
+                        for (int j = 0; j < F; ++j) {
+                            text += ',';
+                            if (wide[(size_t)j] >= 0) append_double(text, wide_rows[(size_t)i * W + wide[(size_t)j]], false);
+                            else append_float(text, rows[(size_t)i * F + j], false);
+                        }
                         text += '\n';
                     }
                 }
@@ -288,7 +328,8 @@ int main(int argc, char **argv)
                 nfx_centroid_key(cen[2 * (size_t)i], cen[2 * (size_t)i + 1], key, sizeof key);
                 keys[(size_t)i] = key;
             }
-            const FeatureTable table{&header, &keys, rows.data(), n, F};
+            FeatureTable table{&header, &keys, rows.data(), n, F};
+            if (any_wide) { table.wide = wide.data(); table.wide_rows = wide_rows.data(); table.W = W; }
             if (oext == "parquet" || oext == "pqt") write_parquet(fo, table);
             else write_arrow_ipc(fo, table);
         }

@@ -2,11 +2,12 @@
 //
 // The reference hands its DataFrame to polars' ParquetWriter / IpcWriter by output extension
 // (main.rs:169-180: "parquet" | "pqt", "ipc" | "feather"). The table here is always one string column
-// (`centroid`) followed by F float32 columns, which is all these writers support:
+// (`centroid`) followed by F numeric columns -- float32, except the columns the reference's frame holds as float64
+// (the seven polygon columns of the geometry set, shape.rs:116-127: `wide`) -- which is all these writers support:
 //   * Parquet: format version 1, one row group per 131072 rows, one uncompressed PLAIN data page per column
 //     chunk, REQUIRED fields (the table has no nulls; NaN stays NaN), `centroid` BYTE_ARRAY annotated UTF8/STRING.
 //     Metadata is Thrift compact protocol, written by the small encoder below.
-//   * Arrow IPC file: metadata V5, little endian, `centroid` Utf8 (int32 offsets), features FloatingPoint(SINGLE),
+//   * Arrow IPC file: metadata V5, little endian, `centroid` Utf8 (int32 offsets), features FloatingPoint(SINGLE | DOUBLE),
 //     one record batch per 131072 rows, no compression, no dictionaries. Messages are FlatBuffers, written by
 //     the small back-to-front builder below.
 // Both files are read back by pyarrow in tests/test_cli.py. The input is the row-major [n, F] block the engine
@@ -30,6 +31,11 @@ struct FeatureTable {
     const float *rows;                     // [n, F] row-major
     int64_t n;
     int F;
+    // columns the reference emits as f64 (nfx_feature_set_column_dtype): wide[c] = index into wide_rows' columns, -1 for f32
+    const int *wide = nullptr;             // [F] or null (all f32)
+    const double *wide_rows = nullptr;     // [n, W] row-major
+    int W = 0;
+    int wide_of(int c) const { return wide ? wide[c] : -1; } // c: feature column, 0-based
 };
 
 class FileSink {
@@ -94,7 +100,7 @@ class ThriftCompact {
 
 inline void write_parquet(FILE *f, const FeatureTable &t)
 {
-    enum { T_FLOAT = 4, T_BYTE_ARRAY = 6, ENC_PLAIN = 0, ENC_RLE = 3, PAGE_DATA = 0, REP_REQUIRED = 0, CONV_UTF8 = 0 };
+    enum { T_FLOAT = 4, T_DOUBLE = 5, T_BYTE_ARRAY = 6, ENC_PLAIN = 0, ENC_RLE = 3, PAGE_DATA = 0, REP_REQUIRED = 0, CONV_UTF8 = 0 };
     struct Chunk { int64_t offset, bytes, values; };
     struct Group { std::vector<Chunk> cols; int64_t rows, bytes; };
     FileSink sink(f);
@@ -114,6 +120,11 @@ inline void write_parquet(FILE *f, const FeatureTable &t)
                     page.append(reinterpret_cast<const char *>(&len), 4);
                     page += k;
                 }
+            } else if (t.wide_of(c - 1) >= 0) {
+                page.resize((size_t)rows * 8);
+                double *dst = reinterpret_cast<double *>(&page[0]);
+                const double *src = t.wide_rows + (size_t)r0 * t.W + t.wide_of(c - 1);
+                for (int64_t i = 0; i < rows; ++i) dst[i] = src[(size_t)i * t.W];
             } else {
                 page.resize((size_t)rows * 4);
                 float *dst = reinterpret_cast<float *>(&page[0]);
@@ -150,7 +161,7 @@ inline void write_parquet(FILE *f, const FeatureTable &t)
     m.end_struct();
     for (int c = 0; c < ncol; ++c) {
         m.elem_struct();
-        m.i32(1, c == 0 ? T_BYTE_ARRAY : T_FLOAT);
+        m.i32(1, c == 0 ? T_BYTE_ARRAY : (t.wide_of(c - 1) >= 0 ? T_DOUBLE : T_FLOAT));
         m.i32(3, REP_REQUIRED);
         m.str(4, (*t.names)[(size_t)c]);
         if (c == 0) {
@@ -172,7 +183,7 @@ inline void write_parquet(FILE *f, const FeatureTable &t)
             m.elem_struct(); // ColumnChunk
             m.i64(2, ch.offset);
             m.struct_field(3); // ColumnMetaData
-            m.i32(1, c == 0 ? T_BYTE_ARRAY : T_FLOAT);
+            m.i32(1, c == 0 ? T_BYTE_ARRAY : (t.wide_of(c - 1) >= 0 ? T_DOUBLE : T_FLOAT));
             m.list_field(2, 5, 2);
             m.elem_i32(ENC_PLAIN);
             m.elem_i32(ENC_RLE);
@@ -278,7 +289,7 @@ class FlatBuilder {
 };
 
 namespace arrowfb {
-enum { V5 = 4, HDR_SCHEMA = 1, HDR_RECORD_BATCH = 3, TYPE_FLOATING_POINT = 3, TYPE_UTF8 = 5, PRECISION_SINGLE = 1 };
+enum { V5 = 4, HDR_SCHEMA = 1, HDR_RECORD_BATCH = 3, TYPE_FLOATING_POINT = 3, TYPE_UTF8 = 5, PRECISION_SINGLE = 1, PRECISION_DOUBLE = 2 };
 
 inline FlatBuilder::Off schema(FlatBuilder &b, const FeatureTable &t)
 {
@@ -287,7 +298,7 @@ inline FlatBuilder::Off schema(FlatBuilder &b, const FeatureTable &t)
         const FlatBuilder::Off name = b.string((*t.names)[(size_t)c]);
         const FlatBuilder::Off children = b.offset_vector({});
         b.start_table(); // Utf8 {} or FloatingPoint { precision }
-        if (c > 0) b.add_i16(0, PRECISION_SINGLE);
+        if (c > 0) b.add_i16(0, t.wide_of(c - 1) >= 0 ? PRECISION_DOUBLE : PRECISION_SINGLE);
         const FlatBuilder::Off type = b.end_table();
         b.start_table(); // Field
         b.add_offset(0, name);
@@ -339,6 +350,7 @@ inline void write_arrow_ipc(FILE *f, const FeatureTable &t)
     std::vector<int32_t> offsets;
     std::string chars;
     std::vector<float> column;
+    std::vector<double> wide_column;
     for (int64_t r0 = 0; r0 < t.n; r0 += kRowGroup) {
         const int64_t rows = std::min(kRowGroup, t.n - r0);
         offsets.assign((size_t)rows + 1, 0);
@@ -360,8 +372,9 @@ inline void write_arrow_ipc(FILE *f, const FeatureTable &t)
         for (int c = 0; c < t.F; ++c) {
             nodes.insert(nodes.end(), {rows, 0});
             buffers.insert(buffers.end(), {at, 0});
-            buffers.insert(buffers.end(), {at, rows * 4});
-            at += pad8(rows * 4);
+            const int64_t width = t.wide_of(c) >= 0 ? 8 : 4;
+            buffers.insert(buffers.end(), {at, rows * width});
+            at += pad8(rows * width);
         }
         FlatBuilder b;
         const FlatBuilder::Off bv = b.struct_vector(buffers, 2);
@@ -379,10 +392,17 @@ inline void write_arrow_ipc(FILE *f, const FeatureTable &t)
         sink.write(chars.data(), chars.size());
         sink.pad_to(8);
         column.resize((size_t)rows);
+        wide_column.resize((size_t)rows);
         for (int c = 0; c < t.F; ++c) {
-            const float *src = t.rows + (size_t)r0 * t.F + c;
-            for (int64_t i = 0; i < rows; ++i) column[(size_t)i] = src[(size_t)i * t.F];
-            sink.write(column.data(), (size_t)rows * 4);
+            if (t.wide_of(c) >= 0) {
+                const double *src = t.wide_rows + (size_t)r0 * t.W + t.wide_of(c);
+                for (int64_t i = 0; i < rows; ++i) wide_column[(size_t)i] = src[(size_t)i * t.W];
+                sink.write(wide_column.data(), (size_t)rows * 8);
+            } else {
+                const float *src = t.rows + (size_t)r0 * t.F + c;
+                for (int64_t i = 0; i < rows; ++i) column[(size_t)i] = src[(size_t)i * t.F];
+                sink.write(column.data(), (size_t)rows * 4);
+            }
             sink.pad_to(8);
         }
         if (sink.pos() - body0 != at) throw std::logic_error("arrow body length mismatch");

@@ -139,7 +139,8 @@ def test_two_contexts_in_one_process_match_one(nfx, tmp_path):
 @pytest.mark.gpu
 def test_every_output_format_holds_the_same_table(nfx, tmp_path):
     """main.rs:165-189: the writer is picked by extension (csv, parquet | pqt, json, ipc | feather); all six files carry
-    the same centroid keys and, in the binary formats, the same float32 bits."""
+    the same centroid keys and, in the binary formats, the same bits -- float32 columns, and float64 for the seven polygon
+    columns the reference's frame holds at that width (shape.rs:116-127)."""
     pa = pytest.importorskip("pyarrow")
     import pyarrow.ipc
     import pyarrow.parquet
@@ -157,7 +158,13 @@ def test_every_output_format_holds_the_same_table(nfx, tmp_path):
     rows = list(csv.reader(open(tmp_path / "o.csv")))
     assert rows[0] == names and len(rows) == n + 1
     keys = [r_[0] for r_ in rows[1:]]
-    text = np.array([[float(v) for v in r_[1:]] for r_ in rows[1:]], np.float32)   # shortest round-trip text -> same f32
+    text = np.array([[float(v) for v in r_[1:]] for r_ in rows[1:]], np.float64)   # shortest round-trip text -> the same f32 / f64
+    dtypes = ["f32"] * 0
+    for s_ in range(5):
+        dtypes += nfx.column_dtypes(s_)
+    wide = [j for j, d in enumerate(dtypes) if d == "f64"]
+    assert [names[1 + j] for j in wide] == ["area", "perimeter", "equivalent_perimeter", "compacity", "convex_hull_area", "convex_deffect",
+                                            "convex_perimeter"]
     tables = {
         "parquet": pa.parquet.read_table(str(tmp_path / "o.parquet")),
         "pqt": pa.parquet.read_table(str(tmp_path / "o.pqt")),
@@ -167,9 +174,12 @@ def test_every_output_format_holds_the_same_table(nfx, tmp_path):
     for ext, t in tables.items():
         assert t.column_names == names, ext
         assert t.column(0).to_pylist() == keys, ext
-        got = np.stack([t.column(j).to_numpy() for j in range(1, len(names))], axis=1)
-        assert got.dtype == np.float32
-        np.testing.assert_array_equal(got, text, err_msg=ext)
+        for j in range(len(names) - 1):
+            col = t.column(j + 1).to_numpy()
+            assert col.dtype == (np.float64 if j in wide else np.float32), (ext, names[j + 1])
+            np.testing.assert_array_equal(col.astype(np.float64), text[:, j], err_msg=f"{ext} {names[j + 1]}")
+    per = tables["parquet"].column("perimeter").to_numpy()
+    assert (per != per.astype(np.float32).astype(np.float64)).mean() > 0.9       # genuinely f64 values, not widened f32
     lines = (tmp_path / "o.json").read_text().strip().splitlines()
     assert [json.loads(ln)["centroid"] for ln in lines] == keys
 

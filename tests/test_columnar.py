@@ -41,7 +41,16 @@ int main(int argc, char **argv)
         rows[(size_t)2 * F] = -std::numeric_limits<float>::infinity();
     }
     FILE *f = fopen(argv[1], "wb");
-    const FeatureTable t{&names, &keys, rows.data(), n, F};
+    FeatureTable t{&names, &keys, rows.data(), n, F};
+    // optional: every column j with j %% 3 == 1 is an f64 column (the reference's polygon columns), fed from a side matrix
+    std::vector<int> wide((size_t)F, -1);
+    int W = 0;
+    for (int j = 0; j < F; ++j) if (j %% 3 == 1) wide[(size_t)j] = W++;
+    std::vector<double> wide_rows((size_t)n * (W ? W : 1));
+    for (int64_t i = 0; i < n; ++i)
+        for (int j = 0; j < F; ++j)
+            if (wide[(size_t)j] >= 0) wide_rows[(size_t)i * W + wide[(size_t)j]] = (double)(i * 31 + j) * 0.1 - 7.0;
+    if (argc > 4 && W) { t.wide = wide.data(); t.wide_rows = wide_rows.data(); t.W = W; }
     const std::string path = argv[1];
     if (path.size() > 8 && path.substr(path.size() - 8) == ".parquet") write_parquet(f, t);
     else write_arrow_ipc(f, t);
@@ -73,7 +82,7 @@ def expected(n, F):
     return names, rows
 
 
-def check(table, n, F):
+def check(table, n, F, wide=False):
     names, rows = expected(n, F)
     assert table.column_names == names
     assert table.num_rows == n
@@ -82,8 +91,12 @@ def check(table, n, F):
     if n:
         assert keys[0] == "0,0.000000" and keys[-1].startswith(f"{n - 1},")
     for k in range(F):
-        assert table.schema.field(k + 1).type == pa.float32()
         got = table.column(k + 1).to_numpy()
+        if wide and k % 3 == 1:   # an f64 column: values no f32 holds
+            assert table.schema.field(k + 1).type == pa.float64() and got.dtype == np.float64
+            np.testing.assert_array_equal(got, (np.arange(n, dtype=np.int64) * 31 + k).astype(np.float64) * 0.1 - 7.0)
+            continue
+        assert table.schema.field(k + 1).type == pa.float32()
         assert got.dtype == np.float32
         np.testing.assert_array_equal(got, rows[:, k])  # NaN == NaN here, bit-exact otherwise
 
@@ -129,3 +142,20 @@ def test_pandas_sees_the_same_frame(driver, tmp_path):
     assert list(fa.columns) == list(fb.columns)
     assert fa["centroid"].tolist() == fb["centroid"].tolist()
     np.testing.assert_array_equal(fa.iloc[:, 1:].to_numpy(), fb.iloc[:, 1:].to_numpy())
+
+
+@pytest.mark.filterwarnings("ignore:pyarrow.feather:FutureWarning")
+@pytest.mark.parametrize("n,F", [(5, 3), (0, 5), (150001, 4), (1000, 418)])
+def test_f64_columns_keep_their_width_in_both_formats(driver, tmp_path, n, F):
+    """shape.rs:116-127: the reference's frame holds the polygon columns as f64; the writers type those columns DOUBLE."""
+    a, b = tmp_path / "w.parquet", tmp_path / "w.feather"
+    for p in (a, b):
+        subprocess.run([str(driver), str(p), str(n), str(F), "wide"], check=True)
+    pf = pa.parquet.ParquetFile(str(a))
+    check(pf.read(), n, F, wide=True)
+    if n:
+        assert pf.schema.column(2).physical_type == "DOUBLE" and pf.schema.column(1).physical_type == "FLOAT"
+    with pa.ipc.open_file(str(b)) as rd:
+        table = rd.read_all()
+    check(table, n, F, wide=True)
+    table.validate(full=True)
