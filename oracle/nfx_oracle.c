@@ -451,6 +451,10 @@ static void orc_mean_std_plane(const float *x, const float *m, int n, float area
  *   mask [n,1,ps,ps] broadcasts to [n,n,ps,ps]; nucleus i sums mask_i * sin(h_j) over every patch j
  *   of the batch.
  * ---------------------------------------------------------------------------------------- */
+/* single-pixel entry points of the two colour transforms, for the independent cross-checks in tests/ */
+void orc_hsv_pixel(float r, float g, float b, float out[3]) { orc_hsv(r, g, b, &out[0], &out[1], &out[2]); }
+void orc_hed_pixel(float r, float g, float b, float out[3]) { orc_hed(r, g, b, out); }
+
 void orc_color_batch(int n, const float *patches, const float *masks, int ps, float *out)
 {
     const int P = ps * ps;
