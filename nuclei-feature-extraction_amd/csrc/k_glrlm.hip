@@ -272,7 +272,9 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
                         rem &= rem - 1u;
                         const unsigned len1 = ((h0 >> pos) & 1u) | (((h1 >> pos) & 1u) << 1) | (((h2 >> pos) & 1u) << 2) | (((h3 >> pos) & 1u) << 3);
                         const unsigned q = s_q[rbase + sh + pos];
-                        atomicAdd(&s_R[q * RL_MAXLEN + len1], 1u);
+                        // starts lie inside the mask, so q <= 23; the clamp keeps a stray byte (0xFF outside the mask) from ever
+                        // indexing past the 384 bins into a neighbouring wave's table
+                        atomicAdd(&s_R[(q < (unsigned)RL_LEVELS ? q : (unsigned)RL_LEVELS - 1u) * RL_MAXLEN + len1], 1u);
                     }
                 }
             }

@@ -37,7 +37,7 @@ NUCLEI = {"config3": 1_000_000, "config5": 1_250_000}
 DOM = {"config3": "glcm", "config5": "gabor"}
 LAUNCH_SETS = 3  # warmup 1 + steps 2: every kernel ran three times per class
 doc = {"csrc_stamp": bench.csrc_stamp(),
-       "source": f"rocprofv3 --pmc (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_*) of `bench.py --workload W --steps 2 --warmup 1`, "
+       "source": f"rocprofv3 --pmc (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_*) of bench.py --workload W --steps 2 --warmup 1, "
                  f"scripts/profile_round.sh {tag}; traffic = (2*FETCH_SIZE + WRITE_SIZE) KB summed over every launch of the dominant kernel "
                  "in one step (FETCH_SIZE doubled per MI355X_MICROARCH.md: gfx950 counts half of wide streaming reads; narrower reads are "
                  "uncalibrated), valu = SQ_INSTS_VALU per nucleus"}

@@ -147,20 +147,25 @@ def test_reserved_context_never_grows_and_says_so(nfx):
     sets = [0, 1, 2, 3, 4]
     ctx = nfx.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     n_small = 100
-    ctx.reserve(sets, n_small, int(off[n_small]), ps, batch_size=100)
     s_off, s_xy, s_p = d_off[:n_small + 1].contiguous(), d_xy[:int(off[n_small])].contiguous(), d_p[:n_small].contiguous()
-    small = torch.empty((n_small, 418), dtype=torch.float32, device=dev)
     # (that the first call after a reservation neither allocates nor synchronises is shown by capturing it:
     # test_capture_needs_a_reservation_and_works_with_one; free device memory is no witness, the HIP runtime loads kernel
     # code objects lazily on a first launch)
-    ctx.extract(sets, s_off, s_xy, s_p, ps, out=small, want_centroids=False)
-    torch.cuda.synchronize()
-    with pytest.raises(nfx.NfxError, match="reservation"):
-        ctx.extract(sets, d_off, d_xy, d_p, ps, want_centroids=False)
-    ctx.reserve(sets, 400, int(off[-1]), ps, batch_size=100)      # reservations grow on request
+    ctx.reserve([0], n_small, int(off[n_small]), ps, batch_size=100)          # geometry only: a few hundred KB
+    geo, _ = ctx.extract([0], s_off, s_xy, None, ps, want_centroids=False)
+    with pytest.raises(nfx.NfxError, match="reservation"):                    # the texture sets need tables and 14 MB more
+        ctx.extract(sets, s_off, s_xy, s_p, ps, want_centroids=False)
+    ctx.reserve(sets, n_small, int(off[n_small]), ps, batch_size=100)         # reservations grow on request
+    small, _ = ctx.extract(sets, s_off, s_xy, s_p, ps, want_centroids=False)
+    with pytest.raises(nfx.NfxError, match="reservation"):                    # and are not outgrown silently: 200x the nuclei
+        rep = lambda t: torch.cat([t] * 200)
+        off_rep = torch.cat([d_off[:n_small + 1].to(torch.int64)] + [d_off[1:n_small + 1].to(torch.int64) + k * int(off[n_small]) for k in range(1, 200)]).to(torch.int32)
+        ctx.extract(sets, off_rep, rep(s_xy), rep(s_p), ps, want_centroids=False)
+    ctx.reserve(sets, 400, int(off[-1]), ps, batch_size=100)
     big, _ = ctx.extract(sets, d_off, d_xy, d_p, ps, want_centroids=False)
     torch.cuda.synchronize()
     assert torch.equal(torch.nan_to_num(big[:n_small]), torch.nan_to_num(small))
+    assert torch.equal(torch.nan_to_num(small[:, :12]), torch.nan_to_num(geo))
     ctx.set_stream(0)
     ctx.close()
 
