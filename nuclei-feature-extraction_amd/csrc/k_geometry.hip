@@ -499,9 +499,57 @@ static __device__ __forceinline__ void polygon_one(VP v, int V, IDX *srt, IDX *h
     }
 }
 
+// ---- one lane per ring ----------------------------------------------------------------------------------------------
+// The serial program, 64 rings per wave: about 40 wave-instructions per ring -- twenty times fewer issue slots than the
+// group-parallel kernel below -- but a chain of dependent LDS reads on 64 diverging control paths, at 5 waves per CU: 92 %
+// of its time is waiting.  That makes it the right kernel BESIDE other work (the side stream of a call that also runs
+// pixel sets: it hides completely and takes almost nothing from the kernels it runs next to) and the wrong one when the
+// polygon columns are on the critical path (geometry alone), where the group-parallel kernel is 1.6x faster.
+static constexpr int PG_CAPV = 2432;               // vertices of one wave's 64 rings kept in LDS (38 per ring on average)
+static constexpr int PG_SLICE = 3 * PG_MAXV + 8;   // sort permutation (V) + hull stack (2V+2), one byte each
+
+__global__ __launch_bounds__(64) void k_polygon_serial(int64_t n, const uint32_t *__restrict__ poly_off,
+                                                       const float *__restrict__ poly_xy, uint32_t *__restrict__ scratch,
+                                                       float *__restrict__ out, int F, int col0, double *__restrict__ out64)
+{
+    // The rings of the wave's 64 nuclei are copied once into LDS, packed back to back (a wave scan of the ring lengths gives
+    // every lane its slice of the vertex and of the index arrays), so the sort's and the hull walk's dependent reads are LDS
+    // reads.  A wave whose rings do not all fit (more than PG_CAPV vertices in total, or a ring longer than PG_MAXV) reads
+    // them in place, with per-lane index slices of the maximum size.
+    __shared__ __attribute__((aligned(8))) uint8_t s_raw[PG_CAPV * 8 + 3 * PG_CAPV + 64 * 8];
+    static_assert(sizeof(s_raw) >= 64 * PG_SLICE, "the in-place path's index slices fit too");
+    float2 *s_xy = reinterpret_cast<float2 *>(s_raw);
+    uint8_t *s_idx = s_raw + PG_CAPV * 8;
+    const int lane = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = i < n;
+    const uint32_t v0 = live ? poly_off[i] : 0u;
+    const int V = live ? (int)(poly_off[i + 1] - v0) : 0;
+    const int incl = wave_inclusive_scan_i32(V);
+    const int first = incl - V;
+    const float2 *gv = reinterpret_cast<const float2 *>(poly_xy) + v0;
+    const bool packed = __all(V <= PG_MAXV && incl <= PG_CAPV); // wave-uniform
+    float *o = out ? out + i * (int64_t)F + col0 : nullptr;
+    double *o64 = out64 ? out64 + i * 7 : nullptr;
+    if (packed) {
+        for (int k = 0; k < V; ++k) s_xy[first + k] = gv[k];
+        if (!live) return;
+        uint8_t *srt = s_idx + 3 * first + 8 * lane; // V sort indices, then 2V + 2 hull slots
+        polygon_one<uint8_t, const float2 *>(s_xy + first, V, srt, srt + V, o, o64);
+    } else {
+        if (!live) return;
+        if (V <= PG_MAXV) {
+            uint8_t *srt = s_raw + lane * PG_SLICE;
+            polygon_one<uint8_t, const float2 *__restrict__>(gv, V, srt, srt + PG_MAXV, o, o64);
+        } else {
+            uint32_t *srt = scratch + 3 * (size_t)v0 + 4 * (size_t)i;
+            polygon_one<uint32_t, const float2 *__restrict__>(gv, V, srt, srt + V, o, o64);
+        }
+    }
+}
+
 // ---- LPR lanes per ring --------------------------------------------------------------------------------------------
-// One lane per ring ran 64 different serial programs per wave (sort merges, hull pops: every lane on its own control path)
-// at 1.5 waves per SIMD: 92 % of the wave's time was waiting.  Here a ring belongs to a GROUP of LPR lanes (64 / LPR rings per
+// For calls whose critical path the polygon columns are on.  A ring belongs to a GROUP of LPR lanes (64 / LPR rings per
 // wave, four waves per block), so the chip holds 4-16x as many waves for the same rings and most of the work is lane-parallel:
 //   * the vertices go to LDS once (ring stride padded so the groups' rings start on different banks) and stay in the
 //     lanes' registers (lane `sub` holds vertices sub, sub + LPR, ...);
@@ -707,10 +755,15 @@ hipError_t launch_shape_from_rows(nfx_ctx *ctx, int64_t n, const uint64_t *rows,
 }
 
 hipError_t launch_polygon(nfx_ctx *ctx, int64_t n, const uint32_t *poly_off, const float *poly_xy, void *scratch,
-                          float *out, int F, int col0, double *out64)
+                          float *out, int F, int col0, double *out64, bool beside_other_work)
 {
     if (n == 0) return hipSuccess;
     ScopedTiming t(ctx, KS_POLYGON);
+    if (beside_other_work) {
+        hipLaunchKernelGGL(k_polygon_serial, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, n, poly_off, poly_xy,
+                           reinterpret_cast<uint32_t *>(scratch), out, F, col0, out64);
+        return hipGetLastError();
+    }
     constexpr int rings_per_block = 4 * (64 / NFX_PG_LPR);
     hipLaunchKernelGGL(k_polygon<NFX_PG_LPR>, dim3((unsigned)((n + rings_per_block - 1) / rings_per_block)), dim3(256), 0, ctx->stream, n,
                        poly_off, poly_xy, reinterpret_cast<uint32_t *>(scratch), out, F, col0, out64);

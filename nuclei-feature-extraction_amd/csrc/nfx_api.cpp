@@ -467,13 +467,11 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
     // and is joined at the end of the call
     hipStream_t const main_stream = ctx->stream;
     const bool want_fork = count_set(sets, n_sets, NFX_SET_GEOMETRY) && pix; // next to the rasteriser alone (geometry only) the two f64-heavy kernels just share the issue slots: no gain
-#ifndef NFX_FORK_AFTER_RASTER
     if (want_fork) {
         NFX_HIP(ctx, hipEventRecord(ctx->ev_fork, main_stream));
         NFX_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
         forked = true;
     }
-#endif
     if (image && pix) {
         uint8_t *gp = (uint8_t *)ws_alloc(ctx, (size_t)n * 3 * ps * ps);
         if (!gp) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
@@ -490,13 +488,6 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
         }
     }
     NFX_HIP(ctx, launch_raster_shape(ctx, n, ring_off, centred, ps, rows, geo_col >= 0 ? out_rows : nullptr, F, geo_col >= 0 ? geo_col : 0, areas));
-#ifdef NFX_FORK_AFTER_RASTER
-    if (want_fork) {
-        NFX_HIP(ctx, hipEventRecord(ctx->ev_fork, main_stream));
-        NFX_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
-        forked = true;
-    }
-#endif
 
     Job job;
     job.n = n; job.ps = ps; job.batch_size = batch_size; job.poly_off = ring_off; job.poly_xy = centred;
@@ -514,7 +505,7 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
             if (geo_done) // a repeated "geometry" (args.rs does not de-duplicate): recompute into its own columns
                 NFX_HIP(ctx, launch_raster_shape(ctx, n, ring_off, centred, ps, nullptr, out_rows, F, col));
             if (forked) ctx->stream = ctx->side_stream; // launch (and time) on the side stream
-            const hipError_t pe = launch_polygon(ctx, n, ring_off, centred, scr, out_rows, F, col);
+            const hipError_t pe = launch_polygon(ctx, n, ring_off, centred, scr, out_rows, F, col, nullptr, forked);
             ctx->stream = main_stream;
             NFX_HIP(ctx, pe);
             geo_done = true;

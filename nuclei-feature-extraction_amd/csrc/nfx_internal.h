@@ -105,9 +105,11 @@ hipError_t launch_raster_shape(nfx_ctx *ctx, int64_t n, const uint32_t *poly_off
 // geometry columns from existing mask rows (trait entry: masks are given, not rasterised)
 hipError_t launch_shape_from_rows(nfx_ctx *ctx, int64_t n, const uint64_t *rows, int ps, float *out, int F, int col0);
 // polygon-derived geometry columns; scratch: 3*total_vertices+2n+... doubles pairs (see k_geometry.hip)
-// out (f32 rows, columns 0,5,6,7,9,10,11 of the geometry block) and out64 ([n][7] f64) may each be nullptr
+// out (f32 rows, columns 0,5,6,7,9,10,11 of the geometry block) and out64 ([n][7] f64) may each be nullptr.
+// beside_other_work: the launch sits on a side stream next to other kernels of the call (the issue-frugal serial kernel) rather
+// than on the call's critical path (the group-parallel kernel)
 hipError_t launch_polygon(nfx_ctx *ctx, int64_t n, const uint32_t *poly_off, const float *poly_xy, void *scratch,
-                          float *out, int F, int col0, double *out64 = nullptr);
+                          float *out, int F, int col0, double *out64 = nullptr, bool beside_other_work = false);
 size_t polygon_scratch_bytes(int64_t n, int64_t total_vertices);
 hipError_t launch_pack_masks(nfx_ctx *ctx, int64_t n, const float *masks_f32, int ps, uint64_t *rows);
 hipError_t launch_unpack_masks(nfx_ctx *ctx, int64_t n, const uint64_t *rows, int ps, float *masks_f32);
