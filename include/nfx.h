@@ -57,7 +57,7 @@ typedef struct nfx_ctx nfx_ctx;
 typedef enum {
     NFX_OK = 0,
     NFX_ERR_INVALID_ARGUMENT = 1,
-    NFX_ERR_UNSUPPORTED = 2,   /* e.g. patch size > 64 */
+    NFX_ERR_UNSUPPORTED = 2,   /* e.g. patch size > 128 */
     NFX_ERR_DEVICE = 3,        /* HIP runtime error, text in nfx_last_error */
     NFX_ERR_OUT_OF_MEMORY = 4
 } nfx_status;
@@ -74,7 +74,10 @@ typedef enum {
 
 typedef enum { NFX_MEM_HOST = 0, NFX_MEM_DEVICE = 1 } nfx_mem;
 
-#define NFX_MAX_PATCH_SIZE 64 /* one mask row == one 64-bit word == one lane's register pair */
+/* Patch sizes (args.rs:93-94, default 64).  Up to 64 a mask row is one 64-bit word in one lane's registers and the
+   wave-per-nucleus kernels run; 65..128 take a plainer kernel family (one workgroup per nucleus, two words per mask row): same
+   results, far lower throughput.  Larger patches are refused with NFX_ERR_UNSUPPORTED. */
+#define NFX_MAX_PATCH_SIZE 128
 
 /* ---- registry (no context, no GPU needed) ------------------------------------------------ */
 int nfx_version(void);
@@ -148,7 +151,8 @@ nfx_status nfx_preprocess_polygons(nfx_ctx *ctx, int64_t n, int64_t n_vertices, 
 /* ---- R2: tch_utils::shapes::polygon call sites utils.rs:90-95,152-157 ---------------------
    centred polygons in, masks out.  Either output may be NULL:
      masks_f32  [n][1][ps][ps] f32 in {0,1}  (the reference's tensor)
-     mask_rows  [n][ps] u64, bit c of word r == pixel (r,c)  (the engine's native form) */
+     mask_rows  [n][ps][W] u64, W = 1 for ps <= 64 (bit c of word r == pixel (r,c)) and 2 for ps 65..128 (bit c & 63 of word
+                c >> 6)  (the engine's native form) */
 nfx_status nfx_rasterize_polygons(nfx_ctx *ctx, int64_t n, int64_t n_vertices, const uint32_t *poly_offsets,
                                   const float *poly_xy, int ps, float *masks_f32, uint64_t *mask_rows, nfx_mem mem);
 

@@ -349,6 +349,80 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
     }
 }
 
+// ---- patch sizes 65..128: one 256-thread workgroup per nucleus (see k_geometry.hip, "patch sizes 65..128") -----------------
+// Same per-pixel arithmetic (pixel_channels), same finishing formulas; the threads stride over the patch, test the mask bit
+// in the [ps][2] row words, and the twenty sums are reduced per wave (DPP) and across the four waves through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void k_color_wide(int64_t n, int ps, int batch_size, const T *__restrict__ patches,
+                                                    const uint64_t *__restrict__ mask_rows, const double *__restrict__ SC,
+                                                    const float *__restrict__ od_lut, float *__restrict__ out, int F, int col0)
+{
+    __shared__ float s_od[256];
+    __shared__ double s_red[4][20];
+    __shared__ int s_K[4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    s_od[t] = od_lut[t];
+    __syncthreads();
+    const int P = ps * ps;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const T *pp = patches + (size_t)i * 3 * P;
+        const uint64_t *rows = mask_rows + (size_t)i * ps * 2;
+        const double *S = SC + (size_t)(i / batch_size) * 2 * P;
+        const double *Cc = S + P;
+        double acc[20]; // sum x (9), sum x^2 (9), sum sin, sum cos
+#pragma unroll
+        for (int k = 0; k < 20; ++k) acc[k] = 0.0;
+        int K = 0;
+        for (int p = t; p < P; p += 256) {
+            const int r = p / ps, c = p - r * ps;
+            if (!((rows[2 * r + (c >> 6)] >> (c & 63)) & 1ull)) continue;
+            ++K;
+            float x[9];
+            if (sizeof(T) == 1) {
+                const uint8_t *pb = reinterpret_cast<const uint8_t *>(pp);
+                const unsigned b0 = pb[p], b1 = pb[P + p], b2 = pb[2 * P + p];
+                pixel_channels<T>(u8_unit(b0), u8_unit(b1), u8_unit(b2), b0, b1, b2, 0.0f, s_od, x); // utils.rs:172
+            } else {
+                pixel_channels<T>(Px<T>::ld(pp, p), Px<T>::ld(pp, P + p), Px<T>::ld(pp, 2 * P + p), 0u, 0u, 0u, 0.0f, s_od, x);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { const double xd = (double)x[k]; acc[k] += xd; acc[9 + k] += xd * xd; }
+            acc[18] += S[p];
+            acc[19] += Cc[p];
+        }
+#pragma unroll
+        for (int k = 0; k < 20; ++k) {
+            const double tot = wave_total_f64(acc[k]);
+            if (lane == 0) s_red[wv][k] = tot;
+        }
+        const int Kw = wave_total_i32(K);
+        if (lane == 0) s_K[wv] = Kw;
+        __syncthreads();
+        if (t < 9) {
+            const int Kt = s_K[0] + s_K[1] + s_K[2] + s_K[3];
+            const float area = (float)Kt;
+            auto tot = [&](int k) { return (s_red[0][k] + s_red[1][k]) + (s_red[2][k] + s_red[3][k]); };
+            const float rad2deg = (float)(180.0 / 3.14159265358979323846);
+            const float sinm = (float)tot(18) / area, cosm = (float)tot(19) / area;
+            float mh = (float)atan2((double)sinm, (double)cosm);
+            mh = mh * rad2deg;
+            mh = mh + 360.0f;
+            mh = fmodf(mh, 360.0f); // color.rs:154
+            const int k = t;
+            const double a = tot(k), b = tot(9 + k);
+            const float mu = (float)a / area;
+            const double mud = (double)mu;
+            double D = b - 2.0 * mud * a + (double)Kt * mud * mud; // sum (x-mu)^2 about the f32 mean
+            D = D > 0.0 ? D : (D == D ? 0.0 : D);
+            const float sd = sqrtf((float)D / area);
+            float *o = out + i * (int64_t)F + col0;
+            o[k < 3 ? k : (k < 6 ? 3 + k : 6 + k)] = k == 3 ? mh : mu;
+            o[k < 3 ? 3 + k : (k < 6 ? 6 + k : 9 + k)] = sd;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 size_t color_scratch_bytes(const Job &job)
 {
@@ -412,6 +486,17 @@ hipError_t launch_color(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
         }
         e = hipGetLastError();
         if (e != hipSuccess) return e;
+    }
+    if (job.ps > 64) {
+        ScopedTiming t(ctx, KS_COLOR);
+        const unsigned wgrid = (unsigned)(job.n < 256 * 8 ? job.n : 256 * 8);
+        if (job.patches_f32)
+            hipLaunchKernelGGL(k_color_wide<float>, dim3(wgrid), dim3(256), 0, ctx->stream, job.n, job.ps, job.batch_size,
+                               reinterpret_cast<const float *>(job.patches), job.mask_rows, SC, ctx->od_lut, job.out, job.F, col0);
+        else
+            hipLaunchKernelGGL(k_color_wide<uint8_t>, dim3(wgrid), dim3(256), 0, ctx->stream, job.n, job.ps, job.batch_size,
+                               reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, SC, ctx->od_lut, job.out, job.F, col0);
+        return hipGetLastError();
     }
     {
         ScopedTiming t(ctx, KS_COLOR);

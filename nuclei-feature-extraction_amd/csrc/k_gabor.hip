@@ -42,9 +42,9 @@
 namespace nfx {
 
 static constexpr int GB_SIZE = 30, GB_PAD = 15, GB_THREADS = 256;
-static constexpr int GB_GW = NFX_MAX_PATCH_SIZE + GB_SIZE - 1; // gray row with apron: 93 floats
-static constexpr int GB_UW = NFX_MAX_PATCH_SIZE + 1;           // U/W row stride (odd: conflict-free both ways)
-static constexpr int GB_UH = NFX_MAX_PATCH_SIZE + GB_SIZE - 1; // U/W rows incl. zero aprons: 93
+static constexpr int GB_GW = NFX_ROW_WORD_PS + GB_SIZE - 1; // gray row with apron: 93 floats
+static constexpr int GB_UW = NFX_ROW_WORD_PS + 1;           // U/W row stride (odd: conflict-free both ways)
+static constexpr int GB_UH = NFX_ROW_WORD_PS + GB_SIZE - 1; // U/W rows incl. zero aprons: 93
 static constexpr int GB_MAX_GROUPS = 16, GB_MAX_FILTERS = 24, GB_MAX_PASSES = 3;
 static constexpr int GB_WSLOT = 64;                            // one pass: 30 weight pairs padded to 32 float2
 static constexpr int GB_WBUF = GB_WSLOT * (1 + GB_MAX_PASSES); // row pass + up to three column passes
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
                                                          int F, int col0, int dbg)
 {
     __shared__ __attribute__((aligned(16))) float s_wt[2][GB_WBUF];
-    __shared__ float s_g[NFX_MAX_PATCH_SIZE * GB_GW + 16];
+    __shared__ float s_g[NFX_ROW_WORD_PS * GB_GW + 16];
     __shared__ f2 s_UW[GB_UH * GB_UW]; // plane pair; row r lives at index r + GB_PAD; aprons stay zero
     __shared__ uint64_t s_rows[64 + 16];
     __shared__ double s_part[4][GB_MAX_FILTERS][2];
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int P = ps * ps;
-    for (int k = t; k < NFX_MAX_PATCH_SIZE * GB_GW + 16; k += GB_THREADS) s_g[k] = 0.0f; // apron stays zero
+    for (int k = t; k < NFX_ROW_WORD_PS * GB_GW + 16; k += GB_THREADS) s_g[k] = 0.0f; // apron stays zero
     for (int k = t; k < GB_UH * GB_UW; k += GB_THREADS) s_UW[k] = (f2){0.0f, 0.0f};
     if (t < 64 + 16) s_rows[t] = 0ull;
     const int n_groups = tab->n_groups, n_filters = tab->n_filters, n_plain = tab->n_plain;
@@ -550,6 +550,94 @@ static void build_tables(GaborTables &T)
     T.n_groups = ok ? ng : GB_MAX_GROUPS + 1;
 }
 
+// ---- patch sizes 65..128: one 256-thread workgroup per nucleus (see k_geometry.hip, "patch sizes 65..128") -----------------
+// The paired separable passes above keep a 93 x 93 window of planes in LDS; a 128 x 128 patch does not fit.  This plainer form
+// is the reference's own shape: the DENSE 30 x 30 kernel of every channel (texture.rs:333-334; same bank as the separable
+// one, angle index * 6 + frequency index, theta = a pi / 4), correlated with the zero-padded gray patch (15 before, 14 after)
+// at the masked pixels only, one channel at a time with its 900 taps in LDS; masked mean and variance (texture.rs:339-344)
+// from f64 sums.  A tap row is accumulated in f32 (30 terms), rows in f64.
+static constexpr int GBW_CH = 48;
+struct GaborDense { float w[GBW_CH][GB_SIZE * GB_SIZE]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gabor_wide(int64_t n, int ps, const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
+                                                    const GaborDense *__restrict__ bank, float *__restrict__ out, int F, int col0)
+{
+    __shared__ float s_gray[NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE];
+    __shared__ float s_w[GB_SIZE * GB_SIZE];
+    __shared__ double s_red[4][2];
+    __shared__ int s_K[4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int P = ps * ps;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const T *pp = patches + (size_t)i * 3 * P;
+        const uint64_t *rows = mask_rows + (size_t)i * ps * 2;
+        int K = 0;
+        for (int p = t; p < P; p += 256) {
+            float gs = BPx<T>::ld(pp, p) + BPx<T>::ld(pp, P + p);
+            gs = gs + BPx<T>::ld(pp, 2 * P + p);
+            s_gray[p] = sizeof(T) == 1 ? third_of_u8_sum(gs) : gs / 3.0f; // texture.rs:332
+            const int r = p / ps, c = p - r * ps;
+            K += (int)((rows[2 * r + (c >> 6)] >> (c & 63)) & 1ull);
+        }
+        K = wave_total_i32(K);
+        if (lane == 0) s_K[wv] = K;
+        __syncthreads();
+        const double area = (double)(s_K[0] + s_K[1] + s_K[2] + s_K[3]);
+        float *o = out + i * (int64_t)F + col0;
+        for (int ch = 0; ch < GBW_CH; ++ch) {
+            for (int k = t; k < GB_SIZE * GB_SIZE; k += 256) s_w[k] = bank->w[ch][k];
+            __syncthreads();
+            double s1 = 0.0, s2 = 0.0;
+            for (int p = t; p < P; p += 256) {
+                const int r = p / ps, c = p - r * ps;
+                if (!((rows[2 * r + (c >> 6)] >> (c & 63)) & 1ull)) continue;
+                const int i0 = r - GB_PAD < 0 ? GB_PAD - r : 0, i1 = r - GB_PAD + GB_SIZE > ps ? ps - (r - GB_PAD) : GB_SIZE;
+                const int j0 = c - GB_PAD < 0 ? GB_PAD - c : 0, j1 = c - GB_PAD + GB_SIZE > ps ? ps - (c - GB_PAD) : GB_SIZE;
+                double acc = 0.0;
+                for (int ii = i0; ii < i1; ++ii) {
+                    const float *g = &s_gray[(r + ii - GB_PAD) * ps + (c - GB_PAD)];
+                    const float *w = &s_w[ii * GB_SIZE];
+                    float row = 0.0f;
+                    for (int jj = j0; jj < j1; ++jj) row = fmaf(w[jj], g[jj], row);
+                    acc += (double)row;
+                }
+                s1 += acc;
+                s2 += acc * acc;
+            }
+            s1 = wave_total_f64(s1);
+            s2 = wave_total_f64(s2);
+            if (lane == 0) { s_red[wv][0] = s1; s_red[wv][1] = s2; }
+            __syncthreads();
+            if (t == 0) {
+                const double a = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
+                const double b = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
+                const double mean = a / area; // 0/0 for an empty mask, as texture.rs:340-344
+                double var = b / area - mean * mean;
+                var = var > 0.0 ? var : (var == var ? 0.0 : var);
+                o[2 * ch] = (float)mean;
+                o[2 * ch + 1] = (float)var;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+static void build_dense_bank(GaborDense &D)
+{
+    const double PI = 3.14159265358979323846, sigma = 0.45;
+    const double freqs[6] = {0.5, 1.0, 2.0, 4.0, 6.0, 8.0}; // texture.rs:320
+    for (int a = 0; a < 8; ++a)
+        for (int f = 0; f < 6; ++f) {
+            const double th = (double)a * PI / 4.0, ct = cos(th), st = sin(th);
+            for (int i = 0; i < GB_SIZE; ++i)
+                for (int j = 0; j < GB_SIZE; ++j) {
+                    const double x = -1.0 + 2.0 * (double)j / (double)(GB_SIZE - 1), y = -1.0 + 2.0 * (double)i / (double)(GB_SIZE - 1);
+                    D.w[a * 6 + f][i * GB_SIZE + j] = (float)(exp(-(x * x + y * y) / (2.0 * sigma * sigma)) * cos(2.0 * PI * freqs[f] * (x * ct + y * st)));
+                }
+        }
+}
+
 // The bank is the same for every context: built once per process (contexts are created and first used concurrently,
 // one per host thread -- main.rs:146-151), immutable afterwards.
 static const GaborTables &gabor_tables()
@@ -571,7 +659,16 @@ hipError_t prepare_gabor(nfx_ctx *ctx)
     if (e != hipSuccess) return e;
     e = hipMemcpy(tab, &T, sizeof(GaborTables), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(tab); return e; }
-    ctx->gabor_tab = tab; // published only once it is complete
+    // the dense bank of the wide kernels (172 KB)
+    static GaborDense D;
+    static std::once_flag dense_once;
+    std::call_once(dense_once, [] { build_dense_bank(D); });
+    float *dense = nullptr;
+    e = hipMalloc(reinterpret_cast<void **>(&dense), sizeof(GaborDense));
+    if (e == hipSuccess) e = hipMemcpy(dense, &D, sizeof(GaborDense), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(tab); if (dense) (void)hipFree(dense); return e; }
+    ctx->gabor_dense = dense;
+    ctx->gabor_tab = tab; // published only once both are complete
     return hipSuccess;
 }
 
@@ -581,6 +678,17 @@ hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0)
     hipError_t e = prepare_gabor(ctx);
     if (e != hipSuccess) return e;
     ScopedTiming t(ctx, KS_GABOR);
+    if (job.ps > NFX_ROW_WORD_PS) {
+        const unsigned wgrid = (unsigned)(job.n < 256 * 4 ? job.n : 256 * 4);
+        const GaborDense *dense = reinterpret_cast<const GaborDense *>(ctx->gabor_dense);
+        if (job.patches_f32)
+            hipLaunchKernelGGL(k_gabor_wide<float>, dim3(wgrid), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const float *>(job.patches),
+                               job.mask_rows, dense, job.out, job.F, col0);
+        else
+            hipLaunchKernelGGL(k_gabor_wide<uint8_t>, dim3(wgrid), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const uint8_t *>(job.patches),
+                               job.mask_rows, dense, job.out, job.F, col0);
+        return hipGetLastError();
+    }
     const int64_t maxb = 256 * 2 * 2;
     const unsigned grid = (unsigned)(job.n < maxb ? job.n : maxb);
     const GaborTables *tab = reinterpret_cast<const GaborTables *>(ctx->gabor_tab);

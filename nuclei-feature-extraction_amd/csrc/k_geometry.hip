@@ -200,37 +200,39 @@ static __device__ void slanv2(float a, float b, float c, float d, float &rt1, fl
     rt1 = a; rt2 = d;
 }
 
-// ---- mask-derived geometry columns from the wave's row words ------------------------------------
-// writes out[1]=major_axis [2]=minor_axis [3]=eccentricity [4]=orientation [8]=eliptic_deviation
-static __device__ void shape_from_row(uint64_t row, int ps, int lane, float *__restrict__ o)
+// ---- mask-derived geometry columns ------------------------------------------------------------------------------------
+// per-word moments by popcount against the bit patterns "bit index has bit j set": count, sum of bit indices, sum of squares
+static __device__ __forceinline__ void word_moments(uint64_t w, int &pc, int &sc, int &scc)
 {
-    // per-row moments by popcount against the bit patterns "column index has bit j set"
     constexpr uint64_t PAT[6] = {0xAAAAAAAAAAAAAAAAull, 0xCCCCCCCCCCCCCCCCull, 0xF0F0F0F0F0F0F0F0ull,
                                  0xFF00FF00FF00FF00ull, 0xFFFF0000FFFF0000ull, 0xFFFFFFFF00000000ull};
-    const int kr = __popcll(row);
-    int sc = 0, scc = 0;
+    pc = __popcll(w);
+    sc = 0; scc = 0;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        const uint64_t mj = row & PAT[j];
+        const uint64_t mj = w & PAT[j];
         const int pj = __popcll(mj);
         sc += pj << j;
         scc += pj << (2 * j);
 #pragma unroll
         for (int k = j + 1; k < 6; ++k) scc += __popcll(mj & PAT[k]) << (j + k + 1);
     }
-    // seven totals in one reduce-scatter butterfly (wave_ops.h); lane l holds the total of M[scatter_index<8>(l & 7)]
-    unsigned M[8] = {(unsigned)kr, (unsigned)(lane * kr), (unsigned)sc, (unsigned)(lane * lane * kr), (unsigned)(lane * sc), (unsigned)scc, 0u, 0u};
-    const int tot = (int)wave_reduce_scatter(M, lane);
-    // scatter_index<8> reverses three bits: slots 0..5 sit in lanes 0, 4, 2, 6, 1, 5
-    const int K = __builtin_amdgcn_readlane(tot, 0), sr = __builtin_amdgcn_readlane(tot, 4), scs = __builtin_amdgcn_readlane(tot, 2);
-    const int srr = __builtin_amdgcn_readlane(tot, 6), src = __builtin_amdgcn_readlane(tot, 1), sccs = __builtin_amdgcn_readlane(tot, 5);
+}
 
+// center_of_mass, major_minor_axes_w_angle, eccentricity (shape.rs:141-226) from the six integer moments of the mask
+struct ShapeAxes {
+    float major, minor, angle, ecc, cen0, cen1; // cen0 / cen1: centre of mass (row, column) minus ps / 2 (shape.rs:71-73)
+};
+
+static __device__ ShapeAxes shape_axes(int K, int sr, int scs, int srr, int src, int sccs, int ps)
+{
+    ShapeAxes A;
     // center_of_mass (shape.rs:219-226): integer sums < 2^24 are exact in f32
     const float mu_r = (float)sr / (float)K; // K == 0 -> NaN
     const float mu_c = (float)scs / (float)K;
     const float halfps = (float)ps / 2.0f;
-    const float cen0 = mu_r - halfps, cen1 = mu_c - halfps;
-
+    A.cen0 = mu_r - halfps;
+    A.cen1 = mu_c - halfps;
     float major, minor, angle;
     if (K == 0) {
         major = minor = angle = __builtin_nanf("");
@@ -255,74 +257,108 @@ static __device__ void shape_from_row(uint64_t row, int ps, int lane, float *__r
         minor = eb * 2.0f;
     }
     const float hM = major * 0.5f, hm = minor * 0.5f;
-    const float ecc = sqrtf(hM * hM - hm * hm) / hM;
+    A.major = major; A.minor = minor; A.angle = angle;
+    A.ecc = sqrtf(hM * hM - hm * hm) / hM;
+    return A;
+}
 
+// ellipse (shape.rs:80-87), one row: the columns that pass the reference test form an interval [lo, lo + len) (the ellipse is
+// convex).  Its ends are estimated from the quadratic in x and then made EXACT by evaluating the reference test itself at the
+// ends, so the result equals the per-pixel evaluation bit for bit at ~6 tests per row instead of ps.  len = 0: empty row.
+struct EllipseFrame {
+    double ct, st, half, xc, yc, a, b;
+};
+static __device__ __forceinline__ EllipseFrame ellipse_frame(const ShapeAxes &A, int ps)
+{
+    EllipseFrame E;
+    E.ct = cos((double)A.angle); E.st = sin((double)A.angle);
+    E.half = (double)ps / 2.0;
+    E.xc = (double)A.cen1; E.yc = (double)A.cen0; E.a = (double)A.major; E.b = (double)A.minor;
+    return E;
+}
+static __device__ void ellipse_row_span(const EllipseFrame &E, int ps, int row, int &lo, int &len)
+{
+    lo = 0; len = 0;
+    const double ct = E.ct, st = E.st, half = E.half, xc = E.xc, yc = E.yc, a = E.a, b = E.b;
+    if (!(a > 0.0 && b > 0.0)) return; // a or b zero/NaN: every test is false
+    const double y = ((double)row - half) - yc;
+    auto inside = [&](int c) -> bool {
+        const double x = ((double)c - half) - xc;
+        const double xrr = x * ct + y * st;
+        const double yrr = y * ct - x * st;
+        const double u = xrr / a, v = yrr / b;
+        return (u * u + v * v) <= 1.0;
+    };
+    const double ia2 = 1.0 / (a * a), ib2 = 1.0 / (b * b);
+    const double qa = ct * ct * ia2 + st * st * ib2;
+    const double qb = 2.0 * y * ct * st * (ia2 - ib2);
+    const double qc = y * y * (st * st * ia2 + ct * ct * ib2) - 1.0;
+    const double disc = qb * qb - 4.0 * qa * qc;
+    const double shift = half + xc; // column = x + shift
+    const double xv = -qb / (2.0 * qa);
+    auto clampc = [&](double f) -> int { return f < 0.0 ? 0 : (f > (double)(ps - 1) ? ps - 1 : (int)f); };
+    // a pixel inside the interval, if there is one: the column nearest to the quadratic's vertex (or its
+    // neighbours, when rounding put the vertex on the other side of a pixel centre)
+    const int cm = clampc(floor(xv + shift + 0.5));
+    int seed = -1;
+#pragma unroll 1
+    for (int d = 0; d < 3 && seed < 0; ++d) {
+        const int c = cm + (d == 0 ? 0 : (d == 1 ? -1 : 1));
+        if (c >= 0 && c < ps && inside(c)) seed = c;
+    }
+    if (seed < 0) return;
+    const double sq = disc > 0.0 ? sqrt(disc) / (2.0 * qa) : 0.0;
+    int bound[2];
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+        const int dir = side == 0 ? -1 : 1;
+        int e = side == 0 ? clampc(ceil(xv - sq + shift)) : clampc(floor(xv + sq + shift));
+        e = side == 0 ? (e < seed ? e : seed) : (e > seed ? e : seed);
+        bool grow = false; // first walk towards the seed until inside, then outwards while inside
+        for (;;) {
+            if (!grow && e == seed) grow = true;
+            const int probe = grow ? e + dir : e;
+            if (grow && (probe < 0 || probe >= ps)) break;
+            const bool in = inside(probe);
+            if (!grow) { if (in) grow = true; else e -= dir; }
+            else { if (in) e = probe; else break; }
+        }
+        bound[side] = e;
+    }
+    lo = bound[0];
+    len = bound[1] - bound[0] + 1;
+}
+
+// one wave per nucleus, lane = row (ps <= 64): writes out[1]=major_axis [2]=minor_axis [3]=eccentricity [4]=orientation
+// [8]=eliptic_deviation
+static __device__ void shape_from_row(uint64_t row, int ps, int lane, float *__restrict__ o)
+{
+    int kr, sc, scc;
+    word_moments(row, kr, sc, scc);
+    // seven totals in one reduce-scatter butterfly (wave_ops.h); lane l holds the total of M[scatter_index<8>(l & 7)]
+    unsigned M[8] = {(unsigned)kr, (unsigned)(lane * kr), (unsigned)sc, (unsigned)(lane * lane * kr), (unsigned)(lane * sc), (unsigned)scc, 0u, 0u};
+    const int tot = (int)wave_reduce_scatter(M, lane);
+    // scatter_index<8> reverses three bits: slots 0..5 sit in lanes 0, 4, 2, 6, 1, 5
+    const int K = __builtin_amdgcn_readlane(tot, 0), sr = __builtin_amdgcn_readlane(tot, 4), scs = __builtin_amdgcn_readlane(tot, 2);
+    const int srr = __builtin_amdgcn_readlane(tot, 6), src = __builtin_amdgcn_readlane(tot, 1), sccs = __builtin_amdgcn_readlane(tot, 5);
+    const ShapeAxes A = shape_axes(K, sr, scs, srr, src, sccs, ps);
     // ellipse (shape.rs:80-87) XOR mask, one row per lane
     int xr = 0;
     {
-        const double ct = cos((double)angle), st = sin((double)angle);
-        const double half = (double)ps / 2.0;
-        const double xc = (double)cen1, yc = (double)cen0, a = (double)major, b = (double)minor;
+        const EllipseFrame E = ellipse_frame(A, ps);
         uint64_t ell = 0;
-        if (lane < ps && a > 0.0 && b > 0.0) { // a or b zero/NaN: every test is false
-            // The set of columns passing the test is an interval (the ellipse is convex).  Its ends are estimated
-            // from the quadratic in x and then made EXACT by evaluating the reference test itself at the ends,
-            // so the result equals the per-pixel evaluation bit for bit at ~6 tests per row instead of ps.
-            const double y = ((double)lane - half) - yc;
-            auto inside = [&](int c) -> bool {
-                const double x = ((double)c - half) - xc;
-                const double xrr = x * ct + y * st;
-                const double yrr = y * ct - x * st;
-                const double u = xrr / a, v = yrr / b;
-                return (u * u + v * v) <= 1.0;
-            };
-            const double ia2 = 1.0 / (a * a), ib2 = 1.0 / (b * b);
-            const double qa = ct * ct * ia2 + st * st * ib2;
-            const double qb = 2.0 * y * ct * st * (ia2 - ib2);
-            const double qc = y * y * (st * st * ia2 + ct * ct * ib2) - 1.0;
-            const double disc = qb * qb - 4.0 * qa * qc;
-            const double shift = half + xc; // column = x + shift
-            const double xv = -qb / (2.0 * qa);
-            auto clampc = [&](double f) -> int { return f < 0.0 ? 0 : (f > (double)(ps - 1) ? ps - 1 : (int)f); };
-            // a pixel inside the interval, if there is one: the column nearest to the quadratic's vertex (or its
-            // neighbours, when rounding put the vertex on the other side of a pixel centre)
-            const int cm = clampc(floor(xv + shift + 0.5));
-            int seed = -1;
-#pragma unroll 1
-            for (int d = 0; d < 3 && seed < 0; ++d) {
-                const int c = cm + (d == 0 ? 0 : (d == 1 ? -1 : 1));
-                if (c >= 0 && c < ps && inside(c)) seed = c;
-            }
-            if (seed >= 0) {
-                const double sq = disc > 0.0 ? sqrt(disc) / (2.0 * qa) : 0.0;
-                int bound[2];
-#pragma unroll 1
-                for (int side = 0; side < 2; ++side) {
-                    const int dir = side == 0 ? -1 : 1;
-                    int e = side == 0 ? clampc(ceil(xv - sq + shift)) : clampc(floor(xv + sq + shift));
-                    e = side == 0 ? (e < seed ? e : seed) : (e > seed ? e : seed);
-                    bool grow = false; // first walk towards the seed until inside, then outwards while inside
-                    for (;;) {
-                        if (!grow && e == seed) grow = true;
-                        const int probe = grow ? e + dir : e;
-                        if (grow && (probe < 0 || probe >= ps)) break;
-                        const bool in = inside(probe);
-                        if (!grow) { if (in) grow = true; else e -= dir; }
-                        else { if (in) e = probe; else break; }
-                    }
-                    bound[side] = e;
-                }
-                const int len = bound[1] - bound[0] + 1;
-                ell = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << bound[0];
-            }
+        if (lane < ps) {
+            int lo, len;
+            ellipse_row_span(E, ps, lane, lo, len);
+            if (len > 0) ell = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << lo;
         }
         xr = wave_sum(__popcll(ell ^ row));
     }
     if (lane == 0) {
-        o[1] = major;
-        o[2] = minor;
-        o[3] = ecc;
-        o[4] = angle;
+        o[1] = A.major;
+        o[2] = A.minor;
+        o[3] = A.ecc;
+        o[4] = A.angle;
         o[8] = (float)xr / (float)K;
     }
 }
@@ -354,6 +390,114 @@ __global__ __launch_bounds__(256) void k_shape_from_rows(int64_t n, const uint64
     if (i >= n) return;
     const uint64_t row = lane < ps ? rows[i * ps + lane] : 0ull;
     shape_from_row(row, ps, lane, out + i * (int64_t)F + col0);
+}
+
+// ---- patch sizes 65..128 (args.rs:93-94 takes any u32; `-p 128` works in the reference) ---------------------------------
+// The row-word kernels above hold a mask row in one lane's 64-bit word.  Larger patches take this plainer family (here and in
+// the other k_*.hip files): ONE 256-THREAD WORKGROUP PER NUCLEUS, thread = mask row, a row is W = 2 words.  Same arithmetic,
+// same expression trees (the pieces above are shared), no attempt at the narrow path's speed: every row tests every edge,
+// integer moments and the ellipse XOR count are reduced through LDS atomics.  Row words go out as [n][ps][W].
+static constexpr int WIDE_W = 2;
+static __device__ __forceinline__ uint64_t low_bits(int k) { return k <= 0 ? 0ull : (k >= 64 ? ~0ull : ((1ull << k) - 1ull)); }
+
+template <bool SHAPE>
+__global__ __launch_bounds__(256) void k_raster_shape_wide(int64_t n, const uint32_t *__restrict__ poly_off, const float *__restrict__ poly_xy,
+                                                           int ps, uint64_t *__restrict__ rows_out, float *__restrict__ out, int F, int col0,
+                                                           int *__restrict__ areas_out)
+{
+    __shared__ int s_tot[8];
+    const int t = threadIdx.x;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        if (t < 8) s_tot[t] = 0;
+        __syncthreads();
+        const uint32_t v0 = poly_off[i];
+        const int V = (int)(poly_off[i + 1] - v0);
+        const double half = (double)ps / 2.0;
+        uint64_t row[WIDE_W] = {0ull, 0ull};
+        if (t < ps) {
+            const double py = (double)t - half;
+            for (int e = 0; e < V; ++e) {
+                const float2 p1 = reinterpret_cast<const float2 *>(poly_xy)[v0 + e];
+                const float2 p2 = reinterpret_cast<const float2 *>(poly_xy)[v0 + (e + 1 == V ? 0 : e + 1)];
+                const double x1 = (double)p1.x, y1 = (double)p1.y, x2 = (double)p2.x, y2 = (double)p2.y;
+                if ((y1 > py) != (y2 > py)) {
+                    const int k = crossing_count(x1, y1, x2, y2, py, half, ps);
+                    row[0] ^= low_bits(k);
+                    row[1] ^= low_bits(k - 64);
+                }
+            }
+            if (rows_out) { rows_out[(i * ps + t) * WIDE_W] = row[0]; rows_out[(i * ps + t) * WIDE_W + 1] = row[1]; }
+            int p0, s0, q0, p1, s1, q1;
+            word_moments(row[0], p0, s0, q0);
+            word_moments(row[1], p1, s1, q1);
+            const int kr = p0 + p1, sc = s0 + s1 + 64 * p1, scc = q0 + q1 + 128 * s1 + 4096 * p1;
+            if (kr) { // sums stay below 2^31 for ps <= 128: 128^2 pixels x 127^2
+                atomicAdd(&s_tot[0], kr); atomicAdd(&s_tot[1], t * kr); atomicAdd(&s_tot[2], sc);
+                atomicAdd(&s_tot[3], t * t * kr); atomicAdd(&s_tot[4], t * sc); atomicAdd(&s_tot[5], scc);
+            }
+        }
+        __syncthreads();
+        const int K = s_tot[0];
+        if (areas_out && t == 0) areas_out[i] = K;
+        if (SHAPE) {
+            const ShapeAxes A = shape_axes(K, s_tot[1], s_tot[2], s_tot[3], s_tot[4], s_tot[5], ps);
+            if (t < ps) {
+                const EllipseFrame E = ellipse_frame(A, ps);
+                int lo, len;
+                ellipse_row_span(E, ps, t, lo, len);
+                const uint64_t e0 = low_bits(lo + len) & ~low_bits(lo), e1 = low_bits(lo + len - 64) & ~low_bits(lo - 64);
+                const int x = __popcll(e0 ^ row[0]) + __popcll(e1 ^ row[1]);
+                if (x) atomicAdd(&s_tot[6], x);
+            }
+            __syncthreads();
+            if (t == 0) {
+                float *o = out + i * (int64_t)F + col0;
+                o[1] = A.major; o[2] = A.minor; o[3] = A.ecc; o[4] = A.angle;
+                o[8] = (float)s_tot[6] / (float)K;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shape_from_rows_wide(int64_t n, const uint64_t *__restrict__ rows, int ps, float *__restrict__ out, int F, int col0)
+{
+    __shared__ int s_tot[8];
+    const int t = threadIdx.x;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        if (t < 8) s_tot[t] = 0;
+        __syncthreads();
+        uint64_t row[WIDE_W] = {0ull, 0ull};
+        if (t < ps) {
+            row[0] = rows[(i * ps + t) * WIDE_W]; row[1] = rows[(i * ps + t) * WIDE_W + 1];
+            int p0, s0, q0, p1, s1, q1;
+            word_moments(row[0], p0, s0, q0);
+            word_moments(row[1], p1, s1, q1);
+            const int kr = p0 + p1, sc = s0 + s1 + 64 * p1, scc = q0 + q1 + 128 * s1 + 4096 * p1;
+            if (kr) {
+                atomicAdd(&s_tot[0], kr); atomicAdd(&s_tot[1], t * kr); atomicAdd(&s_tot[2], sc);
+                atomicAdd(&s_tot[3], t * t * kr); atomicAdd(&s_tot[4], t * sc); atomicAdd(&s_tot[5], scc);
+            }
+        }
+        __syncthreads();
+        const int K = s_tot[0];
+        const ShapeAxes A = shape_axes(K, s_tot[1], s_tot[2], s_tot[3], s_tot[4], s_tot[5], ps);
+        if (t < ps) {
+            const EllipseFrame E = ellipse_frame(A, ps);
+            int lo, len;
+            ellipse_row_span(E, ps, t, lo, len);
+            const uint64_t e0 = low_bits(lo + len) & ~low_bits(lo), e1 = low_bits(lo + len - 64) & ~low_bits(lo - 64);
+            const int x = __popcll(e0 ^ row[0]) + __popcll(e1 ^ row[1]);
+            if (x) atomicAdd(&s_tot[6], x);
+        }
+        __syncthreads();
+        if (t == 0) {
+            float *o = out + i * (int64_t)F + col0;
+            o[1] = A.major; o[2] = A.minor; o[3] = A.ecc; o[4] = A.angle;
+            o[8] = (float)s_tot[6] / (float)K;
+        }
+        __syncthreads();
+    }
 }
 
 // ---- polygon-derived columns (geometric_features::*, shape.rs:89-97) -----------------------------
@@ -738,6 +882,12 @@ hipError_t launch_raster_shape(nfx_ctx *ctx, int64_t n, const uint32_t *poly_off
 {
     if (n == 0) return hipSuccess;
     ScopedTiming t(ctx, KS_RASTER_SHAPE);
+    if (ps > 64) {
+        const unsigned wgrid = (unsigned)(n < 256 * 16 ? n : 256 * 16);
+        if (out) hipLaunchKernelGGL(k_raster_shape_wide<true>, dim3(wgrid), dim3(256), 0, ctx->stream, n, poly_off, poly_xy, ps, rows_out, out, F, col0, areas_out);
+        else hipLaunchKernelGGL(k_raster_shape_wide<false>, dim3(wgrid), dim3(256), 0, ctx->stream, n, poly_off, poly_xy, ps, rows_out, out, F, col0, areas_out);
+        return hipGetLastError();
+    }
     const unsigned grid = (unsigned)((n + 3) / 4);
     if (out)
         hipLaunchKernelGGL(k_raster_shape<true>, dim3(grid), dim3(256), 0, ctx->stream, n, poly_off, poly_xy, ps, rows_out, out, F, col0, areas_out);
@@ -750,6 +900,10 @@ hipError_t launch_shape_from_rows(nfx_ctx *ctx, int64_t n, const uint64_t *rows,
 {
     if (n == 0) return hipSuccess;
     ScopedTiming t(ctx, KS_RASTER_SHAPE);
+    if (ps > 64) {
+        hipLaunchKernelGGL(k_shape_from_rows_wide, dim3((unsigned)(n < 256 * 16 ? n : 256 * 16)), dim3(256), 0, ctx->stream, n, rows, ps, out, F, col0);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_shape_from_rows, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, n, rows, ps, out, F, col0);
     return hipGetLastError();
 }

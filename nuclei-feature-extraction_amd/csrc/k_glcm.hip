@@ -285,6 +285,8 @@ __global__ __launch_bounds__(256) void k_glcm_classify(int64_t n, int ps, const 
 
 // The 14 Haralick features of one (level, offset) combination from its ten sums; one lane per combination.
 // dbg (test hook, nfx_debug_texture_counts): the six exact integers among the sums.
+// WIDE: patches above 64 x 64 hold more pairs than the x ln x table covers; that (register-rich) kernel takes plain logarithms.
+template <bool WIDE>
 static __device__ void glcm_features(const double (&a)[GL_NACC], const GlcmLuts *__restrict__ lut, float *__restrict__ o, int64_t *__restrict__ dbg)
 {
     const double N = a[0], S1 = a[1], S2 = a[2], D1 = a[3], D2 = a[4], IDM = a[5], ASMN = a[6], ENTS = a[7], HXS = a[8], HSS = a[9];
@@ -297,25 +299,29 @@ static __device__ void glcm_features(const double (&a)[GL_NACC], const GlcmLuts 
         for (int k = 0; k < 14; ++k) o[k] = qnan;
         return;
     }
+    // one reciprocal instead of fifteen f64 divisions by N, 2N and 4N (each a dozen instructions on 16 of the wave's 64 lanes);
+    // the quotients differ from true divisions in the last bit of an f64, far below the f32 the features are rounded to.
+    // angular_second_moment keeps its exact division: a single-cell matrix must come out as exactly 1.
     const double T2 = 2.0 * N;
-    const double mu = S1 / T2;
-    const double ei2 = (S2 + D2) / (4.0 * N);
+    const double rN = 1.0 / N, rT = 0.5 * rN, rQ = 0.25 * rN;
+    const double mu = S1 * rT;
+    const double ei2 = (S2 + D2) * rQ;
     const double var = ei2 - mu * mu;
-    const double eij = (S2 - D2) / (4.0 * N);
-    const double con = D2 / N, dis = D1 / N, sa = S1 / N;
-    const double sv = S2 / N - sa * sa;
+    const double eij = (S2 - D2) * rQ;
+    const double con = D2 * rN, dis = D1 * rN, sa = S1 * rN;
+    const double sv = S2 * rN - sa * sa;
     // All pairs in one (diagonal) cell -- a flat nucleus -- is known exactly: sum G^2 == (sum G)^2 in integers.  The three
     // entropies are then exactly 0, as a sum over cells finds them; the closed forms below would leave ln T - (T ln T)/T,
     // a rounding residue, and information_measure_correlation1 = 0/0 must come out NaN, not residue/residue.
     const bool one_cell = ASMN == T2 * T2;
     // ln of the two integers from the x ln x table (N <= 4032 pairs): two loads instead of two f64 logarithm expansions,
     // whose registers this spot of the kernel does not have
-    const double lnT = lut->xlnx[(int)T2] / T2;
-    const double se = one_cell ? 0.0 : lut->xlnx[(int)N] / N - HSS / N;
-    const double ent = one_cell ? 0.0 : lnT - ENTS / T2;
+    const double lnT = WIDE ? log(T2) : lut->xlnx[(int)T2] * rT;
+    const double se = one_cell ? 0.0 : (WIDE ? log(N) - HSS * rN : (lut->xlnx[(int)N] - HSS) * rN);
+    const double ent = one_cell ? 0.0 : lnT - ENTS * rT;
     const double asm_ = ASMN / (T2 * T2);
-    const double dv = D2 / N - dis * dis;
-    const double hx = one_cell ? 0.0 : lnT - HXS / T2;
+    const double dv = con - dis * dis;
+    const double hx = one_cell ? 0.0 : lnT - HXS * rT;
     const double hxy1 = 2.0 * hx; // = HXY2 for a symmetric matrix (marginalisation)
     double a2 = 1.0 - exp(-2.0 * (hxy1 - ent));
     a2 = a2 > 0.0 ? a2 : 0.0;
@@ -328,7 +334,7 @@ static __device__ void glcm_features(const double (&a)[GL_NACC], const GlcmLuts 
     o[6] = (float)sv;
     o[7] = (float)se;
     o[8] = (float)var;
-    o[9] = (float)(IDM / N);
+    o[9] = (float)(IDM * rN);
     o[10] = (float)dis;
     o[11] = (float)dv;
     o[12] = (float)((ent - hxy1) / hx);
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : (LOG2SLOT
 #pragma unroll
                 for (int k = 0; k < GL_NACC; ++k)
                     a[k] = __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long *>(src) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                glcm_features(a, lut, out + i_done * (int64_t)F + col0 + lane * 14, dbg ? dbg + (i_done * 16 + lane) * 6 : nullptr);
+                glcm_features<false>(a, lut, out + i_done * (int64_t)F + col0 + lane * 14, dbg ? dbg + (i_done * 16 + lane) * 6 : nullptr);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -642,10 +648,124 @@ __global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : (LOG2SLOT
     }
 }
 
+// ---- patch sizes 65..128: one 256-thread workgroup per nucleus (see k_geometry.hip, "patch sizes 65..128") -----------------
+// Up to 16 384 mask pixels do not fit the LDS lists and hash tables above.  This plainer form counts the pairs of one
+// (level, offset) combination into a DENSE symmetric matrix in global memory (the workgroup's own L x L slab of the workspace,
+// touched only inside the nucleus's level range) with global atomics, exactly as the reference's dense [N,L,L] tensor holds
+// them, then scans that square once for sum G^2 and sum G ln G; the pair sums are accumulated while counting, the marginal
+// and sum histograms are LDS counters.  The ten sums feed the same glcm_features as the wave kernel.
+static constexpr int GW_LMAX = 254;
+template <typename T>
+__global__ __launch_bounds__(256) void k_glcm_wide(int64_t n, int ps, const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
+                                                   const GlcmLuts *__restrict__ lut, unsigned *__restrict__ slabs, float *__restrict__ out, int F,
+                                                   int col0, int64_t *__restrict__ dbg)
+{
+    __shared__ float s_gray[NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE];
+    __shared__ uint8_t s_q[NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE];
+    __shared__ uint64_t s_rows[NFX_MAX_PATCH_SIZE][2];
+    __shared__ unsigned s_hx[256], s_hs[512];
+    __shared__ double s_red[4][8];
+    __shared__ double s_sums[16][GL_NACC];
+    __shared__ int s_range[2];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int P = ps * ps;
+    unsigned *G = slabs + (size_t)blockIdx.x * GW_LMAX * GW_LMAX;
+    const int levels[4] = {32, 64, 128, 254}; // texture.rs:19
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const T *pp = patches + (size_t)i * 3 * P;
+        for (int k = t; k < 2 * ps; k += 256) s_rows[k >> 1][k & 1] = mask_rows[(size_t)i * ps * 2 + k];
+        __syncthreads();
+        auto masked = [&](int r, int c) -> bool {
+            return (unsigned)r < (unsigned)ps && (unsigned)c < (unsigned)ps && ((s_rows[r][c >> 6] >> (c & 63)) & 1ull);
+        };
+        for (int p = t; p < P; p += 256) {
+            float g;
+            if (sizeof(T) == 1) {
+                const uint8_t *pb = reinterpret_cast<const uint8_t *>(pp);
+                float gs = u8_unit(pb[p]) + u8_unit(pb[P + p]); // utils.rs:172
+                gs = gs + u8_unit(pb[2 * P + p]);
+                g = third_of_u8_sum(gs);                          // texture.rs:36
+            } else {
+                g = gray_at<T>(pp, P, p);
+            }
+            s_gray[p] = g;
+        }
+        __syncthreads();
+        for (int li = 0; li < 4; ++li) {
+            const int L = levels[li];
+            if (t == 0) { s_range[0] = L; s_range[1] = -1; }
+            __syncthreads();
+            int qlo = L, qhi = -1;
+            for (int p = t; p < P; p += 256) {
+                const unsigned q = quant(s_gray[p], L);
+                s_q[p] = (uint8_t)q;
+                const int r = p / ps, c = p - r * ps;
+                if (masked(r, c)) { qlo = (int)q < qlo ? (int)q : qlo; qhi = (int)q > qhi ? (int)q : qhi; }
+            }
+            atomicMin(&s_range[0], qlo);
+            atomicMax(&s_range[1], qhi);
+            __syncthreads();
+            const int q0 = s_range[0], R = s_range[1] - s_range[0] + 1; // level range of the mask (R <= 0: empty mask)
+            for (int oi = 0; oi < 4; ++oi) {
+                const int dy = kGlcmOffsets[oi][0], dx = kGlcmOffsets[oi][1];
+                for (int k = t; k < R * R; k += 256) G[(size_t)(q0 + k / R) * L + q0 + k % R] = 0u;
+                s_hx[t] = 0u; s_hs[t] = 0u; s_hs[256 + t] = 0u;
+                __syncthreads(); // (workgroup-wide: the slab's zeros are in L2 before the atomics below reach it)
+                double np = 0, S1 = 0, S2 = 0, D1 = 0, D2 = 0, idm = 0;
+                for (int p = t; p < P; p += 256) {
+                    const int r = p / ps, c = p - r * ps;
+                    if (!masked(r, c) || !masked(r + dy, c + dx)) continue;
+                    const unsigned a = s_q[p], b = s_q[(r + dy) * ps + c + dx];
+                    atomicAdd(&G[(size_t)a * L + b], 1u);
+                    atomicAdd(&G[(size_t)b * L + a], 1u);
+                    atomicAdd(&s_hx[a], 1u);
+                    atomicAdd(&s_hx[b], 1u);
+                    atomicAdd(&s_hs[a + b], 1u);
+                    const double sm = (double)(a + b), d = (double)(a > b ? a - b : b - a);
+                    np += 1.0; S1 += sm; S2 += sm * sm; D1 += d; D2 += d * d; idm += 1.0 / (1.0 + d * d);
+                }
+                __syncthreads();
+                double asmn = 0, ents = 0, hxs = 0, hss = 0;
+                for (int k = t; k < R * R; k += 256) { // atomic loads: the counts live in L2, this CU's L1 may hold the zeros
+                    const unsigned g = __hip_atomic_load(&G[(size_t)(q0 + k / R) * L + q0 + k % R], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asmn += (double)g * (double)g;
+                    ents += lut->xlnx[g < (unsigned)GL_COUNTS ? g : 0u] + (g < (unsigned)GL_COUNTS ? 0.0 : (double)g * log((double)g));
+                }
+                { const unsigned h = s_hx[t]; hxs += h < (unsigned)GL_COUNTS ? lut->xlnx[h] : (double)h * log((double)h); }
+                for (int k = t; k < 512; k += 256) { const unsigned h = s_hs[k]; hss += h < (unsigned)GL_COUNTS ? lut->xlnx[h] : (double)h * log((double)h); }
+                double v[10] = {np, S1, S2, D1, D2, idm, asmn, ents, hxs, hss};
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+                    // two rounds of eight through the 4 x 8 staging array
+                    v[k] = wave_total_f64(v[k]);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if (lane == 0)
+                        for (int k = 0; k < 5; ++k) s_red[wv][k] = v[5 * half + k];
+                    __syncthreads();
+                    if (t < 5) s_sums[li * 4 + oi][5 * half + t] = (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]);
+                    __syncthreads();
+                }
+            }
+        }
+        if (t < 16) { // combination t = level * 4 + offset, the column order of texture.rs:81-157
+            double a[GL_NACC];
+#pragma unroll
+            for (int k = 0; k < GL_NACC; ++k) a[k] = s_sums[t][k];
+            glcm_features<true>(a, lut, out + i * (int64_t)F + col0 + t * 14, dbg ? dbg + (i * 16 + t) * 6 : nullptr);
+        }
+        __syncthreads();
+    }
+}
+
 static constexpr int GL_MAX_GRID = 256 * 11 * 4; // resident single-wave workgroups of the largest launch = parking slots
 static size_t glcm_slots_bytes() { return sizeof(double) * 16 * GL_NACC * (size_t)GL_MAX_GRID; }
+static constexpr int GW_GRID = 256; // workgroups (and dense slabs) of the wide kernel
 size_t glcm_scratch_bytes(const Job &job)
 {
+    if (job.ps > 64) return sizeof(unsigned) * (size_t)GW_GRID * GW_LMAX * GW_LMAX; // k_glcm_wide's count slabs (66 MB)
     const size_t n = (size_t)(job.n > 0 ? job.n : 1);
     return glcm_slots_bytes() + sizeof(int) * (GL_CLASSES * n + 64);
 }
@@ -698,6 +818,17 @@ hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
     hipError_t e = prepare_glcm(ctx);
     if (e != hipSuccess) return e;
     ScopedTiming t(ctx, KS_GLCM);
+    if (job.ps > 64) {
+        const GlcmLuts *wlut = reinterpret_cast<const GlcmLuts *>(ctx->glcm_lut);
+        const unsigned wgrid = (unsigned)(job.n < GW_GRID ? job.n : GW_GRID);
+        if (job.patches_f32)
+            hipLaunchKernelGGL(k_glcm_wide<float>, dim3(wgrid), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const float *>(job.patches),
+                               job.mask_rows, wlut, reinterpret_cast<unsigned *>(scratch), job.out, job.F, col0, job.dbg_glcm);
+        else
+            hipLaunchKernelGGL(k_glcm_wide<uint8_t>, dim3(wgrid), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const uint8_t *>(job.patches),
+                               job.mask_rows, wlut, reinterpret_cast<unsigned *>(scratch), job.out, job.F, col0, job.dbg_glcm);
+        return hipGetLastError();
+    }
     double *slots = reinterpret_cast<double *>(scratch);
     int *lists = reinterpret_cast<int *>(reinterpret_cast<char *>(scratch) + glcm_slots_bytes());
     int *counts = lists + GL_CLASSES * job.n;

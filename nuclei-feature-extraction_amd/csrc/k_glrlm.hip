@@ -53,13 +53,84 @@ static __device__ __forceinline__ unsigned eq16(const unsigned (&a)[4], unsigned
     return eq4(a[0], b0) | (eq4(a[1], b1) << 4) | (eq4(a[2], b2) << 8) | (eq4(a[3], b3) << 12);
 }
 
+// per-lane constant weights of the 17 features: with bin = lane + 64 k a lane always sees the same run length
+// l = lane % 16 + 1 and six fixed gray levels g_k = lane / 16 + 4 k + 1
+struct RlWeights {
+    double l, l2, il2, g2[6], ig2[6], wmid[6], wext[6];
+    __device__ __forceinline__ void init(int lane)
+    {
+        l = (double)((lane & 15) + 1);
+        l2 = l * l; il2 = 1.0 / l2;
+        const double cmid = ((double)RL_LEVELS + 1.0) / 2.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double g = (double)((lane >> 4) + 4 * k + 1);
+            g2[k] = g * g;
+            ig2[k] = 1.0 / g2[k];
+            const double e = (g - cmid) * (g - cmid);
+            wext[k] = e;
+            wmid[k] = 1.0 / (1.0 + e);
+        }
+    }
+};
+
+// The 17 features of one direction (texture.rs:244-301) from the 384 bins in LDS, by one wave; clears the bins.
+// o: the direction's 17 columns; dbg_bins: test hook (nfx_debug_texture_counts), the direction's [level][length] counts
+static __device__ __forceinline__ void rl_features(const RlWeights &W, unsigned *s_R, int lane, double Np, float *__restrict__ o,
+                                                   uint32_t *__restrict__ dbg_bins)
+{
+    const double l = W.l, l2 = W.l2, il2 = W.il2;
+    const double (&g2)[6] = W.g2, (&ig2)[6] = W.ig2, (&wmid)[6] = W.wmid, (&wext)[6] = W.wext;
+    // weighted sums over the bins this lane owns
+    double nr = 0, sre = 0, lre = 0, lgre = 0, hgre = 0, srlge = 0, srhge = 0, lrlge = 0, lrhge = 0;
+    double srmge = 0, lrmge = 0, srege = 0, lrege = 0, rlm = 0, gln = 0, colsum = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const unsigned bin = s_R[lane + 64 * k];
+        const double v = (double)bin;
+        s_R[lane + 64 * k] = 0u;
+        if (dbg_bins) dbg_bins[lane + 64 * k] = bin; // test hook (nfx_debug_texture_counts): [level][length]
+        nr += v;
+        const double vs = v * il2, vl = v * l2;
+        sre += vs; lre += vl;
+        lgre += v * ig2[k]; hgre += v * g2[k];
+        srlge += vs * ig2[k]; srhge += vs * g2[k];
+        lrlge += vl * ig2[k]; lrhge += vl * g2[k];
+        srmge += vs * wmid[k]; lrmge += vl * wmid[k];
+        srege += vs * wext[k]; lrege += vl * wext[k];
+        rlm += v * l;
+        colsum += v;
+        // row sum of gray level g_k over the 16 lanes that share lane/16
+        const double rs = row16_total_f64(v);
+        if ((lane & 15) == 0) gln += rs * rs;
+    }
+    // column sum of run length l over the 4 lanes that share lane%16
+    colsum += __shfl_xor(colsum, 16, 64);
+    colsum += __shfl_xor(colsum, 32, 64);
+    const double rln = lane < 16 ? colsum * colsum : 0.0;
+    // sixteen totals at once (wave_ops.h: reduce-scatter butterfly), in column order (texture.rs:244-301): lane l then
+    // holds the total of V[scatter_index<16>(l & 15)], and sixteen lanes do the sixteen divisions side by side
+    double V[16] = {sre, lre, gln, rln, lgre, hgre, srlge, srhge, lrlge, lrhge, srmge, lrmge, srege, lrege, nr, rlm};
+    const double tot = wave_reduce_scatter(V, lane);
+    // scatter_index<16> reverses the four bits: V[14] (nr) sits in lanes 7 + 16k, V[15] (rlm) in lanes 15 + 16k
+    const double nr_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 7), __builtin_amdgcn_readlane(__double2loint(tot), 7));
+    const double rlm_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 15), __builtin_amdgcn_readlane(__double2loint(tot), 15));
+    if (lane < 16) {
+                        const int idx = scatter_index<16>(lane);
+        const double mean = rlm_t / nr_t;
+        const double q = idx == 14 ? nr_t / Np : tot / nr_t; // run_percentage = Nr / Np; everything else over Nr
+        o[idx] = (float)q;                                    // idx 15: run_length_mean
+        if (idx == 1) o[16] = (float)(q - mean * mean);       // run_length_variance = sum R (l-mean)^2 / Nr = lre/nr - mean^2
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__restrict__ patches,
                                               const uint64_t *__restrict__ mask_rows, float *__restrict__ out, int F,
                                               int col0, uint32_t *__restrict__ dbg_bins)
 {
     constexpr int QS = 68; // byte-map row stride: lane = row reads of one column spread over the banks
-    __shared__ uint8_t s_q_all[4][NFX_MAX_PATCH_SIZE * QS];
+    __shared__ uint8_t s_q_all[4][NFX_ROW_WORD_PS * QS];
     __shared__ unsigned s_R_all[4][RL_BINS];
     __shared__ uint64_t s_rows_all[4][64];
     __shared__ __attribute__((aligned(16))) uint64_t s_C_all[4][4 * 64]; // vector path: C_d[r] assembled from 16-bit pieces
@@ -70,7 +141,7 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
     uint64_t *s_C = s_C_all[wv];
     const int P = ps * ps;
     // vector staging: rows are whole 16-byte pieces, every patch starts on a 16-byte boundary
-    constexpr int NPC = NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE / 16 / 64; // pieces per lane and channel (4)
+    constexpr int NPC = NFX_ROW_WORD_PS * NFX_ROW_WORD_PS / 16 / 64; // pieces per lane and channel (4)
     const bool vec = sizeof(T) == 1 && (ps & 15) == 0 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0;
     const int npieces = P / 16;
     uint4 pre[3][NPC];
@@ -89,20 +160,8 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
         }
     };
 
-    // per-lane constant weights: l = lane%16 + 1, g_k = lane/16 + 4k + 1
-    const double l = (double)((lane & 15) + 1);
-    const double l2 = l * l, il2 = 1.0 / l2;
-    double g2[6], ig2[6], wmid[6], wext[6];
-    const double cmid = ((double)RL_LEVELS + 1.0) / 2.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const double g = (double)((lane >> 4) + 4 * k + 1);
-        g2[k] = g * g;
-        ig2[k] = 1.0 / g2[k];
-        const double e = (g - cmid) * (g - cmid);
-        wext[k] = e;
-        wmid[k] = 1.0 / (1.0 + e);
-    }
+    RlWeights Wt;
+    Wt.init(lane);
 #pragma unroll
     for (int k = 0; k < 6; ++k) s_R[lane + 64 * k] = 0u;
     wave_lds_fence();
@@ -279,49 +338,67 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
                 }
             }
             wave_lds_fence();
-            // weighted sums over the bins this lane owns
-            double nr = 0, sre = 0, lre = 0, lgre = 0, hgre = 0, srlge = 0, srhge = 0, lrlge = 0, lrhge = 0;
-            double srmge = 0, lrmge = 0, srege = 0, lrege = 0, rlm = 0, gln = 0, colsum = 0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const unsigned bin = s_R[lane + 64 * k];
-                const double v = (double)bin;
-                s_R[lane + 64 * k] = 0u;
-                if (dbg_bins) dbg_bins[(i * 4 + d) * RL_BINS + lane + 64 * k] = bin; // test hook (nfx_debug_texture_counts): [level][length]
-                nr += v;
-                const double vs = v * il2, vl = v * l2;
-                sre += vs; lre += vl;
-                lgre += v * ig2[k]; hgre += v * g2[k];
-                srlge += vs * ig2[k]; srhge += vs * g2[k];
-                lrlge += vl * ig2[k]; lrhge += vl * g2[k];
-                srmge += vs * wmid[k]; lrmge += vl * wmid[k];
-                srege += vs * wext[k]; lrege += vl * wext[k];
-                rlm += v * l;
-                colsum += v;
-                // row sum of gray level g_k over the 16 lanes that share lane/16
-                const double rs = row16_total_f64(v);
-                if ((lane & 15) == 0) gln += rs * rs;
-            }
-            // column sum of run length l over the 4 lanes that share lane%16
-            colsum += __shfl_xor(colsum, 16, 64);
-            colsum += __shfl_xor(colsum, 32, 64);
-            const double rln = lane < 16 ? colsum * colsum : 0.0;
-            // sixteen totals at once (wave_ops.h: reduce-scatter butterfly), in column order (texture.rs:244-301): lane l then
-            // holds the total of V[scatter_index<16>(l & 15)], and sixteen lanes do the sixteen divisions side by side
-            double V[16] = {sre, lre, gln, rln, lgre, hgre, srlge, srhge, lrlge, lrhge, srmge, lrmge, srege, lrege, nr, rlm};
-            const double tot = wave_reduce_scatter(V, lane);
-            // scatter_index<16> reverses the four bits: V[14] (nr) sits in lanes 7 + 16k, V[15] (rlm) in lanes 15 + 16k
-            const double nr_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 7), __builtin_amdgcn_readlane(__double2loint(tot), 7));
-            const double rlm_t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tot), 15), __builtin_amdgcn_readlane(__double2loint(tot), 15));
-            if (lane < 16) {
-                float *o = out + i * (int64_t)F + col0 + 17 * d;
-                const int idx = scatter_index<16>(lane);
-                const double mean = rlm_t / nr_t;
-                const double q = idx == 14 ? nr_t / Np : tot / nr_t; // run_percentage = Nr / Np; everything else over Nr
-                o[idx] = (float)q;                                    // idx 15: run_length_mean
-                if (idx == 1) o[16] = (float)(q - mean * mean);       // run_length_variance = sum R (l-mean)^2 / Nr = lre/nr - mean^2
-            }
+            rl_features(Wt, s_R, lane, Np, out + i * (int64_t)F + col0 + 17 * d, dbg_bins ? dbg_bins + (i * 4 + d) * RL_BINS : nullptr);
             wave_lds_fence();
+        }
+    }
+}
+
+// ---- patch sizes 65..128: one 256-thread workgroup per nucleus (see k_geometry.hip, "patch sizes 65..128") -----------------
+// The level map (0xFF outside the mask) sits in LDS as bytes; every thread walks its pixels, and a pixel that starts a run
+// (its predecessor along the direction is outside the mask or of another level) follows the run for at most 16 steps and bumps
+// one of the 384 bins; wave 0 turns the bins into the 17 features with the same code as the wave kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void k_glrlm_wide(int64_t n, int ps, const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
+                                                    float *__restrict__ out, int F, int col0, uint32_t *__restrict__ dbg_bins)
+{
+    __shared__ uint8_t s_q[NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE];
+    __shared__ unsigned s_R[RL_BINS];
+    __shared__ int s_np;
+    const int t = threadIdx.x, lane = t & 63;
+    const int P = ps * ps;
+    RlWeights Wt;
+    Wt.init(lane);
+    for (int k = t; k < RL_BINS; k += 256) s_R[k] = 0u;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        if (t == 0) s_np = 0;
+        __syncthreads();
+        const T *pp = patches + (size_t)i * 3 * P;
+        const uint64_t *rows = mask_rows + (size_t)i * ps * 2;
+        int np = 0;
+        for (int p = t; p < P; p += 256) {
+            const int r = p / ps, c = p - r * ps;
+            unsigned q = 0xFFu;
+            if ((rows[2 * r + (c >> 6)] >> (c & 63)) & 1ull) {
+                float gs = RPx<T>::ld(pp, p) + RPx<T>::ld(pp, P + p);
+                gs = gs + RPx<T>::ld(pp, 2 * P + p);
+                gs = sizeof(T) == 1 ? third_of_u8_sum(gs) : gs / 3.0f; // texture.rs:189
+                int qi = (int)floorf(gs * (float)RL_LEVELS);
+                qi = qi < 0 ? 0 : (qi > RL_LEVELS - 1 ? RL_LEVELS - 1 : qi);
+                q = (unsigned)qi;
+                ++np;
+            }
+            s_q[p] = (uint8_t)q;
+        }
+        np = wave_total_i32(np);
+        if (lane == 0 && np) atomicAdd(&s_np, np);
+        __syncthreads();
+        const double Np = (double)s_np; // pixel_count, texture.rs:196
+        for (int d = 0; d < 4; ++d) {
+            const int dx = kRlDirs[d][0], dy = kRlDirs[d][1];
+            for (int p = t; p < P; p += 256) {
+                const unsigned q = s_q[p];
+                if (q == 0xFFu) continue;
+                const int r = p / ps, c = p - r * ps;
+                const int rp = r - dy, cp = c - dx;
+                if (rp >= 0 && rp < ps && cp >= 0 && cp < ps && s_q[rp * ps + cp] == q) continue; // not a run start
+                int len = 1, rn = r + dy, cn = c + dx;
+                while (len < RL_MAXLEN && rn >= 0 && rn < ps && cn >= 0 && cn < ps && s_q[rn * ps + cn] == q) { ++len; rn += dy; cn += dx; }
+                atomicAdd(&s_R[q * RL_MAXLEN + (len - 1)], 1u); // runs longer than 16 share the last bin
+            }
+            __syncthreads();
+            if (t < 64) rl_features(Wt, s_R, lane, Np, out + i * (int64_t)F + col0 + 17 * d, dbg_bins ? dbg_bins + (i * 4 + d) * RL_BINS : nullptr);
+            __syncthreads();
         }
     }
 }
@@ -330,6 +407,16 @@ hipError_t launch_glrlm(nfx_ctx *ctx, const Job &job, int col0)
 {
     if (job.n == 0) return hipSuccess;
     ScopedTiming t(ctx, KS_GLRLM);
+    if (job.ps > NFX_ROW_WORD_PS) {
+        const unsigned wgrid = (unsigned)(job.n < 256 * 8 ? job.n : 256 * 8);
+        if (job.patches_f32)
+            hipLaunchKernelGGL(k_glrlm_wide<float>, dim3(wgrid), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const float *>(job.patches),
+                               job.mask_rows, job.out, job.F, col0, job.dbg_glrlm);
+        else
+            hipLaunchKernelGGL(k_glrlm_wide<uint8_t>, dim3(wgrid), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const uint8_t *>(job.patches),
+                               job.mask_rows, job.out, job.F, col0, job.dbg_glrlm);
+        return hipGetLastError();
+    }
     const int64_t maxb = 256 * 7 * 2, need = (job.n + 3) / 4; // 7 workgroups (28 waves) fit a CU's LDS
     const unsigned grid = (unsigned)(need < maxb ? need : maxb);
     if (job.patches_f32)

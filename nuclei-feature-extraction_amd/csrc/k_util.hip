@@ -65,9 +65,13 @@ __global__ __launch_bounds__(256) void k_pack_masks(int64_t nrows, const float *
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= nrows) return;
-    const bool on = lane < ps && masks[r * ps + lane] != 0.0f;
-    const uint64_t w = __ballot(on);
-    if (lane == 0) rows[r] = w;
+    const int W = (ps + 63) >> 6; // one word per row up to ps = 64, two words up to 128
+    for (int k = 0; k < W; ++k) {
+        const int c = 64 * k + lane;
+        const bool on = c < ps && masks[r * ps + c] != 0.0f;
+        const uint64_t w = __ballot(on);
+        if (lane == 0) rows[r * W + k] = w;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_unpack_masks(int64_t nrows, const uint64_t *__restrict__ rows, int ps,
@@ -76,8 +80,12 @@ __global__ __launch_bounds__(256) void k_unpack_masks(int64_t nrows, const uint6
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= nrows) return;
-    const uint64_t w = rows[r];
-    if (lane < ps) masks[r * ps + lane] = ((w >> lane) & 1ull) ? 1.0f : 0.0f;
+    const int W = (ps + 63) >> 6;
+    for (int k = 0; k < W; ++k) {
+        const uint64_t w = rows[r * W + k];
+        const int c = 64 * k + lane;
+        if (c < ps) masks[r * ps + c] = ((w >> lane) & 1ull) ? 1.0f : 0.0f;
+    }
 }
 
 // Rust's `f32 as i64` (utils.rs:159-162): truncates, saturates, NaN -> 0 (a C cast of such values is undefined).  The result

@@ -296,6 +296,7 @@ void nfx_ctx_destroy(nfx_ctx *ctx)
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->gabor_tab) (void)hipFree(ctx->gabor_tab);
+    if (ctx->gabor_dense) (void)hipFree(ctx->gabor_dense);
     if (ctx->od_lut) (void)hipFree(ctx->od_lut);
     if (ctx->glcm_lut) (void)hipFree(ctx->glcm_lut);
     delete ctx;
@@ -364,7 +365,7 @@ static nfx_status check_common(nfx_ctx *ctx, int64_t n, int64_t nv, int ps)
     if (!ctx) return NFX_ERR_INVALID_ARGUMENT;
     if (n < 0 || nv < 0) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "negative size");
     if (ps < 1) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "patch size must be >= 1");
-    if (ps > NFX_MAX_PATCH_SIZE) return fail(ctx, NFX_ERR_UNSUPPORTED, "patch size > 64 is not supported by the gfx950 row-word kernels");
+    if (ps > NFX_MAX_PATCH_SIZE) return fail(ctx, NFX_ERR_UNSUPPORTED, "patch size > 128 is not supported");
     if (nv > 0xFFFFFFFFll) return fail(ctx, NFX_ERR_UNSUPPORTED, "more than 2^32-1 vertices in one call");
     return NFX_OK;
 }
@@ -425,7 +426,7 @@ static size_t extract_ws_bytes(const int *sets, int n_sets, int64_t n, int64_t n
     size_t b = 0;
     b += al(sizeof(float) * 2 * (size_t)nv);                     // centred polygons
     if (need_centroids) b += al(sizeof(float) * 2 * (size_t)n);
-    if (any_pixel_set(sets, n_sets)) b += al(sizeof(uint64_t) * (size_t)n * ps);
+    if (any_pixel_set(sets, n_sets)) b += al(sizeof(uint64_t) * (size_t)n * ps * mask_words_per_row(ps));
     if (count_set(sets, n_sets, NFX_SET_GLCM)) b += al(sizeof(int) * (size_t)n); // mask areas
     if (count_set(sets, n_sets, NFX_SET_GEOMETRY)) b += al(polygon_scratch_bytes(n, nv));
     if (gather) b += al((size_t)n * 3 * ps * ps);
@@ -454,7 +455,7 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
     if (!centroids && image) centroids = (float *)ws_alloc(ctx, sizeof(float) * 2 * (size_t)n);
     uint64_t *rows = nullptr;
     const bool pix = any_pixel_set(sets, n_sets);
-    if (pix) rows = (uint64_t *)ws_alloc(ctx, sizeof(uint64_t) * (size_t)n * ps);
+    if (pix) rows = (uint64_t *)ws_alloc(ctx, sizeof(uint64_t) * (size_t)n * ps * mask_words_per_row(ps));
     int *areas = count_set(sets, n_sets, NFX_SET_GLCM) ? (int *)ws_alloc(ctx, sizeof(int) * (size_t)n) : nullptr;
     if (!centred || (pix && !rows) || (image && !centroids) || (count_set(sets, n_sets, NFX_SET_GLCM) && !areas))
         return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
@@ -562,7 +563,7 @@ static size_t trait_ws_bytes(int set, int64_t n, int64_t nv, int ps)
 {
     Job job;
     job.n = n; job.ps = ps; job.batch_size = (int)(n > 0 ? n : 1);
-    size_t need = al(8 * (size_t)n * ps + 8) + 4096;
+    size_t need = al(8 * (size_t)n * ps * mask_words_per_row(ps) + 8) + 4096;
     if (set == NFX_SET_GEOMETRY) need += al(polygon_scratch_bytes(n, nv));
     if (set == NFX_SET_COLOR) need += al(color_scratch_bytes(job));
     if (set == NFX_SET_GLCM) need += al(glcm_scratch_bytes(job));
@@ -628,7 +629,7 @@ nfx_status nfx_rasterize_polygons(nfx_ctx *ctx, int64_t n, int64_t nv, const uin
     if (!poly_offsets || (nv && !poly_xy)) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null input");
     NFX_HIP(ctx, hipSetDevice(ctx->device));
     StreamScope stream_scope(ctx, mem);
-    const size_t rows_b = sizeof(uint64_t) * (size_t)n * ps, mask_b = sizeof(float) * (size_t)n * ps * ps;
+    const size_t rows_b = sizeof(uint64_t) * (size_t)n * ps * mask_words_per_row(ps), mask_b = sizeof(float) * (size_t)n * ps * ps;
     if (mem == NFX_MEM_DEVICE) {
         uint64_t *rows = mask_rows;
         if (!rows) {
@@ -723,7 +724,7 @@ nfx_status nfx_compute_features_batched(nfx_ctx *ctx, int set, int64_t n, int64_
         if (!poly_offsets || !poly_xy || !masks || (set != NFX_SET_GEOMETRY && !patchs) || !d_out)
             return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
     }
-    uint64_t *rows = (uint64_t *)ws_alloc(ctx, 8 * (size_t)n * ps + 8);
+    uint64_t *rows = (uint64_t *)ws_alloc(ctx, 8 * (size_t)n * ps * mask_words_per_row(ps) + 8);
     if (!rows) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
     NFX_HIP(ctx, launch_pack_masks(ctx, n, masks, ps, rows));
     job.poly_off = poly_offsets; job.poly_xy = poly_xy; job.patches = patchs; job.mask_rows = rows; job.out = d_out;
@@ -854,7 +855,7 @@ nfx_status nfx_debug_texture_counts(nfx_ctx *ctx, int64_t n, int64_t nv, const u
     const size_t gb = sizeof(int64_t) * 96 * (size_t)n, rb = sizeof(uint32_t) * 4 * 384 * (size_t)n, fb = sizeof(float) * 224 * (size_t)n;
     Job job;
     job.n = n; job.ps = ps; job.batch_size = 100;
-    size_t need = al(8 * nv + 8) + al(8 * (size_t)n * ps + 8) + al(glcm_scratch_bytes(job)) + al(fb + 8) + 4096;
+    size_t need = al(8 * nv + 8) + al(8 * (size_t)n * ps * mask_words_per_row(ps) + 8) + al(glcm_scratch_bytes(job)) + al(fb + 8) + 4096;
     if (mem == NFX_MEM_HOST) {
         if ((st = check_offsets(ctx, ring_offsets, n, nv, "ring_offsets")) != NFX_OK) return st;
         need += al(4 * (n + 1)) + al(8 * nv + 8) + al(3 * n * P + 8) + al(gb + 8) + al(rb + 8);
@@ -871,7 +872,7 @@ nfx_status nfx_debug_texture_counts(nfx_ctx *ctx, int64_t n, int64_t nv, const u
         if (!ring_offsets || !ring_xy || !patches_u8 || (glcm_sums && !d_g) || (glrlm_bins && !d_r)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
     }
     float *centred = (float *)ws_alloc(ctx, 8 * (size_t)nv + 8);
-    uint64_t *rows = (uint64_t *)ws_alloc(ctx, 8 * (size_t)n * ps + 8);
+    uint64_t *rows = (uint64_t *)ws_alloc(ctx, 8 * (size_t)n * ps * mask_words_per_row(ps) + 8);
     float *feat = (float *)ws_alloc(ctx, fb + 8); // the feature columns themselves are computed and dropped
     void *scr = ws_alloc(ctx, glcm_scratch_bytes(job));
     if (!centred || !rows || !feat || !scr) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");

@@ -26,6 +26,10 @@ enum KernelSlot {
 extern const char *const kKernelSlotNames[KS_COUNT];
 
 static constexpr int kNumCols[NFX_SET_COUNT] = {12, 18, 224, 68, 96};
+// The fast kernels hold one mask row in one lane's 64-bit word; patches above this size take the "wide" family
+// (one 256-thread workgroup per nucleus, mask rows of two words), up to NFX_MAX_PATCH_SIZE
+#define NFX_ROW_WORD_PS 64
+static inline int mask_words_per_row(int ps) { return ps > NFX_ROW_WORD_PS ? 2 : 1; }
 
 struct Timing {
     hipEvent_t start, stop;
@@ -55,6 +59,7 @@ struct nfx_ctx {
     double total_ms[nfx::KS_COUNT] = {};
     // Gabor filter tables (device), built lazily
     float *gabor_tab = nullptr;
+    float *gabor_dense = nullptr; // the dense 48 x 30 x 30 bank of the wide (ps > 64) kernel
     // u8 -> optical-density lookup (device), built lazily
     float *od_lut = nullptr;
     // GLCM rank-difference / x ln x tables (device), built lazily
