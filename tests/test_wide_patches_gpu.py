@@ -63,10 +63,14 @@ def test_wide_all_sets_match_the_oracle(nfx, synth, ctx, ps):
 def test_wide_texture_counts_are_exact(ctx):
     ps, n = 96, 10
     off, xy, pu8 = par.make_inputs(53, n, ps)
+    c = 900.0
+    full = np.array([[c - 2 * ps, c - 2 * ps], [c + 2 * ps, c - 2 * ps], [c + 2 * ps, c + 2 * ps], [c - 2 * ps, c + 2 * ps], [c - 2 * ps, c - 2 * ps]], np.float32)
+    off, xy = par.concat_rings((off, xy), (np.array([0, 5], np.uint32), full))    # a mask that covers the whole patch: 96 x 95 pairs
+    pu8 = np.concatenate([pu8, pu8[:1]])
     got = ctx.debug_texture_counts(off, xy, pu8, ps)
     want = orc.texture_counts(off, xy, pu8, ps)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
-    assert int(want[0][0, 3, 0, 0]) > 4032          # more pairs than any 64 x 64 patch holds
+    assert int(want[0][:, 3, 0, 0].max()) > 4032    # more pairs than any 64 x 64 patch holds (beyond the wave kernel's tables)
 
 
 @pytest.mark.parametrize("set_id", range(5))
