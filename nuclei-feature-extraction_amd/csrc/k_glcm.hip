@@ -9,7 +9,7 @@
 // thousand), so the matrix is >90 % zeros.  Here nothing dense is ever built or reduced:
 //
 //   * ONE WAVEFRONT PER NUCLEUS (single-wave workgroups, persistent): no cross-wave barrier or reduction.
-//     k_glcm_classify sorts the nuclei into four lists by mask size (= hash capacity); each list has its own
+//     k_glcm_classify sorts the nuclei into six lists by mask size (= list and hash capacity); each list has its own
 //     instantiation, so a wave knows its next nucleus and requests that nucleus's whole u8 patch (16-byte pieces,
 //     in registers) and mask row while it works on the current one: no HBM latency on the critical path;
 //   * the mask's pixels are compacted into an LDS list, one word per pixel: r << 24 | c << 16 | level128 << 8 |
@@ -245,8 +245,10 @@ static __device__ __forceinline__ void sweep(unsigned *tab, int words, unsigned 
 
 // ---- mask-size classes ---------------------------------------------------------------------------------------
 // One list of nucleus indices per hash capacity, filled by k_glcm_classify (order inside a list is irrelevant).
-static constexpr int GL_CLASSES = 4;
-static __device__ __host__ __forceinline__ int glcm_class(int K) { return K <= 512 ? 0 : K <= 1024 ? 1 : K <= 2048 ? 2 : 3; }
+// A wave's LDS footprint grows with its class's capacity and LDS is what limits the waves per CU (11 / 9 / 8 / 6 / 5 / 3 for
+// the six capacities at 48 x 48), so the steps are fine where the nuclei are: half-steps between the powers of two.
+static constexpr int GL_CLASSES = 6;
+static __device__ __host__ __forceinline__ int glcm_class(int K) { return K <= 512 ? 0 : K <= 768 ? 1 : K <= 1024 ? 2 : K <= 1536 ? 3 : K <= 2048 ? 4 : 5; }
 
 __global__ __launch_bounds__(256) void k_glcm_classify(int64_t n, int ps, const uint64_t *__restrict__ mask_rows, const int *__restrict__ areas,
                                                        int *__restrict__ lists, int *__restrict__ counts)
@@ -342,18 +344,17 @@ static __device__ void glcm_features(const double (&a)[GL_NACC], const GlcmLuts 
 }
 
 // ---- the kernel -------------------------------------------------------------------------------------------
-// LOG2SLOTS: size class; serves the nuclei of its class list (K <= 2^LOG2SLOTS / 2 mask pixels).
+// QCAP: size class; serves the nuclei of its class list (K <= QCAP mask pixels).
 // NPRE: 16-byte pieces of a u8 patch per lane (3 ps^2 / 1024 rounded up: 3, 7 or 12 for ps <= 32, 48, 64)
-template <typename T, int LOG2SLOTS, int NPRE>
-__global__ __launch_bounds__(64, ((LOG2SLOTS <= 10 && NPRE <= 7) ? 3 : (LOG2SLOTS <= 12 ? 2 : 1))) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int ps,
+template <typename T, int QCAP, int NPRE>
+__global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048 ? 2 : 1))) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int ps,
                                              const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
                                              const GlcmLuts *__restrict__ lut, double *__restrict__ slots, float *__restrict__ out, int F,
                                              int col0, int64_t *__restrict__ dbg)
 {
-    // hash slots per list entry: 11/8 -- the 1.3-10 KB of LDS saved against 2 buy another wave per CU (11, 8, 5 and 3
-    // instead of 10, 7, 4 and 2) -- except in the first class of 64x64 patches, whose table memory doubles as the staging
-    // area of the 12 KB patch
-    constexpr int QCAP = (1 << LOG2SLOTS) / 2, SLOTS = (LOG2SLOTS == 10 && NPRE > 7) ? 2 * QCAP : 11 * QCAP / 8;
+    // hash slots per list entry: 11/8 -- the LDS saved against 2 buys another wave per CU -- except in the first class of
+    // 64x64 patches, whose table memory doubles as the staging area of the 12 KB patch
+    constexpr int SLOTS = (QCAP == 512 && NPRE > 7) ? 2 * QCAP : 11 * QCAP / 8;
     constexpr int TAB_WORDS = GL_H128_OFF + SLOTS;
     __shared__ __attribute__((aligned(16))) unsigned s_mem[TAB_WORDS + GL_HIST_WORDS]; // tables | histograms
     __shared__ unsigned s_q[QCAP + 1];         // list entry: r << 24 | c << 16 | level128 << 8 | level254 (levels 64 and 32
@@ -791,24 +792,35 @@ hipError_t prepare_glcm(nfx_ctx *ctx)
     return hipSuccess;
 }
 
+// One launch per size class whose capacity the patch can reach.  The grid is four rounds of the workgroups a CU really
+// holds (asked of the runtime once per instantiation: LDS allocation granularity and register budget included); blocks
+// beyond a list's length exit at once.
+template <typename T, int QCAP, int NPRE>
+static void launch_class(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *slots, const int *lists, const int *counts, int cls, int col0)
+{
+    static int wgs_per_cu = 0; // same answer for every context: one device type per process
+    if (wgs_per_cu == 0) {
+        int b = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_glcm<T, QCAP, NPRE>, 64, 0) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 1; }
+        wgs_per_cu = b > 11 ? 11 : b;
+    }
+    const int64_t m = 256ll * wgs_per_cu * 4;
+    static_assert(256 * 11 * 4 <= GL_MAX_GRID, "every launch's waves have a parking slot");
+    const unsigned grid = (unsigned)(job.n < m ? job.n : m);
+    hipLaunchKernelGGL((k_glcm<T, QCAP, NPRE>), dim3(grid), dim3(64), 0, ctx->stream, lists + (int64_t)cls * job.n, counts + cls, job.ps,
+                       reinterpret_cast<const T *>(job.patches), job.mask_rows, lut, slots, job.out, job.F, col0, job.dbg_glcm);
+}
+
 template <typename T, int NPRE>
 static void launch_classes(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *slots, const int *lists, const int *counts, int col0)
 {
-    const T *p = reinterpret_cast<const T *>(job.patches);
     const int P = job.ps * job.ps;
-    auto grid = [&](int wgs_per_cu) { const int64_t m = 256ll * wgs_per_cu * 4; return (unsigned)(job.n < m ? job.n : m); };
-    static_assert(256 * 11 * 4 <= GL_MAX_GRID, "every launch's waves have a parking slot");
-    // Smaller classes keep more nuclei in flight per CU (15-16 KB of LDS per wave for masks up to 512 pixels, 20 KB up
-    // to 1024, 31 KB up to 2048, 53 KB up to 4096).  Blocks beyond a list's length exit at once.
-    const int64_t n = job.n;
-#define NFX_GLCM_LAUNCH(LOG2, WGS, CLS)                                                                                        \
-    hipLaunchKernelGGL((k_glcm<T, LOG2, NPRE>), dim3(grid(WGS)), dim3(64), 0, ctx->stream, lists + CLS * n, counts + CLS, job.ps, p, \
-                       job.mask_rows, lut, slots, job.out, job.F, col0, job.dbg_glcm)
-    NFX_GLCM_LAUNCH(10, (NPRE <= 7 ? 11 : 10), 0);
-    if (P > 512) NFX_GLCM_LAUNCH(11, 8, 1);
-    if (P > 1024) NFX_GLCM_LAUNCH(12, 5, 2);
-    if (P > 2048) NFX_GLCM_LAUNCH(13, 3, 3);
-#undef NFX_GLCM_LAUNCH
+    launch_class<T, 512, NPRE>(ctx, job, lut, slots, lists, counts, 0, col0);
+    if (P > 512) launch_class<T, 768, NPRE>(ctx, job, lut, slots, lists, counts, 1, col0);
+    if (P > 768) launch_class<T, 1024, NPRE>(ctx, job, lut, slots, lists, counts, 2, col0);
+    if (P > 1024) launch_class<T, 1536, NPRE>(ctx, job, lut, slots, lists, counts, 3, col0);
+    if (P > 1536) launch_class<T, 2048, NPRE>(ctx, job, lut, slots, lists, counts, 4, col0);
+    if (P > 2048) launch_class<T, 4096, NPRE>(ctx, job, lut, slots, lists, counts, 5, col0);
 }
 
 hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)

@@ -19,13 +19,18 @@ template <typename K> static void probe(const char *name, K kernel)
 int main()
 {
     using namespace nfx;
-    probe("k_glcm<u8,10,3> (ps 32)", k_glcm<uint8_t, 10, 3>);
-    probe("k_glcm<u8,10,7> (ps 48)", k_glcm<uint8_t, 10, 7>);
-    probe("k_glcm<u8,11,7> (ps 48)", k_glcm<uint8_t, 11, 7>);
-    probe("k_glcm<u8,12,7> (ps 48)", k_glcm<uint8_t, 12, 7>);
-    probe("k_glcm<u8,10,12> (ps 64)", k_glcm<uint8_t, 10, 12>);
-    probe("k_glcm<u8,11,12> (ps 64)", k_glcm<uint8_t, 11, 12>);
-    probe("k_glcm<u8,12,12> (ps 64)", k_glcm<uint8_t, 12, 12>);
-    probe("k_glcm<u8,13,12> (ps 64)", k_glcm<uint8_t, 13, 12>);
+    probe("k_glcm<u8, 512,3> (ps 32)", k_glcm<uint8_t, 512, 3>);
+    probe("k_glcm<u8, 768,3> (ps 32)", k_glcm<uint8_t, 768, 3>);
+    probe("k_glcm<u8, 512,7> (ps 48)", k_glcm<uint8_t, 512, 7>);
+    probe("k_glcm<u8, 768,7> (ps 48)", k_glcm<uint8_t, 768, 7>);
+    probe("k_glcm<u8,1024,7> (ps 48)", k_glcm<uint8_t, 1024, 7>);
+    probe("k_glcm<u8,1536,7> (ps 48)", k_glcm<uint8_t, 1536, 7>);
+    probe("k_glcm<u8,2048,7> (ps 48)", k_glcm<uint8_t, 2048, 7>);
+    probe("k_glcm<u8, 512,12> (ps 64)", k_glcm<uint8_t, 512, 12>);
+    probe("k_glcm<u8, 768,12> (ps 64)", k_glcm<uint8_t, 768, 12>);
+    probe("k_glcm<u8,1024,12> (ps 64)", k_glcm<uint8_t, 1024, 12>);
+    probe("k_glcm<u8,1536,12> (ps 64)", k_glcm<uint8_t, 1536, 12>);
+    probe("k_glcm<u8,2048,12> (ps 64)", k_glcm<uint8_t, 2048, 12>);
+    probe("k_glcm<u8,4096,12> (ps 64)", k_glcm<uint8_t, 4096, 12>);
     return 0;
 }
