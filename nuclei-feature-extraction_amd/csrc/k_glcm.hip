@@ -301,17 +301,17 @@ static __device__ void glcm_features(const double (&a)[GL_NACC], const GlcmLuts 
         for (int k = 0; k < 14; ++k) o[k] = qnan;
         return;
     }
-    // one reciprocal instead of fifteen f64 divisions by N, 2N and 4N (each a dozen instructions on 16 of the wave's 64 lanes);
-    // the quotients differ from true divisions in the last bit of an f64, far below the f32 the features are rounded to.
-    // angular_second_moment keeps its exact division: a single-cell matrix must come out as exactly 1.
+    // The moment-type sums are divided exactly: a flat nucleus must give var = a^2 - a^2 = 0 and correlation 0/0 = NaN as the
+    // reference's dense sums do, not a rounding residue.  The entropy-type sums, which only ever meet a subtraction of unlike
+    // numbers, share one reciprocal (each f64 division is a dozen instructions on 16 of the wave's 64 lanes).
     const double T2 = 2.0 * N;
-    const double rN = 1.0 / N, rT = 0.5 * rN, rQ = 0.25 * rN;
-    const double mu = S1 * rT;
-    const double ei2 = (S2 + D2) * rQ;
+    const double rN = 1.0 / N, rT = 0.5 * rN;
+    const double mu = S1 / T2;
+    const double ei2 = (S2 + D2) / (4.0 * N);
     const double var = ei2 - mu * mu;
-    const double eij = (S2 - D2) * rQ;
-    const double con = D2 * rN, dis = D1 * rN, sa = S1 * rN;
-    const double sv = S2 * rN - sa * sa;
+    const double eij = (S2 - D2) / (4.0 * N);
+    const double con = D2 / N, dis = D1 / N, sa = S1 / N;
+    const double sv = S2 / N - sa * sa;
     // All pairs in one (diagonal) cell -- a flat nucleus -- is known exactly: sum G^2 == (sum G)^2 in integers.  The three
     // entropies are then exactly 0, as a sum over cells finds them; the closed forms below would leave ln T - (T ln T)/T,
     // a rounding residue, and information_measure_correlation1 = 0/0 must come out NaN, not residue/residue.
