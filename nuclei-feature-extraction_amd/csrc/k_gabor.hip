@@ -550,75 +550,102 @@ static void build_tables(GaborTables &T)
     T.n_groups = ok ? ng : GB_MAX_GROUPS + 1;
 }
 
-// ---- patch sizes 65..128: one 256-thread workgroup per nucleus (see k_geometry.hip, "patch sizes 65..128") -----------------
+// ---- patch sizes 65..128: one 512-thread workgroup per nucleus (see k_geometry.hip, "patch sizes 65..128") -----------------
 // The paired separable passes above keep a 93 x 93 window of planes in LDS; a 128 x 128 patch does not fit.  This plainer form
 // is the reference's own shape: the DENSE 30 x 30 kernel of every channel (texture.rs:333-334; same bank as the separable
-// one, angle index * 6 + frequency index, theta = a pi / 4), correlated with the zero-padded gray patch (15 before, 14 after)
-// at the masked pixels only, one channel at a time with its 900 taps in LDS; masked mean and variance (texture.rs:339-344)
-// from f64 sums.  A tap row is accumulated in f32 (30 terms), rows in f64.
+// one, angle index * 6 + frequency index, theta = a pi / 4) correlated with the zero-padded gray patch (15 before, 14 after)
+// at the masked pixels only.  The masked pixels are compacted (row by row, in order: the sums are reproducible) so that
+// every lane owns one; a lane reads one 30-value row of its window from LDS and uses it for all 48 channels -- the weights are
+// wave-uniform and come through the scalar cache -- before it moves to the next of the 30 rows: 1440 FMAs per 30 LDS reads.
+// A tap row is accumulated in f32 (30 terms), rows in f64; masked mean and variance (texture.rs:339-344) from f64 sums.
 static constexpr int GBW_CH = 48;
+static constexpr int GBW_THREADS = 512; // two waves per SIMD: one wave's scalar weight loads hide behind the other's FMAs
+static constexpr int GBW_GS = NFX_MAX_PATCH_SIZE + GB_SIZE - 1; // gray row with apron: 157 floats (odd: conflict-free)
 struct GaborDense { float w[GBW_CH][GB_SIZE * GB_SIZE]; };
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_gabor_wide(int64_t n, int ps, const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
-                                                    const GaborDense *__restrict__ bank, float *__restrict__ out, int F, int col0)
+__global__ __launch_bounds__(GBW_THREADS, 2) void k_gabor_wide(int64_t n, int ps, const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
+                                                       const GaborDense *__restrict__ bank, float *__restrict__ out, int F, int col0)
 {
-    __shared__ float s_gray[NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE];
-    __shared__ float s_w[GB_SIZE * GB_SIZE];
-    __shared__ double s_red[4][2];
-    __shared__ int s_K[4];
+    __shared__ float s_ga[GBW_GS * GBW_GS];                                      // gray patch at [r + 15][c + 15], zero apron
+    __shared__ unsigned short s_list[NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE];   // masked pixels, r * ps + c, in raster order
+    __shared__ double s_sum[GBW_THREADS / 64][GBW_CH][2];
+    __shared__ int s_rowstart[NFX_MAX_PATCH_SIZE + 1];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int P = ps * ps;
+    for (int k = t; k < GBW_GS * GBW_GS; k += GBW_THREADS) s_ga[k] = 0.0f;
     for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        __syncthreads();
         const T *pp = patches + (size_t)i * 3 * P;
         const uint64_t *rows = mask_rows + (size_t)i * ps * 2;
-        int K = 0;
-        for (int p = t; p < P; p += 256) {
+        for (int p = t; p < P; p += GBW_THREADS) {
             float gs = BPx<T>::ld(pp, p) + BPx<T>::ld(pp, P + p);
             gs = gs + BPx<T>::ld(pp, 2 * P + p);
-            s_gray[p] = sizeof(T) == 1 ? third_of_u8_sum(gs) : gs / 3.0f; // texture.rs:332
             const int r = p / ps, c = p - r * ps;
-            K += (int)((rows[2 * r + (c >> 6)] >> (c & 63)) & 1ull);
+            s_ga[(r + GB_PAD) * GBW_GS + c + GB_PAD] = sizeof(T) == 1 ? third_of_u8_sum(gs) : gs / 3.0f; // texture.rs:332
         }
-        K = wave_total_i32(K);
-        if (lane == 0) s_K[wv] = K;
+        if (t == 0) { // row starts of the compacted list (128 additions: nothing next to the 43 200 FMAs per pixel below)
+            int at = 0;
+            for (int r = 0; r < ps; ++r) { s_rowstart[r] = at; at += __popcll(rows[2 * r]) + __popcll(rows[2 * r + 1]); }
+            s_rowstart[ps] = at;
+        }
+        for (int k = t; k < (GBW_THREADS / 64) * GBW_CH * 2; k += GBW_THREADS) (&s_sum[0][0][0])[k] = 0.0;
         __syncthreads();
-        const double area = (double)(s_K[0] + s_K[1] + s_K[2] + s_K[3]);
-        float *o = out + i * (int64_t)F + col0;
-        for (int ch = 0; ch < GBW_CH; ++ch) {
-            for (int k = t; k < GB_SIZE * GB_SIZE; k += 256) s_w[k] = bank->w[ch][k];
-            __syncthreads();
-            double s1 = 0.0, s2 = 0.0;
-            for (int p = t; p < P; p += 256) {
-                const int r = p / ps, c = p - r * ps;
-                if (!((rows[2 * r + (c >> 6)] >> (c & 63)) & 1ull)) continue;
-                const int i0 = r - GB_PAD < 0 ? GB_PAD - r : 0, i1 = r - GB_PAD + GB_SIZE > ps ? ps - (r - GB_PAD) : GB_SIZE;
-                const int j0 = c - GB_PAD < 0 ? GB_PAD - c : 0, j1 = c - GB_PAD + GB_SIZE > ps ? ps - (c - GB_PAD) : GB_SIZE;
-                double acc = 0.0;
-                for (int ii = i0; ii < i1; ++ii) {
-                    const float *g = &s_gray[(r + ii - GB_PAD) * ps + (c - GB_PAD)];
-                    const float *w = &s_w[ii * GB_SIZE];
-                    float row = 0.0f;
-                    for (int jj = j0; jj < j1; ++jj) row = fmaf(w[jj], g[jj], row);
-                    acc += (double)row;
+        if (t < ps) {
+            int at = s_rowstart[t];
+            for (int w = 0; w < 2; ++w) {
+                uint64_t bits = rows[2 * t + w];
+                while (bits) {
+                    const int c = 64 * w + __ffsll((long long)bits) - 1;
+                    bits &= bits - 1ull;
+                    s_list[at++] = (unsigned short)(t * ps + c);
                 }
-                s1 += acc;
-                s2 += acc * acc;
             }
-            s1 = wave_total_f64(s1);
-            s2 = wave_total_f64(s2);
-            if (lane == 0) { s_red[wv][0] = s1; s_red[wv][1] = s2; }
-            __syncthreads();
-            if (t == 0) {
-                const double a = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
-                const double b = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
-                const double mean = a / area; // 0/0 for an empty mask, as texture.rs:340-344
-                double var = b / area - mean * mean;
-                var = var > 0.0 ? var : (var == var ? 0.0 : var);
-                o[2 * ch] = (float)mean;
-                o[2 * ch + 1] = (float)var;
+        }
+        __syncthreads();
+        const int K = s_rowstart[ps];
+        for (int base = 0; base < K; base += GBW_THREADS) {
+            const int e = base + t;
+            const bool valid = e < K;
+            const int p = s_list[valid ? e : 0];
+            const int r = p / ps, c = p - r * ps;
+            double acc[GBW_CH];
+#pragma unroll
+            for (int f = 0; f < GBW_CH; ++f) acc[f] = 0.0;
+#pragma unroll 1
+            for (int ii = 0; ii < GB_SIZE; ++ii) {
+                float g[GB_SIZE];
+                const float *grow = &s_ga[(r + ii) * GBW_GS + c]; // gray row r + ii - 15, columns c - 15 .. c + 14
+#pragma unroll
+                for (int jj = 0; jj < GB_SIZE; ++jj) g[jj] = grow[jj];
+#pragma unroll
+                for (int f = 0; f < GBW_CH; ++f) {
+                    const float *w = &bank->w[f][ii * GB_SIZE]; // wave-uniform: scalar loads
+                    float row = 0.0f;
+#pragma unroll
+                    for (int jj = 0; jj < GB_SIZE; ++jj) row = fmaf(w[jj], g[jj], row);
+                    acc[f] += (double)row;
+                }
             }
-            __syncthreads();
+#pragma unroll
+            for (int f = 0; f < GBW_CH; ++f) {
+                const double a = valid ? acc[f] : 0.0;
+                const double s1 = wave_total_f64(a), s2 = wave_total_f64(a * a);
+                if (lane == 0) { s_sum[wv][f][0] += s1; s_sum[wv][f][1] += s2; }
+            }
+        }
+        __syncthreads();
+        if (t < GBW_CH) {
+            const double area = (double)K;
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int w = 0; w < GBW_THREADS / 64; ++w) { a += s_sum[w][t][0]; b += s_sum[w][t][1]; }
+            const double mean = a / area; // 0/0 for an empty mask, as texture.rs:340-344
+            double var = b / area - mean * mean;
+            var = var > 0.0 ? var : (var == var ? 0.0 : var);
+            float *o = out + i * (int64_t)F + col0;
+            o[2 * t] = (float)mean;
+            o[2 * t + 1] = (float)var;
         }
     }
 }
@@ -679,13 +706,13 @@ hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0)
     if (e != hipSuccess) return e;
     ScopedTiming t(ctx, KS_GABOR);
     if (job.ps > NFX_ROW_WORD_PS) {
-        const unsigned wgrid = (unsigned)(job.n < 256 * 4 ? job.n : 256 * 4);
+        const unsigned wgrid = (unsigned)(job.n < 256 * 2 ? job.n : 256 * 2);
         const GaborDense *dense = reinterpret_cast<const GaborDense *>(ctx->gabor_dense);
         if (job.patches_f32)
-            hipLaunchKernelGGL(k_gabor_wide<float>, dim3(wgrid), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const float *>(job.patches),
+            hipLaunchKernelGGL(k_gabor_wide<float>, dim3(wgrid), dim3(GBW_THREADS), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const float *>(job.patches),
                                job.mask_rows, dense, job.out, job.F, col0);
         else
-            hipLaunchKernelGGL(k_gabor_wide<uint8_t>, dim3(wgrid), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const uint8_t *>(job.patches),
+            hipLaunchKernelGGL(k_gabor_wide<uint8_t>, dim3(wgrid), dim3(GBW_THREADS), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const uint8_t *>(job.patches),
                                job.mask_rows, dense, job.out, job.F, col0);
         return hipGetLastError();
     }
