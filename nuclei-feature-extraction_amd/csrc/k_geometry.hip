@@ -129,7 +129,7 @@ static __device__ __forceinline__ uint64_t raster_row(const uint32_t *__restrict
 // ---- LAPACK slanv2 (f32) as reached by sgeev on a 2x2 block; see DESIGN.md "orientation" -------
 static __device__ __forceinline__ float sign1(float x) { return __builtin_signbit(x) ? -1.0f : 1.0f; }
 
-static __device__ float slapy2(float x, float y)
+static __device__ __forceinline__ float slapy2(float x, float y)
 {
     const float xa = fabsf(x), ya = fabsf(y);
     const float w = xa > ya ? xa : ya;
@@ -139,7 +139,7 @@ static __device__ float slapy2(float x, float y)
     return w * sqrtf(1.0f + t * t);
 }
 
-static __device__ void slanv2(float a, float b, float c, float d, float &rt1, float &rt2, float &cs, float &sn)
+static __device__ __forceinline__ void slanv2(float a, float b, float c, float d, float &rt1, float &rt2, float &cs, float &sn)
 {
     const float eps = 1.1920929e-07f, multpl = 4.0f;
     if (c == 0.0f) {
@@ -224,7 +224,7 @@ struct ShapeAxes {
     float major, minor, angle, ecc, cen0, cen1; // cen0 / cen1: centre of mass (row, column) minus ps / 2 (shape.rs:71-73)
 };
 
-static __device__ ShapeAxes shape_axes(int K, int sr, int scs, int srr, int src, int sccs, int ps)
+static __device__ __forceinline__ ShapeAxes shape_axes(int K, int sr, int scs, int srr, int src, int sccs, int ps)
 {
     ShapeAxes A;
     // center_of_mass (shape.rs:219-226): integer sums < 2^24 are exact in f32
@@ -276,7 +276,7 @@ static __device__ __forceinline__ EllipseFrame ellipse_frame(const ShapeAxes &A,
     E.xc = (double)A.cen1; E.yc = (double)A.cen0; E.a = (double)A.major; E.b = (double)A.minor;
     return E;
 }
-static __device__ void ellipse_row_span(const EllipseFrame &E, int ps, int row, int &lo, int &len)
+static __device__ __forceinline__ void ellipse_row_span(const EllipseFrame &E, int ps, int row, int &lo, int &len)
 {
     lo = 0; len = 0;
     const double ct = E.ct, st = E.st, half = E.half, xc = E.xc, yc = E.yc, a = E.a, b = E.b;
@@ -331,7 +331,7 @@ static __device__ void ellipse_row_span(const EllipseFrame &E, int ps, int row, 
 
 // one wave per nucleus, lane = row (ps <= 64): writes out[1]=major_axis [2]=minor_axis [3]=eccentricity [4]=orientation
 // [8]=eliptic_deviation
-static __device__ void shape_from_row(uint64_t row, int ps, int lane, float *__restrict__ o)
+static __device__ __forceinline__ void shape_from_row(uint64_t row, int ps, int lane, float *__restrict__ o)
 {
     int kr, sc, scc;
     word_moments(row, kr, sc, scc);
@@ -363,8 +363,10 @@ static __device__ void shape_from_row(uint64_t row, int ps, int lane, float *__r
     }
 }
 
+// (eight waves per SIMD: with the shape arithmetic inlined the kernel needs 62 registers, and it is a chain of dependent f64
+// divisions and transcendental expansions that only other waves can hide: -11 % against five waves at 86 registers)
 template <bool SHAPE>
-__global__ __launch_bounds__(256) void k_raster_shape(int64_t n, const uint32_t *__restrict__ poly_off,
+__global__ __launch_bounds__(256, 8) void k_raster_shape(int64_t n, const uint32_t *__restrict__ poly_off,
                                                       const float *__restrict__ poly_xy, int ps,
                                                       uint64_t *__restrict__ rows_out, float *__restrict__ out, int F,
                                                       int col0, int *__restrict__ areas_out)
