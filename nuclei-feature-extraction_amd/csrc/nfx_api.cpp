@@ -467,7 +467,7 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
     // fork: the polygon columns only need the centred rings; their kernel runs on the side stream next to everything below
     // and is joined at the end of the call
     hipStream_t const main_stream = ctx->stream;
-    const bool want_fork = count_set(sets, n_sets, NFX_SET_GEOMETRY) && pix; // next to the rasteriser alone (geometry only) the two f64-heavy kernels just share the issue slots: no gain
+    const bool want_fork = count_set(sets, n_sets, NFX_SET_GEOMETRY) && pix; // next to the rasteriser alone (geometry only) the two kernels just share the issue slots: no gain (measured again in round 2: 0.492 vs 0.479 ms)
     if (want_fork) {
         NFX_HIP(ctx, hipEventRecord(ctx->ev_fork, main_stream));
         NFX_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
