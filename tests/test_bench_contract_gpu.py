@@ -34,3 +34,27 @@ def test_bench_line(workload):
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_bench_launches_its_own_ranks_and_checks_the_gather():
+    """`python bench.py --gpus 2` started bare: the parent launches two ranks (torch.distributed.run as a child, before it
+    touches a GPU), relays rank 0's single line and its exit code.  On a box with fewer GPUs than ranks the ranks share a
+    device and the gather runs over gloo (a rehearsal, flagged in the line); the sharding, sliced gathers, transport
+    checksums and the gathered-equals-single-GPU check of the strong-scaling (configs[3]) measurement are the same code."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nuclei", "4000", "--strong-nuclei", "3700",
+                        "--full-set-nuclei", "800", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must carry one line, got {len(lines)}: {r.stdout[:500]}"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert abs(d["value"] - 2 * d["config"]["nuclei_per_gpu"] / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
+    import torch
+    assert ("REHEARSAL" in d["config"]["sharding"]) == (torch.cuda.device_count() < 2)
+    a = d["also"]
+    assert a["gather_checksums_match"] is True
+    s = a["strong_scaling_config4"]
+    assert s["scaling"] == "strong" and s["shard_nuclei"] == [1900, 1800]           # 37 batches of 100: 19 + 18
+    assert s["gather_checksums_match"] is True and s["gathered_equals_single_gpu"] is True
+    f = a["full_feature_set"]
+    assert f["n_gpus"] == 2 and f["config"]["columns"] == 418 and f["gather_checksums_match"] is True and f["value"] > 0
