@@ -13,7 +13,7 @@ for ps in (32, 48, 64, 40, 56):
             t0 = time.time()
             off, xy, pu8 = par.make_inputs(seed + ps, n, ps)
             got, gc = ctx.extract(sets, off, xy, pu8, ps, batch_size=100)
-            want, wc = orc.extract(sets, off, xy, pu8, ps, batch_size=100)
+            want, wc = orc.extract(sets, off, xy, pu8, ps, batch_size=100, threads=16)
             assert np.array_equal(gc, wc, equal_nan=True)
             worst = par.assert_rows_close(got, want, par.column_scales(nfx, sets, ps), what=f"ps={ps} sets={sets} seed={seed}")
             print(f"ps {ps} sets {sets} n {n} seed {seed}: worst {worst:.3e}  ({time.time() - t0:.1f} s)", flush=True)
