@@ -41,7 +41,11 @@
 
 namespace nfx {
 
-static constexpr int GB_SIZE = 30, GB_PAD = 15, GB_THREADS = 256;
+#ifndef NFX_GB_THREADS
+#define NFX_GB_THREADS 256
+#endif
+static constexpr int GB_SIZE = 30, GB_PAD = 15, GB_THREADS = NFX_GB_THREADS, GB_WAVES = GB_THREADS / 64;
+static_assert(GB_WAVES == 4 || GB_WAVES == 8, "the transposed-mask step hands 16 or 8 rows to a wave");
 static constexpr int GB_GW = NFX_ROW_WORD_PS + GB_SIZE - 1; // gray row with apron: 93 floats
 static constexpr int GB_UW = NFX_ROW_WORD_PS + 1;           // U/W row stride (odd: conflict-free both ways)
 static constexpr int GB_UH = NFX_ROW_WORD_PS + GB_SIZE - 1; // U/W rows incl. zero aprons: 93
@@ -121,13 +125,16 @@ static __device__ __forceinline__ void load_tap_block(const float *w, int blk, f
 template <int TS, typename X>
 static __device__ __forceinline__ void taps2(const X (&x)[TS + GB_SIZE - 1], const float *w, f2 init, f2 (&acc)[TS])
 {
-    f2 wr[2][GB_TBLK];
-    load_tap_block(w, 0, wr[0]);
+    // prefetch distance in blocks: a block of 2 TS packed FMAs has to cover the LDS round trip of the block fetched ahead
+    constexpr int D = TS >= 10 ? 1 : (TS >= 5 ? 2 : 4), NB = D + 1;
+    f2 wr[NB][GB_TBLK];
+#pragma unroll
+    for (int d = 0; d < D; ++d) load_tap_block(w, d, wr[d]);
 #pragma unroll
     for (int o = 0; o < TS; ++o) acc[o] = init;
 #pragma unroll
     for (int blk = 0; blk < GB_NBLK; ++blk) {
-        if (blk + 1 < GB_NBLK) load_tap_block(w, blk + 1, wr[(blk + 1) & 1]);
+        if (blk + D < GB_NBLK) load_tap_block(w, blk + D, wr[(blk + D) % NB]);
 #pragma unroll
         for (int jj = 0; jj < GB_TBLK; ++jj) {
             const int j = blk * GB_TBLK + jj;
@@ -136,7 +143,7 @@ static __device__ __forceinline__ void taps2(const X (&x)[TS + GB_SIZE - 1], con
                 f2 xv;
                 if constexpr (sizeof(X) == sizeof(float)) xv = (f2){x[o + j], x[o + j]};
                 else xv = x[o + j];
-                acc[o] = __builtin_elementwise_fma(wr[blk & 1][jj], xv, acc[o]);
+                acc[o] = __builtin_elementwise_fma(wr[blk % NB][jj], xv, acc[o]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -157,25 +164,28 @@ struct GaborView {
     int rmin, rmax, cmin, cmax, rlo, nrow_rp, pad0, pad1;
 };
 
-// All groups of one nucleus with strip size TS: wave w owns column strip w of every row pass and row strip w of
-// every column pass, so each pass is exactly one round for every wave.  No lane-divergent branches: lanes outside the
-// bounding box duplicate their neighbour's work (row pass: same values to the same address) or carry an all-zero
-// mask (column pass), which keeps every FMA block in one basic block.  Everything that does not depend on the group
-// (window addresses, the strip's mask bits) is set up once; everything that does (taps, DC gains, filter slots,
-// number of passes) sits in the group's LDS image, so the loop issues no scalar loads.
+// All groups of one nucleus.  No lane-divergent branches: lanes without work duplicate a neighbour's (row pass: same values to
+// the same address) or carry an all-zero mask (column pass), which keeps every FMA block in one basic block.  Everything that
+// does not depend on the group (window addresses, the lane's mask bits) is set up once per view; everything that does (taps,
+// DC gains, filter slots, number of passes) sits in the group's LDS image, so the loop issues no scalar loads.
+//
+// ROW PASS: wave w owns column strip w (TSR outputs wide, four strips cover the box's columns), lanes run along the rows.
+// COLUMN PASS: the box's columns times S row strips of CT rows are laid over all 256 lanes (item L = strip * ncol + column,
+// S = 256 / ncol, CT = ceil(nrow / S)): a box 40 columns wide keeps 240 lanes busy with 7 outputs each instead of 160 with 10.
+// A wave's lanes may belong to two or three strips; the masked partial sums are wave totals either way.
 //
 // TWO VIEWS.  The 0-degree filters (B = 0) are the 90-degree ones of the TRANSPOSED nucleus, and masked mean / variance do
 // not care about a transposition.  So they run as a second 90-degree-style group (one envelope row pass, three column
 // passes for six filters -- four passes instead of the six that three row-then-envelope groups would take) on the
 // transposed view: swapped bounding box, transposed mask, and a row-pass window that walks DOWN the gray image (lanes along
 // its columns: still conflict-free; the rows above and below the patch are the zero apron a transposed image would have).
-template <int TS>
+template <int N> using gb_int = std::integral_constant<int, N>;
+
 static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const GaborTables *__restrict__ tab, int n_groups, int n_plain, int ps,
                                                      const GaborView *s_view,
                                                      float mu_gray, int t, float (*s_wt)[GB_WBUF], int &buf,
                                                      double (*s_part)[GB_MAX_FILTERS][2], int dbg)
 {
-    constexpr int WIN = TS + GB_SIZE - 1;
     const int lane = t & 63, wv = t >> 6;
 #pragma unroll 1
   for (int view = 0; view < 2; ++view) {
@@ -186,35 +196,40 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
     const int rmin = __builtin_amdgcn_readfirstlane(V.rmin), rmax = __builtin_amdgcn_readfirstlane(V.rmax);
     const int cmin = __builtin_amdgcn_readfirstlane(V.cmin), cmax = __builtin_amdgcn_readfirstlane(V.cmax);
     const int rlo = __builtin_amdgcn_readfirstlane(V.rlo), nrow_rp = __builtin_amdgcn_readfirstlane(V.nrow_rp);
+    const int ncol = cmax - cmin + 1, nrow = rmax - rmin + 1;
     // row pass geometry: lanes run along rows (LDS stride GB_GW, odd), the wave's strip along columns
-    const int c0 = cmin + wv * TS;
+    int tsr = (ncol + GB_WAVES - 1) / GB_WAVES;
+    tsr = tsr < 3 ? 3 : tsr; // 3 .. 16
+    const int c0 = cmin + wv * tsr;
     const bool rstrip = c0 <= cmax && !(dbg & 1); // wave-uniform
     const int rr = rlo + (lane < nrow_rp ? lane : nrow_rp - 1);
-    int c0c = c0 < ps - TS ? c0 : ps - TS; // keep the window inside the apron row
+    int c0c = c0 < ps - tsr ? c0 : ps - tsr; // keep the window inside the apron row
     c0c = c0c > 0 ? c0c : 0;
     const float *src = tr ? &S.g[rr + GB_PAD] : &S.g[rr * GB_GW + c0c]; // gray column c-15 sits at apron index c; transposed: column rr
     f2 *du = &S.UW[(rr + GB_PAD) * GB_UW + c0c];
-    // column pass geometry: lanes run along columns, the wave's strip along rows.  A box at most 32 columns wide would
-    // leave half of the lanes idle, so there the strip is SPLIT: lanes 0-31 take its upper half, lanes 32-63 the lower half
-    // (CT = TS / 2 outputs per lane from a window of CT + 29: half the FMAs, six loads fewer)
-    const bool split = (TS % 2 == 0) && cmax - cmin < 32; // wave-uniform
-    const int CTr = split ? TS / 2 : TS;
-    const int cl = split ? (lane & 31) : lane;
-    const int r0w = rmin + wv * TS;
-    const bool cstrip = r0w <= rmax && !(dbg & 2); // wave-uniform: the wave's strip holds mask rows
-    const int r0 = r0w + (split ? (lane >> 5) * CTr : 0);
-    const int c = cmin + cl <= cmax ? cmin + cl : cmax;
-    int r0c = r0 < ps - CTr ? r0 : ps - CTr; // clamped strips overlap: rows below r0 are masked out
+    // column pass geometry: item = (row strip, column)
+    const int nstrip_max = GB_THREADS / ncol;                    // >= 4
+    int ct = (nrow + nstrip_max - 1) / nstrip_max;               // 1 .. 16
+    ct = ct < 2 ? 2 : ct;
+    const int nstrip = (nrow + ct - 1) / ct;
+    const int items = nstrip * ncol;                             // <= 256
+    const bool cstrip = wv * 64 < items && !(dbg & 2);           // wave-uniform: the wave holds items
+    const bool item = t < items;
+    const int ti = item ? t : items - 1;
+    const int strip = ti / ncol, cl = ti - strip * ncol;
+    const int r0 = rmin + strip * ct;
+    const int c = cmin + cl;
+    int r0c = r0 < ps - ct ? r0 : ps - ct; // clamped strips overlap: rows below r0 are masked out
     r0c = r0c > 0 ? r0c : 0;
     const f2 *su = &S.UW[r0c * GB_UW + c]; // row (r0c - 15) + 15
     // bit q: pixel (r0c + q, c) is in the mask and belongs to this strip.  Column c of this view's mask is row c of
-    // the other view's: one LDS word instead of TS lane reads
+    // the other view's: one LDS word instead of CT lane reads
     unsigned mbits;
     {
         const uint64_t column = s_view[view ^ 1].wrow[c];
         const int skip = r0 - r0c < 31 ? r0 - r0c : 31; // clamped strips overlap: rows below r0 belong to the strip before
-        mbits = (unsigned)(column >> r0c) & ((1u << CTr) - 1u) & ~((1u << skip) - 1u);
-        if (cmin + cl > cmax || r0 > rmax) mbits = 0u;
+        mbits = (unsigned)(column >> r0c) & ((1u << ct) - 1u) & ~((1u << skip) - 1u);
+        if (!item) mbits = 0u;
     }
 
     for (int g = g_begin; g < ((dbg & 4) ? 0 : g_end); ++g) {
@@ -226,7 +241,8 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
         float4 wnext = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (t < GB_WBUF / 4) wnext = reinterpret_cast<const float4 *>(tab->groups[gn].image)[t];
         // ---- row pass ---------------------------------------------------------------------------------------------
-        if (rstrip) {
+        auto row_pass = [&](auto ts_tag) {
+            constexpr int TS = decltype(ts_tag)::value, WIN = TS + GB_SIZE - 1;
             float x[WIN];
             f2 acc[TS];
             if (tr) { // window element j is gray row c0c + j - 15 (wave-uniform): outside the patch it is the apron's zero
@@ -245,6 +261,28 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
             // unconditional stores (c0c <= ps - TS keeps them inside the row; for ps < TS they land in the row's unused tail)
 #pragma unroll
             for (int q = 0; q < TS; ++q) du[q] = acc[q];
+        };
+        if (rstrip) {
+            switch (tsr) {
+            case 3: row_pass(gb_int<3>{}); break;
+            case 4: row_pass(gb_int<4>{}); break;
+            case 5: row_pass(gb_int<5>{}); break;
+            case 6: row_pass(gb_int<6>{}); break;
+            case 7: row_pass(gb_int<7>{}); break;
+            case 8: row_pass(gb_int<8>{}); break;
+#if NFX_GB_THREADS == 256
+            case 9: row_pass(gb_int<9>{}); break;
+            case 10: row_pass(gb_int<10>{}); break;
+            case 11: row_pass(gb_int<11>{}); break;
+            case 12: row_pass(gb_int<12>{}); break;
+            case 13: row_pass(gb_int<13>{}); break;
+            case 14: row_pass(gb_int<14>{}); break;
+            case 15: row_pass(gb_int<15>{}); break;
+            default: row_pass(gb_int<16>{}); break;
+#else
+            default: break;
+#endif
+            }
         }
         __syncthreads();
         // ---- column passes ------------------------------------------------------------------------------------------
@@ -287,8 +325,7 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
                         }
                     }
                 }
-                // every wave runs exactly one strip per pass; each lane holds shifted sums (small numbers), so an f32 wave
-                // reduction is exact enough
+                // each lane holds shifted sums (small numbers), so an f32 wave reduction is exact enough
                 const float a0 = wave_total_f32(a.x), b0 = wave_total_f32(b.x), a1 = wave_total_f32(a.y), b1 = wave_total_f32(b.y);
                 if (lane == 0) {
                     const int f0 = (meta >> 8) & 255, f1 = (meta >> 16) & 255;
@@ -297,8 +334,27 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
                 }
             }
         };
-        if (split) column_passes(std::integral_constant<int, (TS % 2 == 0) ? TS / 2 : TS>{});
-        else column_passes(std::integral_constant<int, TS>{});
+        switch (ct) {
+        case 2: column_passes(gb_int<2>{}); break;
+        case 3: column_passes(gb_int<3>{}); break;
+        case 4: column_passes(gb_int<4>{}); break;
+        case 5: column_passes(gb_int<5>{}); break;
+        case 6: column_passes(gb_int<6>{}); break;
+        case 7: column_passes(gb_int<7>{}); break;
+        case 8: column_passes(gb_int<8>{}); break;
+#if NFX_GB_THREADS == 256
+        case 9: column_passes(gb_int<9>{}); break;
+        case 10: column_passes(gb_int<10>{}); break;
+        case 11: column_passes(gb_int<11>{}); break;
+        case 12: column_passes(gb_int<12>{}); break;
+        case 13: column_passes(gb_int<13>{}); break;
+        case 14: column_passes(gb_int<14>{}); break;
+        case 15: column_passes(gb_int<15>{}); break;
+        default: column_passes(gb_int<16>{}); break;
+#else
+        default: break;
+#endif
+        }
         buf ^= 1; // the other buffer was last read by group g-1, which every wave left before this iteration's first barrier
         if (t < GB_WBUF / 4) reinterpret_cast<float4 *>(s_wt[buf])[t] = wnext;
     }
@@ -306,7 +362,7 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
 }
 
 template <typename T>
-__global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, const T *__restrict__ patches,
+__global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t n, int ps, const T *__restrict__ patches,
                                                          const uint64_t *__restrict__ mask_rows,
                                                          const GaborTables *__restrict__ tab, float *__restrict__ out,
                                                          int F, int col0, int dbg)
@@ -315,8 +371,8 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
     __shared__ float s_g[NFX_ROW_WORD_PS * GB_GW + 16];
     __shared__ f2 s_UW[GB_UH * GB_UW]; // plane pair; row r lives at index r + GB_PAD; aprons stay zero
     __shared__ uint64_t s_rows[64 + 16];
-    __shared__ double s_part[4][GB_MAX_FILTERS][2];
-    __shared__ float s_gsum[4];
+    __shared__ double s_part[GB_WAVES][GB_MAX_FILTERS][2];
+    __shared__ float s_gsum[GB_WAVES];
     __shared__ GaborView s_view[2];
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -386,8 +442,6 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
             continue;
         }
         const int cmin = __ffsll((long long)orr) - 1, cmax = 63 - __clzll((long long)orr);
-        const int ncol = cmax - cmin + 1, nrow = rmax - rmin + 1;
-        const int span = ncol > nrow ? ncol : nrow;   // both passes and both views use the same strip size
         auto put_view = [&](GaborView &V, bool with_rows, uint64_t rows_of_lane, int r_lo, int r_hi, int c_lo, int c_hi) {
             if (with_rows) V.wrow[lane] = rows_of_lane;
             if (lane == 0) {
@@ -398,16 +452,18 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
             }
         };
         // transposed mask: lane c collects column c, one bit per mask row (three instructions a row); wave w does rows
-        // 16w .. 16w+15 and puts its 16 bits down as one quarter of the lane's word
+        // RPW w .. RPW w + RPW - 1 and puts its bits down as one piece of the lane's word
         {
+            constexpr int RPW = 64 / GB_WAVES;
             unsigned acc = 0u;
             const unsigned wlo = (unsigned)wrow, whi = (unsigned)(wrow >> 32);
-            const int Ra = rmin > 16 * wv ? rmin : 16 * wv, Rb = rmax < 16 * wv + 15 ? rmax : 16 * wv + 15;
+            const int Ra = rmin > RPW * wv ? rmin : RPW * wv, Rb = rmax < RPW * wv + RPW - 1 ? rmax : RPW * wv + RPW - 1;
             for (int R = Ra; R <= Rb; ++R) {
                 const unsigned rl = (unsigned)__builtin_amdgcn_readlane((int)wlo, R), rh = (unsigned)__builtin_amdgcn_readlane((int)whi, R);
-                acc |= (((lane < 32 ? rl : rh) >> (lane & 31)) & 1u) << (R & 15);
+                acc |= (((lane < 32 ? rl : rh) >> (lane & 31)) & 1u) << (R & (RPW - 1));
             }
-            reinterpret_cast<unsigned short *>(s_view[1].wrow)[4 * lane + wv] = (unsigned short)acc;
+            if (GB_WAVES == 4) reinterpret_cast<unsigned short *>(s_view[1].wrow)[4 * lane + wv] = (unsigned short)acc;
+            else reinterpret_cast<unsigned char *>(s_view[1].wrow)[8 * lane + wv] = (unsigned char)acc;
         }
         if (wv == 0) { // visible to the other waves after the barrier below
             put_view(s_view[0], true, wrow, rmin, rmax, cmin, cmax);
@@ -415,25 +471,20 @@ __global__ __launch_bounds__(GB_THREADS, 2) void k_gabor(int64_t n, int ps, cons
         }
         if (lane == 0) s_gsum[wv] = gsum;
         __syncthreads();
-        const float mu_gray = (s_gsum[0] + s_gsum[1] + s_gsum[2] + s_gsum[3]) / (float)area;
-#define NFX_GB_CALL(TS) gabor_nucleus<TS>(S, tab, n_groups, n_plain, ps, s_view, mu_gray, t, s_wt, buf, s_part, dbg)
-        // four strips of the smallest even size that covers the bounding box: every wave has work in every pass
-        if (span <= 24) NFX_GB_CALL(6);
-        else if (span <= 32) NFX_GB_CALL(8);
-        else if (span <= 40) NFX_GB_CALL(10);
-        else if (span <= 48) NFX_GB_CALL(12);
-        else if (span <= 56) NFX_GB_CALL(14);
-        else NFX_GB_CALL(16);
-#undef NFX_GB_CALL
+        float gtot = 0.0f;
+#pragma unroll
+        for (int w = 0; w < GB_WAVES; ++w) gtot += s_gsum[w];
+        const float mu_gray = gtot / (float)area;
+        gabor_nucleus(S, tab, n_groups, n_plain, ps, s_view, mu_gray, t, s_wt, buf, s_part, dbg);
         __syncthreads();
         // ---- mean / variance (texture.rs:339-344) from the shifted sums: mean = c + s1/K, var = s2/K - (s1/K)^2 -----
         if (t < n_filters) {
             const GaborFilter &Fl = tab->filters[t];
             const double K = (double)area;
-            const float mu_gray = (s_gsum[0] + s_gsum[1] + s_gsum[2] + s_gsum[3]) / (float)area;
             const double shift = (double)(Fl.dc * mu_gray);
-            const double a = s_part[0][t][0] + s_part[1][t][0] + s_part[2][t][0] + s_part[3][t][0];
-            const double b = s_part[0][t][1] + s_part[1][t][1] + s_part[2][t][1] + s_part[3][t][1];
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int w = 0; w < GB_WAVES; ++w) { a += s_part[w][t][0]; b += s_part[w][t][1]; }
             const double m1 = a / K;
             double var = b / K - m1 * m1;
             var = var > 0.0 ? var : 0.0;
