@@ -101,52 +101,32 @@ static __device__ __forceinline__ double bsum(double v)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
-// TS output pairs of a 30-tap correlation from a (TS+29)-value register window; the tap pairs come from LDS
-// (every lane reads the same address: a broadcast).  Tap-major order, pinned: the TS packed FMAs of one tap hit TS
-// different accumulators (independent, back-to-back issue); left alone, the scheduler serialises all 30 taps of
-// one accumulator into a dependent chain.
-// The pairs are fetched two taps (one 16-byte read) at a time, one block ahead of their use, so only two blocks (8 registers, not 64)
-// are live and the LDS latency of the next block hides behind the current block's FMAs.
-static constexpr int GB_TBLK = 2, GB_NBLK = GB_SIZE / GB_TBLK;
-
-static __device__ __forceinline__ void load_tap_block(const float *w, int blk, f2 (&wr)[GB_TBLK])
-{
-    const float4 *w4 = reinterpret_cast<const float4 *>(w + 2 * GB_TBLK * blk);
-#pragma unroll
-    for (int j = 0; j < GB_TBLK; j += 2) {
-        const float4 v = w4[j / 2];
-        wr[j] = (f2){v.x, v.y};
-        wr[j + 1] = (f2){v.z, v.w};
-    }
-}
-
+// TS output pairs of a 30-tap correlation from a (TS+29)-value register window.  The 30 tap pairs of a pass are the same for
+// every lane and every nucleus: they come through the SCALAR cache (the bank is 8 KB of read-only global memory; `w` is a
+// wave-uniform address) and enter the packed FMAs as scalar operands -- no LDS traffic, no vector registers, no staging and
+// therefore no workgroup barrier for them.  Tap-major order, pinned: the TS packed FMAs of one tap hit TS different
+// accumulators (independent, back-to-back issue); left alone, the scheduler serialises all 30 taps of one accumulator into
+// a dependent chain.
 // PAIRWIN = false: row pass, one gray window, two kernels: (a, b)[o] = sum_j (ra, rb)[j] * x[o + j]
 // PAIRWIN = true:  column pass, a window of plane pairs:   (accA, accB)[o] = sum_j (ca, cb)[j] * (a, b)[o + j]
 template <int TS, typename X>
-static __device__ __forceinline__ void taps2(const X (&x)[TS + GB_SIZE - 1], const float *w, f2 init, f2 (&acc)[TS])
+static __device__ __forceinline__ void taps2(const X (&x)[TS + GB_SIZE - 1], const float *__restrict__ w, f2 init, f2 (&acc)[TS])
 {
-    // prefetch distance in blocks: a block of 2 TS packed FMAs has to cover the LDS round trip of the block fetched ahead
-    constexpr int D = TS >= 10 ? 1 : (TS >= 5 ? 2 : 4), NB = D + 1;
-    f2 wr[NB][GB_TBLK];
+    f2 wr[GB_SIZE];
 #pragma unroll
-    for (int d = 0; d < D; ++d) load_tap_block(w, d, wr[d]);
+    for (int j = 0; j < GB_SIZE; ++j) wr[j] = (f2){w[2 * j], w[2 * j + 1]};
 #pragma unroll
     for (int o = 0; o < TS; ++o) acc[o] = init;
 #pragma unroll
-    for (int blk = 0; blk < GB_NBLK; ++blk) {
-        if (blk + D < GB_NBLK) load_tap_block(w, blk + D, wr[(blk + D) % NB]);
+    for (int j = 0; j < GB_SIZE; ++j) {
 #pragma unroll
-        for (int jj = 0; jj < GB_TBLK; ++jj) {
-            const int j = blk * GB_TBLK + jj;
-#pragma unroll
-            for (int o = 0; o < TS; ++o) {
-                f2 xv;
-                if constexpr (sizeof(X) == sizeof(float)) xv = (f2){x[o + j], x[o + j]};
-                else xv = x[o + j];
-                acc[o] = __builtin_elementwise_fma(wr[blk % NB][jj], xv, acc[o]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int o = 0; o < TS; ++o) {
+            f2 xv;
+            if constexpr (sizeof(X) == sizeof(float)) xv = (f2){x[o + j], x[o + j]};
+            else xv = x[o + j];
+            acc[o] = __builtin_elementwise_fma(wr[j], xv, acc[o]);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -164,15 +144,17 @@ struct GaborView {
     int rmin, rmax, cmin, cmax, rlo, nrow_rp, pad0, pad1;
 };
 
-// All groups of one nucleus.  No lane-divergent branches: lanes without work duplicate a neighbour's (row pass: same values to
-// the same address) or carry an all-zero mask (column pass), which keeps every FMA block in one basic block.  Everything that
-// does not depend on the group (window addresses, the lane's mask bits) is set up once per view; everything that does (taps,
-// DC gains, filter slots, number of passes) sits in the group's LDS image, so the loop issues no scalar loads.
+// All groups of one nucleus, WAVE-AUTONOMOUS: wave w owns column strip w of the bounding box (TSR columns; the four strips are
+// disjoint and lie inside the plane's row) for BOTH passes of every group -- its row pass fills those columns of the plane pair,
+// its column passes read nothing else -- so no wave ever waits for another one between the start of the first group and the
+// end of a view's last: no workgroup barrier per group (sixteen per nucleus before), only wave-level LDS fences and one
+// barrier between the two views.
 //
-// ROW PASS: wave w owns column strip w (TSR outputs wide, four strips cover the box's columns), lanes run along the rows.
-// COLUMN PASS: the box's columns times S row strips of CT rows are laid over all 256 lanes (item L = strip * ncol + column,
-// S = 256 / ncol, CT = ceil(nrow / S)): a box 40 columns wide keeps 240 lanes busy with 7 outputs each instead of 160 with 10.
-// A wave's lanes may belong to two or three strips; the masked partial sums are wave totals either way.
+// ROW PASS: lanes run along the rows within 15 of the mask, the strip along the columns.
+// COLUMN PASS: the strip's TSR columns times S = 64 / TSR row strips of CT = ceil(nrow / S) rows are laid over the wave's
+// lanes (item L = row strip * TSR + column): a box 40 x 40 keeps 60 lanes busy with 7 outputs each.
+// No lane-divergent branches: lanes without work duplicate a neighbour's (row pass: same values to the same address) or carry
+// an all-zero mask (column pass), which keeps every FMA block in one basic block.
 //
 // TWO VIEWS.  The 0-degree filters (B = 0) are the 90-degree ones of the TRANSPOSED nucleus, and masked mean / variance do
 // not care about a transposition.  So they run as a second 90-degree-style group (one envelope row pass, three column
@@ -182,8 +164,7 @@ struct GaborView {
 template <int N> using gb_int = std::integral_constant<int, N>;
 
 static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const GaborTables *__restrict__ tab, int n_groups, int n_plain, int ps,
-                                                     const GaborView *s_view,
-                                                     float mu_gray, int t, float (*s_wt)[GB_WBUF], int &buf,
+                                                     const GaborView *s_view, float mu_gray, int t,
                                                      double (*s_part)[GB_MAX_FILTERS][2], int dbg)
 {
     const int lane = t & 63, wv = t >> 6;
@@ -191,34 +172,36 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
   for (int view = 0; view < 2; ++view) {
     const bool tr = view == 1; // wave-uniform
     const int g_begin = tr ? n_plain : 0, g_end = tr ? n_groups : n_plain;
+    // the strips of the second view cut the plane's columns differently: every wave has to be done with the first view's
+    // last column passes before any wave writes the second view's first row pass (the one barrier between the groups)
+    if (tr) __syncthreads();
     if (g_begin >= g_end) continue;
     const GaborView &V = s_view[view];
     const int rmin = __builtin_amdgcn_readfirstlane(V.rmin), rmax = __builtin_amdgcn_readfirstlane(V.rmax);
     const int cmin = __builtin_amdgcn_readfirstlane(V.cmin), cmax = __builtin_amdgcn_readfirstlane(V.cmax);
     const int rlo = __builtin_amdgcn_readfirstlane(V.rlo), nrow_rp = __builtin_amdgcn_readfirstlane(V.nrow_rp);
     const int ncol = cmax - cmin + 1, nrow = rmax - rmin + 1;
-    // row pass geometry: lanes run along rows (LDS stride GB_GW, odd), the wave's strip along columns
+    // the wave's strip: TSR columns from c0; the strips of the four waves tile [cs, cs + 4 TSR) inside the plane's 64 columns
     int tsr = (ncol + GB_WAVES - 1) / GB_WAVES;
     tsr = tsr < 3 ? 3 : tsr; // 3 .. 16
-    const int c0 = cmin + wv * tsr;
-    const bool rstrip = c0 <= cmax && !(dbg & 1); // wave-uniform
+    const int cs = cmin < NFX_ROW_WORD_PS - GB_WAVES * tsr ? cmin : NFX_ROW_WORD_PS - GB_WAVES * tsr;
+    const int c0 = cs + wv * tsr;
+    if (c0 > cmax || (dbg & 4)) continue; // wave-uniform: no column of the box in this wave's strip (its partial sums stay zero)
+    // row pass geometry: lanes run along rows (LDS stride GB_GW, odd)
     const int rr = rlo + (lane < nrow_rp ? lane : nrow_rp - 1);
-    int c0c = c0 < ps - tsr ? c0 : ps - tsr; // keep the window inside the apron row
-    c0c = c0c > 0 ? c0c : 0;
-    const float *src = tr ? &S.g[rr + GB_PAD] : &S.g[rr * GB_GW + c0c]; // gray column c-15 sits at apron index c; transposed: column rr
-    f2 *du = &S.UW[(rr + GB_PAD) * GB_UW + c0c];
-    // column pass geometry: item = (row strip, column)
-    const int nstrip_max = GB_THREADS / ncol;                    // >= 4
+    const float *src = tr ? &S.g[rr + GB_PAD] : &S.g[rr * GB_GW + c0]; // gray column c-15 sits at apron index c; transposed: column rr
+    f2 *du = &S.UW[(rr + GB_PAD) * GB_UW + c0];
+    // column pass geometry: item = (row strip, column of the wave's strip)
+    const int nstrip_max = 64 / tsr;                             // 4 .. 21
     int ct = (nrow + nstrip_max - 1) / nstrip_max;               // 1 .. 16
     ct = ct < 2 ? 2 : ct;
     const int nstrip = (nrow + ct - 1) / ct;
-    const int items = nstrip * ncol;                             // <= 256
-    const bool cstrip = wv * 64 < items && !(dbg & 2);           // wave-uniform: the wave holds items
-    const bool item = t < items;
-    const int ti = item ? t : items - 1;
-    const int strip = ti / ncol, cl = ti - strip * ncol;
+    const int items = nstrip * tsr;                              // <= 64
+    const bool item = lane < items;
+    const int li = item ? lane : items - 1;
+    const int strip = li / tsr, cj = li - strip * tsr;
     const int r0 = rmin + strip * ct;
-    const int c = cmin + cl;
+    const int c = c0 + cj;                                       // <= 63
     int r0c = r0 < ps - ct ? r0 : ps - ct; // clamped strips overlap: rows below r0 are masked out
     r0c = r0c > 0 ? r0c : 0;
     const f2 *su = &S.UW[r0c * GB_UW + c]; // row (r0c - 15) + 15
@@ -232,23 +215,18 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
         if (!item) mbits = 0u;
     }
 
-    for (int g = g_begin; g < ((dbg & 4) ? 0 : g_end); ++g) {
-        __syncthreads(); // taps (and, for g = 0, gray) visible; every wave has left the previous group's column passes
-        const float *wt = s_wt[buf];
-        // the taps are the same for every nucleus: group g+1's image is fetched into registers while group g runs and
-        // put down in the other buffer afterwards, wrapping around to group 0 for the next nucleus
-        const int gn = g + 1 < n_groups ? g + 1 : 0;
-        float4 wnext = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (t < GB_WBUF / 4) wnext = reinterpret_cast<const float4 *>(tab->groups[gn].image)[t];
+#pragma unroll 1
+    for (int g = g_begin; g < g_end; ++g) {
+        const float *__restrict__ img = tab->groups[g].image; // wave-uniform: the taps arrive through the scalar cache
         // ---- row pass ---------------------------------------------------------------------------------------------
         auto row_pass = [&](auto ts_tag) {
             constexpr int TS = decltype(ts_tag)::value, WIN = TS + GB_SIZE - 1;
             float x[WIN];
             f2 acc[TS];
-            if (tr) { // window element j is gray row c0c + j - 15 (wave-uniform): outside the patch it is the apron's zero
+            if (tr) { // window element j is gray row c0 + j - 15 (wave-uniform): outside the patch it is the apron's zero
                 // (the first row is made opaque here so that the 40-odd range tests are evaluated on the spot: hoisted out
                 // of the group loop they would sit in registers the FMA blocks need)
-                int row0 = __builtin_amdgcn_readfirstlane(c0c - GB_PAD);
+                int row0 = __builtin_amdgcn_readfirstlane(c0 - GB_PAD);
                 asm volatile("" : "+s"(row0));
                 const float *col = src + row0 * GB_GW;
 #pragma unroll
@@ -257,12 +235,11 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
 #pragma unroll
                 for (int j = 0; j < WIN; ++j) x[j] = src[j];
             }
-            taps2<TS, float>(x, wt, (f2){0.0f, 0.0f}, acc);
-            // unconditional stores (c0c <= ps - TS keeps them inside the row; for ps < TS they land in the row's unused tail)
+            taps2<TS, float>(x, img, (f2){0.0f, 0.0f}, acc);
 #pragma unroll
             for (int q = 0; q < TS; ++q) du[q] = acc[q];
         };
-        if (rstrip) {
+        if (!(dbg & 1)) {
             switch (tsr) {
             case 3: row_pass(gb_int<3>{}); break;
             case 4: row_pass(gb_int<4>{}); break;
@@ -270,7 +247,6 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
             case 6: row_pass(gb_int<6>{}); break;
             case 7: row_pass(gb_int<7>{}); break;
             case 8: row_pass(gb_int<8>{}); break;
-#if NFX_GB_THREADS == 256
             case 9: row_pass(gb_int<9>{}); break;
             case 10: row_pass(gb_int<10>{}); break;
             case 11: row_pass(gb_int<11>{}); break;
@@ -279,50 +255,43 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
             case 14: row_pass(gb_int<14>{}); break;
             case 15: row_pass(gb_int<15>{}); break;
             default: row_pass(gb_int<16>{}); break;
-#else
-            default: break;
-#endif
             }
         }
-        __syncthreads();
+        wave_lds_fence(); // the wave's own plane columns: written above, read below
         // ---- column passes ------------------------------------------------------------------------------------------
-        const int n_pass = __float_as_int(wt[GB_META]);
+        const int n_pass = __float_as_int(img[GB_META]);
         auto column_passes = [&](auto ct_tag) {
             constexpr int CT = decltype(ct_tag)::value, CWIN = CT + GB_SIZE - 1;
             f2 x[CWIN];
-            if (cstrip) {
 #pragma unroll
-                for (int j = 0; j < CWIN; ++j) x[j] = su[j * GB_UW];
-            }
+            for (int j = 0; j < CWIN; ++j) x[j] = su[j * GB_UW];
 #pragma unroll 1
             for (int p = 0; p < n_pass; ++p) {
-                const float *wp = wt + (1 + p) * GB_WSLOT;
+                const float *__restrict__ wp = img + (1 + p) * GB_WSLOT;
                 const int meta = __float_as_int(wp[GB_META + 2]); // combine | slot0 << 8 | slot1 << 16 (255: none)
                 f2 a = {0.0f, 0.0f}, b = {0.0f, 0.0f};
-                if (cstrip) {
-                    f2 acc[CT];
-                    const float sh0 = wp[GB_META] * mu_gray, sh1 = wp[GB_META + 1] * mu_gray; // DC gain x mean masked gray
-                    // the accumulators start at minus the shift (for the mixed pair: A - B starts at -sh0, A + B at -sh1), so
-                    // the responses come out already shifted; masked partial sums of the strip's responses follow (f32
-                    // inside the strip and the wave, f64 across waves)
-                    if (meta & 1) {
-                        taps2<CT, f2>(x, wp, (f2){-0.5f * (sh0 + sh1), 0.5f * (sh0 - sh1)}, acc);
+                f2 acc[CT];
+                const float sh0 = wp[GB_META] * mu_gray, sh1 = wp[GB_META + 1] * mu_gray; // DC gain x mean masked gray
+                // the accumulators start at minus the shift (for the mixed pair: A - B starts at -sh0, A + B at -sh1), so
+                // the responses come out already shifted; masked partial sums of the strip's responses follow (f32
+                // inside the strip and the wave, f64 across waves)
+                if (meta & 1) {
+                    taps2<CT, f2>(x, wp, (f2){-0.5f * (sh0 + sh1), 0.5f * (sh0 - sh1)}, acc);
 #pragma unroll
-                        for (int q = 0; q < CT; ++q) {
-                            const float mq = ((mbits >> q) & 1u) ? 1.0f : 0.0f; // the mask as a 0/1 factor: packed multiply
-                            const f2 d = (f2){acc[q].x - acc[q].y, acc[q].x + acc[q].y} * (f2){mq, mq};
-                            a += d;
-                            b = __builtin_elementwise_fma(d, d, b);
-                        }
-                    } else {
-                        taps2<CT, f2>(x, wp, (f2){-sh0, -sh1}, acc);
+                    for (int q = 0; q < CT; ++q) {
+                        const float mq = ((mbits >> q) & 1u) ? 1.0f : 0.0f; // the mask as a 0/1 factor: packed multiply
+                        const f2 d = (f2){acc[q].x - acc[q].y, acc[q].x + acc[q].y} * (f2){mq, mq};
+                        a += d;
+                        b = __builtin_elementwise_fma(d, d, b);
+                    }
+                } else {
+                    taps2<CT, f2>(x, wp, (f2){-sh0, -sh1}, acc);
 #pragma unroll
-                        for (int q = 0; q < CT; ++q) {
-                            const float mq = ((mbits >> q) & 1u) ? 1.0f : 0.0f;
-                            const f2 d = acc[q] * (f2){mq, mq};
-                            a += d;
-                            b = __builtin_elementwise_fma(d, d, b);
-                        }
+                    for (int q = 0; q < CT; ++q) {
+                        const float mq = ((mbits >> q) & 1u) ? 1.0f : 0.0f;
+                        const f2 d = acc[q] * (f2){mq, mq};
+                        a += d;
+                        b = __builtin_elementwise_fma(d, d, b);
                     }
                 }
                 // each lane holds shifted sums (small numbers), so an f32 wave reduction is exact enough
@@ -334,29 +303,26 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
                 }
             }
         };
-        switch (ct) {
-        case 2: column_passes(gb_int<2>{}); break;
-        case 3: column_passes(gb_int<3>{}); break;
-        case 4: column_passes(gb_int<4>{}); break;
-        case 5: column_passes(gb_int<5>{}); break;
-        case 6: column_passes(gb_int<6>{}); break;
-        case 7: column_passes(gb_int<7>{}); break;
-        case 8: column_passes(gb_int<8>{}); break;
-#if NFX_GB_THREADS == 256
-        case 9: column_passes(gb_int<9>{}); break;
-        case 10: column_passes(gb_int<10>{}); break;
-        case 11: column_passes(gb_int<11>{}); break;
-        case 12: column_passes(gb_int<12>{}); break;
-        case 13: column_passes(gb_int<13>{}); break;
-        case 14: column_passes(gb_int<14>{}); break;
-        case 15: column_passes(gb_int<15>{}); break;
-        default: column_passes(gb_int<16>{}); break;
-#else
-        default: break;
-#endif
+        if (!(dbg & 2)) {
+            switch (ct) {
+            case 2: column_passes(gb_int<2>{}); break;
+            case 3: column_passes(gb_int<3>{}); break;
+            case 4: column_passes(gb_int<4>{}); break;
+            case 5: column_passes(gb_int<5>{}); break;
+            case 6: column_passes(gb_int<6>{}); break;
+            case 7: column_passes(gb_int<7>{}); break;
+            case 8: column_passes(gb_int<8>{}); break;
+            case 9: column_passes(gb_int<9>{}); break;
+            case 10: column_passes(gb_int<10>{}); break;
+            case 11: column_passes(gb_int<11>{}); break;
+            case 12: column_passes(gb_int<12>{}); break;
+            case 13: column_passes(gb_int<13>{}); break;
+            case 14: column_passes(gb_int<14>{}); break;
+            case 15: column_passes(gb_int<15>{}); break;
+            default: column_passes(gb_int<16>{}); break;
+            }
         }
-        buf ^= 1; // the other buffer was last read by group g-1, which every wave left before this iteration's first barrier
-        if (t < GB_WBUF / 4) reinterpret_cast<float4 *>(s_wt[buf])[t] = wnext;
+        wave_lds_fence(); // the next group's row pass overwrites the columns read above
     }
   }
 }
@@ -367,7 +333,6 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
                                                          const GaborTables *__restrict__ tab, float *__restrict__ out,
                                                          int F, int col0, int dbg)
 {
-    __shared__ __attribute__((aligned(16))) float s_wt[2][GB_WBUF];
     __shared__ float s_g[NFX_ROW_WORD_PS * GB_GW + 16];
     __shared__ f2 s_UW[GB_UH * GB_UW]; // plane pair; row r lives at index r + GB_PAD; aprons stay zero
     __shared__ uint64_t s_rows[64 + 16];
@@ -381,8 +346,6 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
     for (int k = t; k < GB_UH * GB_UW; k += GB_THREADS) s_UW[k] = (f2){0.0f, 0.0f};
     if (t < 64 + 16) s_rows[t] = 0ull;
     const int n_groups = tab->n_groups, n_filters = tab->n_filters, n_plain = tab->n_plain;
-    int buf = 0;
-    if (t < GB_WBUF / 4) reinterpret_cast<float4 *>(s_wt[0])[t] = reinterpret_cast<const float4 *>(tab->groups[0].image)[t];
     __syncthreads();
     GaborShared S;
     S.g = s_g; S.UW = s_UW; S.rows = s_rows;
@@ -470,12 +433,13 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
             put_view(s_view[1], false, 0ull, cmin, cmax, rmin, rmax);
         }
         if (lane == 0) s_gsum[wv] = gsum;
+        if (lane < GB_MAX_FILTERS) { s_part[wv][lane][0] = 0.0; s_part[wv][lane][1] = 0.0; } // a wave whose strip lies outside the box adds nothing
         __syncthreads();
         float gtot = 0.0f;
 #pragma unroll
         for (int w = 0; w < GB_WAVES; ++w) gtot += s_gsum[w];
         const float mu_gray = gtot / (float)area;
-        gabor_nucleus(S, tab, n_groups, n_plain, ps, s_view, mu_gray, t, s_wt, buf, s_part, dbg);
+        gabor_nucleus(S, tab, n_groups, n_plain, ps, s_view, mu_gray, t, s_part, dbg);
         __syncthreads();
         // ---- mean / variance (texture.rs:339-344) from the shifted sums: mean = c + s1/K, var = s2/K - (s1/K)^2 -----
         if (t < n_filters) {
