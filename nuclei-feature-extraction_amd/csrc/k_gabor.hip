@@ -109,9 +109,10 @@ static __device__ __forceinline__ double bsum(double v)
 // a dependent chain.
 // PAIRWIN = false: row pass, one gray window, two kernels: (a, b)[o] = sum_j (ra, rb)[j] * x[o + j]
 // PAIRWIN = true:  column pass, a window of plane pairs:   (accA, accB)[o] = sum_j (ca, cb)[j] * (a, b)[o + j]
-template <int TS, typename X>
-static __device__ __forceinline__ void taps2(const X (&x)[TS + GB_SIZE - 1], const float *__restrict__ w, f2 init, f2 (&acc)[TS])
+template <int TS, typename X, int XN>
+static __device__ __forceinline__ void taps2(const X (&x)[XN], const float *__restrict__ w, f2 init, f2 (&acc)[TS])
 {
+    static_assert(XN >= TS + GB_SIZE - 1, "window");
     f2 wr[GB_SIZE];
 #pragma unroll
     for (int j = 0; j < GB_SIZE; ++j) wr[j] = (f2){w[2 * j], w[2 * j + 1]};
@@ -221,8 +222,8 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
         // ---- row pass ---------------------------------------------------------------------------------------------
         auto row_pass = [&](auto ts_tag) {
             constexpr int TS = decltype(ts_tag)::value, WIN = TS + GB_SIZE - 1;
-            float x[WIN];
             f2 acc[TS];
+            float x[WIN];
             if (tr) { // window element j is gray row c0 + j - 15 (wave-uniform): outside the patch it is the apron's zero
                 // (the first row is made opaque here so that the 40-odd range tests are evaluated on the spot: hoisted out
                 // of the group loop they would sit in registers the FMA blocks need)
@@ -295,11 +296,12 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
                     }
                 }
                 // each lane holds shifted sums (small numbers), so an f32 wave reduction is exact enough
-                const float a0 = wave_total_f32(a.x), b0 = wave_total_f32(b.x), a1 = wave_total_f32(a.y), b1 = wave_total_f32(b.y);
-                if (lane == 0) {
-                    const int f0 = (meta >> 8) & 255, f1 = (meta >> 16) & 255;
-                    if (f0 != 255) { s_part[wv][f0][0] = (double)a0; s_part[wv][f0][1] = (double)b0; }
-                    if (f1 != 255) { s_part[wv][f1][0] = (double)a1; s_part[wv][f1][1] = (double)b1; }
+                float tot[4] = {a.x, b.x, a.y, b.y}; // four wave totals in one butterfly; lane j < 4 ends up with total scatter_index<4>(j)
+                const float mine = wave_reduce_scatter(tot, lane);
+                if (lane < 4) {
+                    const int which = scatter_index<4>(lane);           // 0: a.x, 1: b.x, 2: a.y, 3: b.y
+                    const int f = (meta >> (8 + 8 * (which >> 1))) & 255; // filter slot of the response
+                    if (f != 255) s_part[wv][f][which & 1] = (double)mine;
                 }
             }
         };
@@ -352,15 +354,26 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
     // u8 patches whose rows are whole 16-byte pieces come in with one 16-byte load per channel and thread
     const bool vec = sizeof(T) == 1 && (ps & 15) == 0 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0;
 
+    // the next nucleus's mask row and (16-byte-piece) patch travel in registers while the current nucleus is processed: their
+    // HBM latency hides behind a whole nucleus of work instead of stalling the workgroup at the top of every iteration
+    uint64_t row_next = 0ull;
+    uint4 r4n = make_uint4(0, 0, 0, 0), g4n = r4n, b4n = r4n;
+    auto request = [&](int64_t i2) {
+        if (t < 64) row_next = t < ps ? mask_rows[i2 * ps + t] : 0ull;
+        if (vec && t < P / 16) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(patches + (size_t)i2 * 3 * P) + t;
+            r4n = src[0]; g4n = src[P / 16]; b4n = src[2 * (P / 16)];
+        }
+    };
+    if ((int64_t)blockIdx.x < n) request(blockIdx.x);
     for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
-        if (t < 64) s_rows[t] = t < ps ? mask_rows[i * ps + t] : 0ull;
+        if (t < 64) s_rows[t] = row_next;
         __syncthreads();
         const T *pp = patches + (size_t)i * 3 * P;
         float gsum = 0.0f; // masked gray sum -> the shift that keeps the f32 partial sums well conditioned
         if (vec) {
             for (int k = t; k < P / 16; k += GB_THREADS) {
-                const uint4 *src = reinterpret_cast<const uint4 *>(pp) + k;
-                const uint4 r4 = src[0], g4 = src[P / 16], b4 = src[2 * (P / 16)];
+                const uint4 r4 = r4n, g4 = g4n, b4 = b4n; // P / 16 <= 256: one piece per thread and channel
                 const unsigned rr[4] = {r4.x, r4.y, r4.z, r4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
                 const int p0 = 16 * k, r = p0 / ps, c0 = p0 - r * ps;
                 const unsigned mrow = (unsigned)(s_rows[r] >> c0) & 0xFFFFu;
@@ -388,6 +401,7 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
                 if (c >= ps) { c -= ps; r += 1; }
             }
         }
+        if (i + (int64_t)gridDim.x < n) request(i + gridDim.x);
         gsum = wave_total_f32(gsum);
         // mask bounding box and area: lane r looks at row r, the wave votes
         const uint64_t wrow = s_rows[lane];
