@@ -45,7 +45,7 @@ namespace nfx {
 #define NFX_GB_THREADS 256
 #endif
 static constexpr int GB_SIZE = 30, GB_PAD = 15, GB_THREADS = NFX_GB_THREADS, GB_WAVES = GB_THREADS / 64;
-static_assert(GB_WAVES == 4 || GB_WAVES == 8, "the transposed-mask step hands 16 or 8 rows to a wave");
+static_assert(GB_WAVES == 4 || GB_WAVES == 8, "GB_WAVES strips of TSR columns have to tile the plane's 64 columns");
 static constexpr int GB_GW = NFX_ROW_WORD_PS + GB_SIZE - 1; // gray row with apron: 93 floats
 static constexpr int GB_UW = NFX_ROW_WORD_PS + 1;           // U/W row stride (odd: conflict-free both ways)
 static constexpr int GB_UH = NFX_ROW_WORD_PS + GB_SIZE - 1; // U/W rows incl. zero aprons: 93
@@ -163,6 +163,10 @@ struct GaborView {
 // transposed view: swapped bounding box, transposed mask, and a row-pass window that walks DOWN the gray image (lanes along
 // its columns: still conflict-free; the rows above and below the patch are the zero apron a transposed image would have).
 template <int N> using gb_int = std::integral_constant<int, N>;
+// strip sizes a workgroup of GB_WAVES waves can meet: TSR = ceil(ncol / GB_WAVES) <= GB_MAX_TSR, CT = ceil(nrow / (64 / TSR)) <= GB_MAX_CT
+static constexpr int GB_MAX_TSR = (NFX_ROW_WORD_PS + GB_WAVES - 1) / GB_WAVES;
+static constexpr int GB_MAX_CT = (NFX_ROW_WORD_PS + (64 / GB_MAX_TSR) - 1) / (64 / GB_MAX_TSR);
+#define NFX_GB_CASE(N, MAXN, F) case N: if constexpr (N <= MAXN) F(gb_int<N>{}); break;
 
 static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const GaborTables *__restrict__ tab, int n_groups, int n_plain, int ps,
                                                      const GaborView *s_view, float mu_gray, int t,
@@ -242,20 +246,21 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
         };
         if (!(dbg & 1)) {
             switch (tsr) {
-            case 3: row_pass(gb_int<3>{}); break;
-            case 4: row_pass(gb_int<4>{}); break;
-            case 5: row_pass(gb_int<5>{}); break;
-            case 6: row_pass(gb_int<6>{}); break;
-            case 7: row_pass(gb_int<7>{}); break;
-            case 8: row_pass(gb_int<8>{}); break;
-            case 9: row_pass(gb_int<9>{}); break;
-            case 10: row_pass(gb_int<10>{}); break;
-            case 11: row_pass(gb_int<11>{}); break;
-            case 12: row_pass(gb_int<12>{}); break;
-            case 13: row_pass(gb_int<13>{}); break;
-            case 14: row_pass(gb_int<14>{}); break;
-            case 15: row_pass(gb_int<15>{}); break;
-            default: row_pass(gb_int<16>{}); break;
+            NFX_GB_CASE(3, GB_MAX_TSR, row_pass)
+            NFX_GB_CASE(4, GB_MAX_TSR, row_pass)
+            NFX_GB_CASE(5, GB_MAX_TSR, row_pass)
+            NFX_GB_CASE(6, GB_MAX_TSR, row_pass)
+            NFX_GB_CASE(7, GB_MAX_TSR, row_pass)
+            NFX_GB_CASE(8, GB_MAX_TSR, row_pass)
+            NFX_GB_CASE(9, GB_MAX_TSR, row_pass)
+            NFX_GB_CASE(10, GB_MAX_TSR, row_pass)
+            NFX_GB_CASE(11, GB_MAX_TSR, row_pass)
+            NFX_GB_CASE(12, GB_MAX_TSR, row_pass)
+            NFX_GB_CASE(13, GB_MAX_TSR, row_pass)
+            NFX_GB_CASE(14, GB_MAX_TSR, row_pass)
+            NFX_GB_CASE(15, GB_MAX_TSR, row_pass)
+            NFX_GB_CASE(16, GB_MAX_TSR, row_pass)
+            default: break;
             }
         }
         wave_lds_fence(); // the wave's own plane columns: written above, read below
@@ -307,21 +312,22 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
         };
         if (!(dbg & 2)) {
             switch (ct) {
-            case 2: column_passes(gb_int<2>{}); break;
-            case 3: column_passes(gb_int<3>{}); break;
-            case 4: column_passes(gb_int<4>{}); break;
-            case 5: column_passes(gb_int<5>{}); break;
-            case 6: column_passes(gb_int<6>{}); break;
-            case 7: column_passes(gb_int<7>{}); break;
-            case 8: column_passes(gb_int<8>{}); break;
-            case 9: column_passes(gb_int<9>{}); break;
-            case 10: column_passes(gb_int<10>{}); break;
-            case 11: column_passes(gb_int<11>{}); break;
-            case 12: column_passes(gb_int<12>{}); break;
-            case 13: column_passes(gb_int<13>{}); break;
-            case 14: column_passes(gb_int<14>{}); break;
-            case 15: column_passes(gb_int<15>{}); break;
-            default: column_passes(gb_int<16>{}); break;
+            NFX_GB_CASE(2, GB_MAX_CT, column_passes)
+            NFX_GB_CASE(3, GB_MAX_CT, column_passes)
+            NFX_GB_CASE(4, GB_MAX_CT, column_passes)
+            NFX_GB_CASE(5, GB_MAX_CT, column_passes)
+            NFX_GB_CASE(6, GB_MAX_CT, column_passes)
+            NFX_GB_CASE(7, GB_MAX_CT, column_passes)
+            NFX_GB_CASE(8, GB_MAX_CT, column_passes)
+            NFX_GB_CASE(9, GB_MAX_CT, column_passes)
+            NFX_GB_CASE(10, GB_MAX_CT, column_passes)
+            NFX_GB_CASE(11, GB_MAX_CT, column_passes)
+            NFX_GB_CASE(12, GB_MAX_CT, column_passes)
+            NFX_GB_CASE(13, GB_MAX_CT, column_passes)
+            NFX_GB_CASE(14, GB_MAX_CT, column_passes)
+            NFX_GB_CASE(15, GB_MAX_CT, column_passes)
+            NFX_GB_CASE(16, GB_MAX_CT, column_passes)
+            default: break;
             }
         }
         wave_lds_fence(); // the next group's row pass overwrites the columns read above
@@ -428,19 +434,17 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
                 V.nrow_rp = rhi - V.rlo + 1;
             }
         };
-        // transposed mask: lane c collects column c, one bit per mask row (three instructions a row); wave w does rows
-        // RPW w .. RPW w + RPW - 1 and puts its bits down as one piece of the lane's word
-        {
-            constexpr int RPW = 64 / GB_WAVES;
+        // transposed mask: lane c collects column c, one bit per mask row (three instructions a row); each of the first four
+        // waves does 16 rows and puts its 16 bits down as one quarter of the lane's word
+        if (wv < 4) {
             unsigned acc = 0u;
             const unsigned wlo = (unsigned)wrow, whi = (unsigned)(wrow >> 32);
-            const int Ra = rmin > RPW * wv ? rmin : RPW * wv, Rb = rmax < RPW * wv + RPW - 1 ? rmax : RPW * wv + RPW - 1;
+            const int Ra = rmin > 16 * wv ? rmin : 16 * wv, Rb = rmax < 16 * wv + 15 ? rmax : 16 * wv + 15;
             for (int R = Ra; R <= Rb; ++R) {
                 const unsigned rl = (unsigned)__builtin_amdgcn_readlane((int)wlo, R), rh = (unsigned)__builtin_amdgcn_readlane((int)whi, R);
-                acc |= (((lane < 32 ? rl : rh) >> (lane & 31)) & 1u) << (R & (RPW - 1));
+                acc |= (((lane < 32 ? rl : rh) >> (lane & 31)) & 1u) << (R & 15);
             }
-            if (GB_WAVES == 4) reinterpret_cast<unsigned short *>(s_view[1].wrow)[4 * lane + wv] = (unsigned short)acc;
-            else reinterpret_cast<unsigned char *>(s_view[1].wrow)[8 * lane + wv] = (unsigned char)acc;
+            reinterpret_cast<unsigned short *>(s_view[1].wrow)[4 * lane + wv] = (unsigned short)acc;
         }
         if (wv == 0) { // visible to the other waves after the barrier below
             put_view(s_view[0], true, wrow, rmin, rmax, cmin, cmax);
