@@ -224,10 +224,9 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
     for (int g = g_begin; g < g_end; ++g) {
         const float *__restrict__ img = tab->groups[g].image; // wave-uniform: the taps arrive through the scalar cache
         // ---- row pass ---------------------------------------------------------------------------------------------
-        auto row_pass = [&](auto ts_tag) {
-            constexpr int TS = decltype(ts_tag)::value, WIN = TS + GB_SIZE - 1;
-            f2 acc[TS];
-            float x[WIN];
+        const bool envelope = __float_as_int(img[GB_META + 1]) != 0; // both row kernels are the bare envelope (90 / 0 degree groups)
+        auto load_window = [&](auto win_tag, float (&x)[decltype(win_tag)::value]) {
+            constexpr int WIN = decltype(win_tag)::value;
             if (tr) { // window element j is gray row c0 + j - 15 (wave-uniform): outside the patch it is the apron's zero
                 // (the first row is made opaque here so that the 40-odd range tests are evaluated on the spot: hoisted out
                 // of the group loop they would sit in registers the FMA blocks need)
@@ -240,27 +239,79 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
 #pragma unroll
                 for (int j = 0; j < WIN; ++j) x[j] = src[j];
             }
+        };
+        auto row_pass = [&](auto ts_tag) {
+            constexpr int TS = decltype(ts_tag)::value, WIN = TS + GB_SIZE - 1;
+            f2 acc[TS];
+            float x[WIN];
+            load_window(gb_int<WIN>{}, x);
             taps2<TS, float>(x, img, (f2){0.0f, 0.0f}, acc);
 #pragma unroll
             for (int q = 0; q < TS; ++q) du[q] = acc[q];
         };
+        // (ra, rb) = (G, G): a packed FMA would compute the same number twice.  Here it carries two OUTPUT POSITIONS instead --
+        // acc[p] = (E[2p], E[2p+1]), fed with the window pair (x[2p+j], x[2p+j+1]) -- half the FMAs for the same chain per
+        // output (tap order and roundings unchanged: the plane is bit-identical).  For an odd TS the last pair's second half
+        // is computed from one element past the window (inside s_g, or the range-tested zero) and not stored.
+        auto row_pass_envelope = [&](auto ts_tag) {
+            constexpr int TS = decltype(ts_tag)::value, TP = (TS + 1) / 2, WIN = 2 * TP + GB_SIZE - 1;
+            float x[WIN];
+            load_window(gb_int<WIN>{}, x);
+            f2 wr[GB_SIZE];
+#pragma unroll
+            for (int j = 0; j < GB_SIZE; ++j) wr[j] = (f2){img[2 * j], img[2 * j + 1]};
+            f2 acc[TP];
+#pragma unroll
+            for (int q = 0; q < TP; ++q) acc[q] = (f2){0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < GB_SIZE; ++j) {
+#pragma unroll
+                for (int q = 0; q < TP; ++q) acc[q] = __builtin_elementwise_fma(wr[j], (f2){x[2 * q + j], x[2 * q + j + 1]}, acc[q]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < TP; ++q) {
+                du[2 * q] = (f2){acc[q].x, acc[q].x};
+                if (2 * q + 1 < TS) du[2 * q + 1] = (f2){acc[q].y, acc[q].y};
+            }
+        };
         if (!(dbg & 1)) {
-            switch (tsr) {
-            NFX_GB_CASE(3, GB_MAX_TSR, row_pass)
-            NFX_GB_CASE(4, GB_MAX_TSR, row_pass)
-            NFX_GB_CASE(5, GB_MAX_TSR, row_pass)
-            NFX_GB_CASE(6, GB_MAX_TSR, row_pass)
-            NFX_GB_CASE(7, GB_MAX_TSR, row_pass)
-            NFX_GB_CASE(8, GB_MAX_TSR, row_pass)
-            NFX_GB_CASE(9, GB_MAX_TSR, row_pass)
-            NFX_GB_CASE(10, GB_MAX_TSR, row_pass)
-            NFX_GB_CASE(11, GB_MAX_TSR, row_pass)
-            NFX_GB_CASE(12, GB_MAX_TSR, row_pass)
-            NFX_GB_CASE(13, GB_MAX_TSR, row_pass)
-            NFX_GB_CASE(14, GB_MAX_TSR, row_pass)
-            NFX_GB_CASE(15, GB_MAX_TSR, row_pass)
-            NFX_GB_CASE(16, GB_MAX_TSR, row_pass)
-            default: break;
+            if (envelope) {
+                switch (tsr) {
+                NFX_GB_CASE(3, GB_MAX_TSR, row_pass_envelope)
+                NFX_GB_CASE(4, GB_MAX_TSR, row_pass_envelope)
+                NFX_GB_CASE(5, GB_MAX_TSR, row_pass_envelope)
+                NFX_GB_CASE(6, GB_MAX_TSR, row_pass_envelope)
+                NFX_GB_CASE(7, GB_MAX_TSR, row_pass_envelope)
+                NFX_GB_CASE(8, GB_MAX_TSR, row_pass_envelope)
+                NFX_GB_CASE(9, GB_MAX_TSR, row_pass_envelope)
+                NFX_GB_CASE(10, GB_MAX_TSR, row_pass_envelope)
+                NFX_GB_CASE(11, GB_MAX_TSR, row_pass_envelope)
+                NFX_GB_CASE(12, GB_MAX_TSR, row_pass_envelope)
+                NFX_GB_CASE(13, GB_MAX_TSR, row_pass_envelope)
+                NFX_GB_CASE(14, GB_MAX_TSR, row_pass_envelope)
+                NFX_GB_CASE(15, GB_MAX_TSR, row_pass_envelope)
+                NFX_GB_CASE(16, GB_MAX_TSR, row_pass_envelope)
+                default: break;
+                }
+            } else {
+                switch (tsr) {
+                NFX_GB_CASE(3, GB_MAX_TSR, row_pass)
+                NFX_GB_CASE(4, GB_MAX_TSR, row_pass)
+                NFX_GB_CASE(5, GB_MAX_TSR, row_pass)
+                NFX_GB_CASE(6, GB_MAX_TSR, row_pass)
+                NFX_GB_CASE(7, GB_MAX_TSR, row_pass)
+                NFX_GB_CASE(8, GB_MAX_TSR, row_pass)
+                NFX_GB_CASE(9, GB_MAX_TSR, row_pass)
+                NFX_GB_CASE(10, GB_MAX_TSR, row_pass)
+                NFX_GB_CASE(11, GB_MAX_TSR, row_pass)
+                NFX_GB_CASE(12, GB_MAX_TSR, row_pass)
+                NFX_GB_CASE(13, GB_MAX_TSR, row_pass)
+                NFX_GB_CASE(14, GB_MAX_TSR, row_pass)
+                NFX_GB_CASE(15, GB_MAX_TSR, row_pass)
+                NFX_GB_CASE(16, GB_MAX_TSR, row_pass)
+                default: break;
+                }
             }
         }
         wave_lds_fence(); // the wave's own plane columns: written above, read below
@@ -556,6 +607,7 @@ static void build_tables(GaborTables &T)
             GaborGroup *G = new_group();
             if (!G) { ok = false; break; }
             for (int j = 0; j < GB_SIZE; ++j) set_row(*G, j, env(tk(j)), env(tk(j)));
+            { const int one = 1; memcpy(&G->image[GB_META + 1], &one, sizeof(int)); } // the row pass pairs output positions
             for (int p = 0; p < GB_MAX_PASSES && i + 2 * p < col.size(); ++p) {
                 Uniq *u = col[i + 2 * p], *v = i + 2 * p + 1 < col.size() ? col[i + 2 * p + 1] : nullptr;
                 for (int j = 0; j < GB_SIZE; ++j)
