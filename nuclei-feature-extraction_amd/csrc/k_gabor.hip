@@ -337,7 +337,11 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
 #pragma unroll
                     for (int q = 0; q < CT; ++q) {
                         const float mq = ((mbits >> q) & 1u) ? 1.0f : 0.0f; // the mask as a 0/1 factor: packed multiply
-                        const f2 d = (f2){acc[q].x - acc[q].y, acc[q].x + acc[q].y} * (f2){mq, mq};
+                        // (A - B, A + B) in ONE packed add: both halves take A from the low word, B from the high word, the low half
+                        // negates it (the compiler builds the pair with two adds and a move)
+                        f2 pm;
+                        asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(pm) : "v"(acc[q]));
+                        const f2 d = pm * (f2){mq, mq};
                         a += d;
                         b = __builtin_elementwise_fma(d, d, b);
                     }
