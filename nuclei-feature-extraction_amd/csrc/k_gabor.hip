@@ -805,7 +805,9 @@ hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0)
                                job.mask_rows, dense, job.out, job.F, col0);
         return hipGetLastError();
     }
-    const int64_t maxb = 256 * 2 * 2;
+    // 64 rounds of the resident workgroups: nuclei differ several-fold in work, and with few large blocks the launch ends when
+    // the unluckiest block does (2 rounds: +5 %); a block still amortises its LDS set-up over some forty nuclei of a large call
+    const int64_t maxb = 256 * 2 * 64;
     const unsigned grid = (unsigned)(job.n < maxb ? job.n : maxb);
     const GaborTables *tab = reinterpret_cast<const GaborTables *>(ctx->gabor_tab);
 #ifdef NFX_EXPERIMENTS // phase-skipping builds for timing experiments only (wrong results): 1 skip row pass, 2 skip column pass, 4 skip all groups

@@ -248,6 +248,7 @@ static __device__ __forceinline__ void sweep(unsigned *tab, int words, unsigned 
 // A wave's LDS footprint grows with its class's capacity and LDS is what limits the waves per CU (11 / 9 / 8 / 6 / 5 / 3 for
 // the six capacities at 48 x 48), so the steps are fine where the nuclei are: half-steps between the powers of two.
 static constexpr int GL_CLASSES = 6;
+static constexpr int GL_CHUNK = 4; // list entries a wave takes per visit to its class's cursor
 static __device__ __host__ __forceinline__ int glcm_class(int K) { return K <= 512 ? 0 : K <= 768 ? 1 : K <= 1024 ? 2 : K <= 1536 ? 3 : K <= 2048 ? 4 : 5; }
 
 __global__ __launch_bounds__(256) void k_glcm_classify(int64_t n, int ps, const uint64_t *__restrict__ mask_rows, const int *__restrict__ areas,
@@ -347,7 +348,7 @@ static __device__ void glcm_features(const double (&a)[GL_NACC], const GlcmLuts 
 // QCAP: size class; serves the nuclei of its class list (K <= QCAP mask pixels).
 // NPRE: 16-byte pieces of a u8 patch per lane (3 ps^2 / 1024 rounded up: 3, 7 or 12 for ps <= 32, 48, 64)
 template <typename T, int QCAP, int NPRE>
-__global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048 ? 2 : 1))) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int ps,
+__global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048 ? 2 : 1))) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int *__restrict__ cursor, int ps,
                                              const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
                                              const GlcmLuts *__restrict__ lut, double *__restrict__ slots, float *__restrict__ out, int F,
                                              int col0, int64_t *__restrict__ dbg)
@@ -368,9 +369,15 @@ __global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048
 
     int lane = threadIdx.x;
     const int P = ps * ps;
+    // The class list is handed out in CHUNKS of GL_CHUNK entries: a wave's first chunk is the static one of its block index,
+    // every further one comes from the class's cursor (an atomic whose answer is needed GL_CHUNK - 1 nuclei later, so its
+    // latency never shows).  Nuclei of one class differ 2-3x in work; with a static stride the launch ended when the
+    // unluckiest wave did (-6 % measured for the dynamic hand-out).
     const int cnt = *count;
-    int j = blockIdx.x;
+    int j = (int)blockIdx.x * GL_CHUNK;
     if (j >= cnt) return;
+    int chunk_pos = 0;              // position of j inside its chunk
+    int next_base = 0x7FFFFFF0;     // lane 0: first entry of the wave's next chunk (valid from chunk_pos 0 of the current one on)
     const double *__restrict__ rank_tab = lut->dO; // dD follows it
     // u8 patches travel through registers: the next nucleus's patch and mask row are requested as soon as the
     // current ones have been put down in LDS, so their HBM latency hides behind a whole nucleus of work
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048
     double *const slot = slots + (size_t)blockIdx.x * 16 * GL_NACC; // this wave's parking slot: [offset][level][GL_NACC]
     int64_t i_done = -1; // the nucleus whose sums sit in the slot, features not yet evaluated
 #pragma unroll 1
-    for (;; j += gridDim.x) {
+    for (;;) {
         const bool more = j < cnt; // wave-uniform
         const int64_t i = i_next;
         const uint64_t myrow = row_next;
@@ -433,8 +440,11 @@ __global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048
         __builtin_amdgcn_sched_barrier(0);
         if (!more) break;
         i_done = i;
-        if (j + (int)gridDim.x < cnt) {
-            i_next = list[j + gridDim.x];
+        if (chunk_pos == 0 && lane == 0) next_base = (int)gridDim.x * GL_CHUNK + atomicAdd(cursor, GL_CHUNK);
+        const int jn = chunk_pos < GL_CHUNK - 1 ? j + 1 : __builtin_amdgcn_readfirstlane(next_base);
+        chunk_pos = chunk_pos < GL_CHUNK - 1 ? chunk_pos + 1 : 0;
+        if (jn < cnt) {
+            i_next = list[jn];
             NFX_GLCM_REQUEST(i_next);
         }
         // ---- row prefix ---------------------------------------------------------------------------------------
@@ -646,6 +656,7 @@ __global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048
             // lane-0 stores straight to memory would touch five partial lines per combination
             if (lane < 4 * GL_NACC) slot[oi * 4 * GL_NACC + lane] = s_sums[lane];
         }
+        j = jn;
     }
 }
 
@@ -761,7 +772,10 @@ __global__ __launch_bounds__(256) void k_glcm_wide(int64_t n, int ps, const T *_
     }
 }
 
-static constexpr int GL_MAX_GRID = 256 * 11 * 4; // resident single-wave workgroups of the largest launch = parking slots
+#ifndef NFX_GL_ROUNDS
+#define NFX_GL_ROUNDS 2
+#endif
+static constexpr int GL_MAX_GRID = 256 * 11 * NFX_GL_ROUNDS; // resident single-wave workgroups of the largest launch = parking slots
 static size_t glcm_slots_bytes() { return sizeof(double) * 16 * GL_NACC * (size_t)GL_MAX_GRID; }
 static constexpr int GW_GRID = 256; // workgroups (and dense slabs) of the wide kernel
 size_t glcm_scratch_bytes(const Job &job)
@@ -804,10 +818,10 @@ static void launch_class(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, doub
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_glcm<T, QCAP, NPRE>, 64, 0) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 1; }
         wgs_per_cu = b > 11 ? 11 : b;
     }
-    const int64_t m = 256ll * wgs_per_cu * 4;
-    static_assert(256 * 11 * 4 <= GL_MAX_GRID, "every launch's waves have a parking slot");
+    const int64_t m = 256ll * wgs_per_cu * NFX_GL_ROUNDS;
+    static_assert(256 * 11 * NFX_GL_ROUNDS <= GL_MAX_GRID, "every launch's waves have a parking slot");
     const unsigned grid = (unsigned)(job.n < m ? job.n : m);
-    hipLaunchKernelGGL((k_glcm<T, QCAP, NPRE>), dim3(grid), dim3(64), 0, ctx->stream, lists + (int64_t)cls * job.n, counts + cls, job.ps,
+    hipLaunchKernelGGL((k_glcm<T, QCAP, NPRE>), dim3(grid), dim3(64), 0, ctx->stream, lists + (int64_t)cls * job.n, counts + cls, const_cast<int *>(counts) + GL_CLASSES + cls, job.ps,
                        reinterpret_cast<const T *>(job.patches), job.mask_rows, lut, slots, job.out, job.F, col0, job.dbg_glcm);
 }
 
@@ -845,7 +859,7 @@ hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
     int *lists = reinterpret_cast<int *>(reinterpret_cast<char *>(scratch) + glcm_slots_bytes());
     int *counts = lists + GL_CLASSES * job.n;
     const GlcmLuts *lut = reinterpret_cast<const GlcmLuts *>(ctx->glcm_lut);
-    e = hipMemsetAsync(counts, 0, sizeof(int) * GL_CLASSES, ctx->stream);
+    e = hipMemsetAsync(counts, 0, sizeof(int) * 2 * GL_CLASSES, ctx->stream); // list lengths | list cursors
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_glcm_classify, dim3((unsigned)((job.n + 63) / 64)), dim3(256), 0, ctx->stream, job.n, job.ps, job.mask_rows, job.areas, lists, counts);
     if (job.patches_f32) launch_classes<float, 1>(ctx, job, lut, slots, lists, counts, col0);
