@@ -248,7 +248,7 @@ static __device__ __forceinline__ void sweep(unsigned *tab, int words, unsigned 
 // A wave's LDS footprint grows with its class's capacity and LDS is what limits the waves per CU (11 / 9 / 8 / 6 / 5 / 3 for
 // the six capacities at 48 x 48), so the steps are fine where the nuclei are: half-steps between the powers of two.
 static constexpr int GL_CLASSES = 6;
-static constexpr int GL_CHUNK = 4; // list entries a wave takes per visit to its class's cursor
+static constexpr int GL_CHUNK = 2; // list entries a wave takes per visit to its class's cursor
 static __device__ __host__ __forceinline__ int glcm_class(int K) { return K <= 512 ? 0 : K <= 768 ? 1 : K <= 1024 ? 2 : K <= 1536 ? 3 : K <= 2048 ? 4 : 5; }
 
 __global__ __launch_bounds__(256) void k_glcm_classify(int64_t n, int ps, const uint64_t *__restrict__ mask_rows, const int *__restrict__ areas,
