@@ -229,14 +229,36 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
     // operations per channel and pixel instead of three f64 ones) and scaled once at the end
     constexpr bool INT4 = sizeof(T) == 1;
     double ss = 0.0, cc = 0.0;
-    double s1[9], s2[9];
+    // The float-valued channels are summed about a PIVOT -- an estimate of the channel's mean over the nucleus, the same
+    // in every lane -- in f32 per lane (at most 64 terms) and in f64 across lanes: d = x - pivot is small against x, so
+    // sum d and sum d^2 carry no cancellation worth f64 (three f32 instructions per channel and pixel instead of four
+    // f64 ones at twice the issue cost); mean and variance are put together in f64 at the end.
+    float f1[9], f2s[9], pv[9];
     unsigned iu[4] = {0u, 0u, 0u, 0u}, iu2[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
-    auto pixel = [&](int p, bool on, unsigned b0, unsigned b1, unsigned b2, float f0, float f1, float f2, double sv, double cv) {
+    for (int k = 0; k < 9; ++k) { f1[k] = 0.0f; f2s[k] = 0.0f; pv[k] = 0.0f; }
+    {   // pivot = mean of 64 pixels spread evenly over the list (one per lane; a wave total per channel)
+        const int Kc = K < cap ? K : cap;
+        const int pm = Kc > 0 ? s_list[(lane * Kc) >> 6] : 0;
+        float smp[9];
+        if (sizeof(T) == 1) {
+            const uint8_t *pb = reinterpret_cast<const uint8_t *>(pp);
+            const unsigned b0 = pb[pm], b1 = pb[P + pm], b2 = pb[2 * P + pm];
+            pixel_channels<T>(u8_unit(b0), u8_unit(b1), u8_unit(b2), b0, b1, b2, 0.0f, s_od, smp);
+        } else {
+            pixel_channels<T>(Px<T>::ld(pp, pm), Px<T>::ld(pp, P + pm), Px<T>::ld(pp, 2 * P + pm), 0u, 0u, 0u, 0.0f, s_od, smp);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (INT4 && (k < 3 || k == 5)) continue;
+            const float m = wave_total_f32(smp[k]) * (1.0f / 64.0f);
+            pv[k] = (m == m && fabsf(m) < 3.0e38f) ? m : 0.0f; // a NaN / infinite pixel must not poison every difference
+        }
+    }
+    auto pixel = [&](int p, bool on, unsigned b0, unsigned b1, unsigned b2, float f0, float f1_, float f2_, double sv, double cv) {
         float x[9];
         if (sizeof(T) == 1) pixel_channels<T>(u8_unit(b0), u8_unit(b1), u8_unit(b2), b0, b1, b2, 0.0f, s_od, x); // utils.rs:172
-        else pixel_channels<T>(f0, f1, f2, 0u, 0u, 0u, 0.0f, s_od, x);
+        else pixel_channels<T>(f0, f1_, f2_, 0u, 0u, 0u, 0.0f, s_od, x);
         ss += on ? sv : 0.0;
         cc += on ? cv : 0.0;
         if (INT4) {
@@ -248,9 +270,9 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             if (INT4 && (k < 3 || k == 5)) continue;
-            const double xd = on ? (double)x[k] : 0.0;
-            s1[k] += xd;
-            s2[k] += xd * xd;
+            const float d = on ? x[k] - pv[k] : 0.0f;
+            f1[k] += d;
+            f2s[k] = fmaf(d, d, f2s[k]);
         }
     };
     const int Kl = K < cap ? K : cap;
@@ -290,11 +312,13 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
     }
     const float area = (float)K;
     float *o = out + i * (int64_t)F + col0; // column order color.rs:80-99: mean rgb, std rgb, mean hsv, std hsv, mean hed, std hed
-    // mean and population standard deviation of channel k from sum x (a) and sum x^2 (b), one lane per channel
-    auto finish = [&](int k, double a, double b, float mh) {
-        const float mu = (float)a / area;
-        const double mud = (double)mu;
-        double D = b - 2.0 * mud * a + (double)K * mud * mud; // sum (x-mu)^2 about the f32 mean
+    // mean and population standard deviation of channel k, one lane per channel, from the sums about the pivot p:
+    // a = sum (x - p), b = sum (x - p)^2.  mean = (float)(sum x) / K as color.rs:119-121 has it; the deviations are taken about
+    // that f32 mean, sum (x - mu)^2 = b - 2 (mu - p) a + K (mu - p)^2 (the two-pass result of color.rs:123-128)
+    auto finish = [&](int k, double a, double b, double p, float mh) {
+        const float mu = (float)(a + (double)K * p) / area;
+        const double md = (double)mu - p;
+        double D = b - 2.0 * md * a + (double)K * md * md;
         D = D > 0.0 ? D : (D == D ? 0.0 : D);                 // rounding can leave -1e-17; keep NaN
         const float sd = sqrtf((float)D / area);
         o[k < 3 ? k : (k < 6 ? 3 + k : 6 + k)] = k == 3 ? mh : mu; // mean_h is the circular mean
@@ -308,33 +332,44 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
         mh = mh + 360.0f;
         return fmodf(mh, 360.0f); // color.rs:154
     };
-    // all totals in reduce-scatter butterflies (wave_ops.h); lane l ends up with the pair (sum x, sum x^2) of one channel
+    // all totals in reduce-scatter butterflies (wave_ops.h); lane l ends up with the pair (sum, sum of squares) of one channel
     if (INT4) {
         unsigned A4[4] = {iu[0], iu[1], iu[2], iu[3]}, B4[4] = {iu2[0], iu2[1], iu2[2], iu2[3]};
         const unsigned ua = wave_reduce_scatter(A4, lane), ub = wave_reduce_scatter(B4, lane);
-        double T1[8] = {s1[3], s1[4], s1[6], s1[7], s1[8], ss, cc, 0.0};
-        double T2[8] = {s2[3], s2[4], s2[6], s2[7], s2[8], 0.0, 0.0, 0.0};
+        double T1[8] = {(double)f1[3], (double)f1[4], (double)f1[6], (double)f1[7], (double)f1[8], ss, cc, 0.0};
+        double T2[8] = {(double)f2s[3], (double)f2s[4], (double)f2s[6], (double)f2s[7], (double)f2s[8], 0.0, 0.0, 0.0};
         const double a = wave_reduce_scatter(T1, lane), b = wave_reduce_scatter(T2, lane);
         // scatter_index<8> reverses three bits: slot 5 (101b) sits in lane 5, slot 6 (110b) in lane 3
         ss = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 5), __builtin_amdgcn_readlane(__double2loint(a), 5));
         cc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 3), __builtin_amdgcn_readlane(__double2loint(a), 3));
         const float mh = circular_mean(ss, cc);
-        if (lane < 4) { // r, g, b, v: sums of bytes -> sums of byte / 255
+        if (lane < 4) { // r, g, b, v: exact sums of bytes -> sums of byte / 255 (pivot 0)
             const int c = scatter_index<4>(lane);
-            finish(c < 3 ? c : 5, (double)ua / 255.0, (double)ub / 65025.0, mh);
+            finish(c < 3 ? c : 5, (double)ua / 255.0, (double)ub / 65025.0, 0.0, mh);
         }
         const int j = scatter_index<8>(lane & 7);
-        if (lane < 8 && j < 5) finish(j < 2 ? 3 + j : 4 + j, a, b, mh); // h, s, he, eo, da
+        if (lane < 8 && j < 5) { // h, s, he, eo, da
+            const int k = j < 2 ? 3 + j : 4 + j;
+            float pk = pv[3];
+#pragma unroll
+            for (int q = 4; q < 9; ++q) pk = k == q ? pv[q] : pk;
+            finish(k, a, b, (double)pk, mh);
+        }
     } else {
-        double T1[16] = {s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7], s1[8], ss, cc, 0.0, 0.0, 0.0, 0.0, 0.0};
-        double T2[16] = {s2[0], s2[1], s2[2], s2[3], s2[4], s2[5], s2[6], s2[7], s2[8], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double T1[16] = {(double)f1[0], (double)f1[1], (double)f1[2], (double)f1[3], (double)f1[4], (double)f1[5], (double)f1[6], (double)f1[7], (double)f1[8], ss, cc, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double T2[16] = {(double)f2s[0], (double)f2s[1], (double)f2s[2], (double)f2s[3], (double)f2s[4], (double)f2s[5], (double)f2s[6], (double)f2s[7], (double)f2s[8], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         const double a = wave_reduce_scatter(T1, lane), b = wave_reduce_scatter(T2, lane);
         // scatter_index<16> reverses the four bits: slot 9 (1001b) sits in lane 9, slot 10 (1010b) in lane 5
         ss = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 9), __builtin_amdgcn_readlane(__double2loint(a), 9));
         cc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 5), __builtin_amdgcn_readlane(__double2loint(a), 5));
         const float mh = circular_mean(ss, cc);
         const int k = scatter_index<16>(lane & 15);
-        if (lane < 16 && k < 9) finish(k, a, b, mh);
+        if (lane < 16 && k < 9) {
+            float pk = pv[0];
+#pragma unroll
+            for (int q = 1; q < 9; ++q) pk = k == q ? pv[q] : pk;
+            finish(k, a, b, (double)pk, mh);
+        }
     }
 }
 
