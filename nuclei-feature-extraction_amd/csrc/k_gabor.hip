@@ -22,12 +22,15 @@
 //   8 row passes and 12 column passes serve the whole bank (25 + 24 unpaired ones at first).
 //
 // One 256-thread workgroup per nucleus (persistent): gray patch with a zero apron and the plane pair (zero aprons,
-// odd row stride) live in LDS (76 KB, two workgroups per CU).  Both passes are REGISTER-TILED and WAVE-STRIPED:
-// wave w owns strip w (8, 12 or 16 outputs wide, chosen per nucleus from the mask's bounding box so that four
-// strips cover it); a lane loads a (TS+29)-value window once and produces TS outputs, the 30 tap pairs arrive as
-// LDS broadcasts from a double-buffered per-group table.  Row passes cover only the mask's column range and the
-// rows within 15 of the mask; per-strip sums are f32 about a per-filter shift (DC gain x mean masked gray),
-// accumulated in f64 and reduced with DPP.
+// odd row stride) live in LDS (76 KB, two workgroups per CU).  Both passes are REGISTER-TILED, and the four waves are
+// AUTONOMOUS: wave w owns column strip w of the mask's bounding box for BOTH passes of every group -- its row pass fills
+// those columns of the plane pair, its column passes read nothing else -- so there is no workgroup barrier between the
+// groups (one between the two views; see gabor_nucleus).  A lane loads a (TS+29)-value window once and produces TS
+// outputs; the 30 tap pairs of a pass are wave-uniform and arrive through the SCALAR cache as scalar operands of the
+// packed FMAs (no LDS traffic, no staging).  Row passes cover only the mask's column range and the rows within 15 of
+// the mask; the envelope row passes pair two output positions per packed FMA; per-strip sums are f32 about a
+// per-filter shift (DC gain x mean masked gray), reduced with one DPP butterfly per pass and accumulated in f64.
+// The next nucleus's patch and mask rows are requested while the current nucleus is processed.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -61,7 +64,7 @@ struct GaborGroup {
     int n_pass, pad0, pad1, pad2;
     int combine[4];            // per column pass: 0 -> responses (accA, accB); 1 -> (accA - accB, accA + accB)
     int filt[4][2];            // per column pass: the two filter slots its responses belong to (-1: none)
-    float image[GB_WBUF];      // the group exactly as it sits in LDS: [row (ra,rb) x 30, n_pass | pass0 (ca,cb) x 30, dc0, dc1, meta | pass1 | pass2]
+    float image[GB_WBUF];      // what the kernel reads with scalar loads: [row (ra,rb) x 30, n_pass, envelope flag | pass0 (ca,cb) x 30, dc0, dc1, meta | pass1 | pass2]
 };
 struct GaborFilter {
     int ch0, ch1;
