@@ -369,12 +369,14 @@ __global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048
 
     int lane = threadIdx.x;
     const int P = ps * ps;
-    // The class list is handed out in CHUNKS of GL_CHUNK entries: a wave's first chunk is the static one of its block index,
+    // The class list is handed out in CHUNKS of GL_CHUNK entries (single entries when the list is short against the grid: a
+    // call of one reference batch wants every nucleus on its own wave): a wave's first chunk is the static one of its block index,
     // every further one comes from the class's cursor (an atomic whose answer is needed GL_CHUNK - 1 nuclei later, so its
     // latency never shows).  Nuclei of one class differ 2-3x in work; with a static stride the launch ended when the
     // unluckiest wave did (-6 % measured for the dynamic hand-out).
     const int cnt = *count;
-    int j = (int)blockIdx.x * GL_CHUNK;
+    const int chunk = cnt >= GL_CHUNK * (int)gridDim.x ? GL_CHUNK : 1; // wave-uniform
+    int j = (int)blockIdx.x * chunk;
     if (j >= cnt) return;
     int chunk_pos = 0;              // position of j inside its chunk
     int next_base = 0x7FFFFFF0;     // lane 0: first entry of the wave's next chunk (valid from chunk_pos 0 of the current one on)
@@ -440,9 +442,9 @@ __global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048
         __builtin_amdgcn_sched_barrier(0);
         if (!more) break;
         i_done = i;
-        if (chunk_pos == 0 && lane == 0) next_base = (int)gridDim.x * GL_CHUNK + atomicAdd(cursor, GL_CHUNK);
-        const int jn = chunk_pos < GL_CHUNK - 1 ? j + 1 : __builtin_amdgcn_readfirstlane(next_base);
-        chunk_pos = chunk_pos < GL_CHUNK - 1 ? chunk_pos + 1 : 0;
+        if (chunk_pos == 0 && lane == 0) next_base = (int)gridDim.x * chunk + atomicAdd(cursor, chunk);
+        const int jn = chunk_pos < chunk - 1 ? j + 1 : __builtin_amdgcn_readfirstlane(next_base);
+        chunk_pos = chunk_pos < chunk - 1 ? chunk_pos + 1 : 0;
         if (jn < cnt) {
             i_next = list[jn];
             NFX_GLCM_REQUEST(i_next);
