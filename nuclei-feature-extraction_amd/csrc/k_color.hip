@@ -60,11 +60,13 @@ static __device__ __forceinline__ void hsv_from_rgb(float r, float g, float b, f
 }
 
 // sin and cos of the hue angle without a general argument reduction: the hexcone hue is 120 s + 60 f degrees with a
-// sector s in {0,1,2} and f = (difference of the two smaller channels) / (max - min) in [-1,1], i.e. s/3 + f/6 of a turn
-// in [-1/6, 1] -- exactly the argument the hardware sine / cosine take (v_sin_f32 / v_cos_f32: input in revolutions,
-// absolute error below 1e-6 on this range).  The reference rounds 60 f and the degree-to-radian product to f32 first
-// (color.rs:147), which moves the angle by up to 7e-7 rad; the sums of 100 patches x K pixels that follow are compared at 1e-5
-// of a full circle.
+// sector s in {0,1,2} and f = (difference of the two smaller channels) / (max - min) in [-1,1], so
+//     sin(hue) = sin(120 s) cos(x) + cos(120 s) sin(x),  x = f pi/3 in [-1.05, 1.05]
+// and two short Taylor polynomials (errors 4e-8 and 4e-9 at the interval ends) replace sincosf.  The reference
+// rounds 60 f and the degree-to-radian product to f32 first (color.rs:147), which moves the angle by up to 7e-7 rad;
+// the sums of 100 patches x K pixels that follow are compared at 1e-5.  (The hardware sine / cosine on the angle in
+// revolutions are 12 % faster for this kernel and 1e-6 off: a batch whose hues spread round the circle has a short
+// resultant vector, and its circular mean moved by 6e-3 degrees -- outside the tolerance -- in tests/test_geometry_extremes_gpu.py.)
 static __device__ __forceinline__ void hue_sincos(float r, float g, float b, float &sn, float &cs)
 {
     const float mx = fmaxf(r, fmaxf(g, b));
@@ -74,10 +76,21 @@ static __device__ __forceinline__ void hue_sincos(float r, float g, float b, flo
     const bool isr = mx == r, isg = !isr && mx == g;
     const float num = isr ? g - b : (isg ? b - r : r - g);
     const float f = d == 0.0f ? 0.0f : quot(num, d);
-    const float sector = (isr || d == 0.0f) ? 0.0f : (isg ? 0.33333333333333333f : 0.66666666666666667f);
-    const float turn = fmaf(f, 0.16666666666666667f, sector);
-    sn = __builtin_amdgcn_sinf(turn);
-    cs = __builtin_amdgcn_cosf(turn);
+    const bool s0 = isr || d == 0.0f;
+    const float ss = s0 ? 0.0f : (isg ? 0.86602540378443865f : -0.86602540378443865f); // sin(120 s)
+    const float sc = s0 ? 1.0f : -0.5f;                                                  // cos(120 s)
+    const float x = f * 1.0471975511965976f, x2 = x * x;
+    float ps = fmaf(x2, 2.7557319223985893e-06f, -1.9841269841269841e-04f);
+    ps = fmaf(x2, ps, 8.3333333333333333e-03f);
+    ps = fmaf(x2, ps, -1.6666666666666667e-01f);
+    ps = fmaf(x2 * x, ps, x);
+    float pc = fmaf(x2, -2.7557319223985888e-07f, 2.4801587301587302e-05f);
+    pc = fmaf(x2, pc, -1.3888888888888889e-03f);
+    pc = fmaf(x2, pc, 4.1666666666666664e-02f);
+    pc = fmaf(x2, pc, -0.5f);
+    pc = fmaf(x2, pc, 1.0f);
+    sn = fmaf(ss, pc, sc * ps);
+    cs = fmaf(sc, pc, -(ss * ps));
 }
 
 // optical density log(max(x,1e-6))/log(1e-6), evaluated in f64 and rounded (f32 inputs only;

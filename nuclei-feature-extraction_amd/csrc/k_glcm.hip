@@ -252,7 +252,7 @@ static constexpr int GL_CHUNK = 2; // list entries a wave takes per visit to its
 static __device__ __host__ __forceinline__ int glcm_class(int K) { return K <= 512 ? 0 : K <= 768 ? 1 : K <= 1024 ? 2 : K <= 1536 ? 3 : K <= 2048 ? 4 : 5; }
 
 __global__ __launch_bounds__(256) void k_glcm_classify(int64_t n, int ps, const uint64_t *__restrict__ mask_rows, const int *__restrict__ areas,
-                                                       int *__restrict__ lists, int *__restrict__ counts)
+                                                       int *__restrict__ lists, int *__restrict__ counts, int force_class)
 {
     // sixteen lanes per nucleus, four nuclei per lane group: 64 nuclei per block.  List slots are handed out inside the
     // block (LDS), so the four global counters see one atomic per block and class, not one per nucleus.
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_glcm_classify(int64_t n, int ps, const 
                 for (int r = sub; r < ps; r += 16) K += __popcll(mask_rows[i * ps + r]);
             K += __shfl_xor(K, 1, 64); K += __shfl_xor(K, 2, 64); K += __shfl_xor(K, 4, 64); K += __shfl_xor(K, 8, 64);
         }
-        cls[u] = glcm_class(K);
+        cls[u] = force_class >= 0 ? force_class : glcm_class(K); // a small call runs as ONE launch of the class every mask fits
         rank[u] = (i < n && sub == 0) ? atomicAdd(&s_cnt[cls[u]], 1) : 0;
     }
     __syncthreads();
@@ -828,15 +828,16 @@ static void launch_class(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, doub
 }
 
 template <typename T, int NPRE>
-static void launch_classes(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *slots, const int *lists, const int *counts, int col0)
+static void launch_classes(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *slots, const int *lists, const int *counts, int col0, int only)
 {
     const int P = job.ps * job.ps;
-    launch_class<T, 512, NPRE>(ctx, job, lut, slots, lists, counts, 0, col0);
-    if (P > 512) launch_class<T, 768, NPRE>(ctx, job, lut, slots, lists, counts, 1, col0);
-    if (P > 768) launch_class<T, 1024, NPRE>(ctx, job, lut, slots, lists, counts, 2, col0);
-    if (P > 1024) launch_class<T, 1536, NPRE>(ctx, job, lut, slots, lists, counts, 3, col0);
-    if (P > 1536) launch_class<T, 2048, NPRE>(ctx, job, lut, slots, lists, counts, 4, col0);
-    if (P > 2048) launch_class<T, 4096, NPRE>(ctx, job, lut, slots, lists, counts, 5, col0);
+    auto want = [&](int cls, int reach) { return P > reach && (only < 0 || only == cls); };
+    if (want(0, 0)) launch_class<T, 512, NPRE>(ctx, job, lut, slots, lists, counts, 0, col0);
+    if (want(1, 512)) launch_class<T, 768, NPRE>(ctx, job, lut, slots, lists, counts, 1, col0);
+    if (want(2, 768)) launch_class<T, 1024, NPRE>(ctx, job, lut, slots, lists, counts, 2, col0);
+    if (want(3, 1024)) launch_class<T, 1536, NPRE>(ctx, job, lut, slots, lists, counts, 3, col0);
+    if (want(4, 1536)) launch_class<T, 2048, NPRE>(ctx, job, lut, slots, lists, counts, 4, col0);
+    if (want(5, 2048)) launch_class<T, 4096, NPRE>(ctx, job, lut, slots, lists, counts, 5, col0);
 }
 
 hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
@@ -863,11 +864,15 @@ hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
     const GlcmLuts *lut = reinterpret_cast<const GlcmLuts *>(ctx->glcm_lut);
     e = hipMemsetAsync(counts, 0, sizeof(int) * 2 * GL_CLASSES, ctx->stream); // list lengths | list cursors
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_glcm_classify, dim3((unsigned)((job.n + 63) / 64)), dim3(256), 0, ctx->stream, job.n, job.ps, job.mask_rows, job.areas, lists, counts);
-    if (job.patches_f32) launch_classes<float, 1>(ctx, job, lut, slots, lists, counts, col0);
-    else if (job.ps <= 32) launch_classes<uint8_t, 3>(ctx, job, lut, slots, lists, counts, col0);
-    else if (job.ps <= 48) launch_classes<uint8_t, 7>(ctx, job, lut, slots, lists, counts, col0);
-    else launch_classes<uint8_t, 12>(ctx, job, lut, slots, lists, counts, col0);
+    // A call of a few hundred nuclei (one reference batch through the trait entry) is latency: six launches, each as long as
+    // its slowest nucleus.  It runs as ONE launch of the class that holds every mask the patch size allows -- its waves all fit
+    // the chip at once (3 per CU in the largest class).
+    const int only = job.n <= 768 ? glcm_class(job.ps * job.ps) : -1;
+    hipLaunchKernelGGL(k_glcm_classify, dim3((unsigned)((job.n + 63) / 64)), dim3(256), 0, ctx->stream, job.n, job.ps, job.mask_rows, job.areas, lists, counts, only);
+    if (job.patches_f32) launch_classes<float, 1>(ctx, job, lut, slots, lists, counts, col0, only);
+    else if (job.ps <= 32) launch_classes<uint8_t, 3>(ctx, job, lut, slots, lists, counts, col0, only);
+    else if (job.ps <= 48) launch_classes<uint8_t, 7>(ctx, job, lut, slots, lists, counts, col0, only);
+    else launch_classes<uint8_t, 12>(ctx, job, lut, slots, lists, counts, col0, only);
     return hipGetLastError();
 }
 
