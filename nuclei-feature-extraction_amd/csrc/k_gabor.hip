@@ -44,11 +44,8 @@
 
 namespace nfx {
 
-#ifndef NFX_GB_THREADS
-#define NFX_GB_THREADS 256
-#endif
-static constexpr int GB_SIZE = 30, GB_PAD = 15, GB_THREADS = NFX_GB_THREADS, GB_WAVES = GB_THREADS / 64;
-static_assert(GB_WAVES == 4 || GB_WAVES == 8, "GB_WAVES strips of TSR columns have to tile the plane's 64 columns");
+static constexpr int GB_SIZE = 30, GB_PAD = 15, GB_THREADS = 256, GB_WAVES = GB_THREADS / 64;
+static_assert(GB_WAVES == 4, "four strips of TSR <= 16 columns tile the plane's 64 columns; the transposed-mask step hands 16 rows to a wave");
 static constexpr int GB_GW = NFX_ROW_WORD_PS + GB_SIZE - 1; // gray row with apron: 93 floats
 static constexpr int GB_UW = NFX_ROW_WORD_PS + 1;           // U/W row stride (odd: conflict-free both ways)
 static constexpr int GB_UH = NFX_ROW_WORD_PS + GB_SIZE - 1; // U/W rows incl. zero aprons: 93
@@ -137,8 +134,6 @@ static __device__ __forceinline__ void taps2(const X (&x)[XN], const float *__re
 struct GaborShared {
     float *g;
     f2 *UW;          // plane pair, interleaved
-    const float *wt; // current group's taps
-    const uint64_t *rows;
 };
 
 // the mask as one orientation of the nucleus sees it (kept in LDS, so that nothing of the second view occupies
@@ -414,7 +409,7 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
     const int n_groups = tab->n_groups, n_filters = tab->n_filters, n_plain = tab->n_plain;
     __syncthreads();
     GaborShared S;
-    S.g = s_g; S.UW = s_UW; S.rows = s_rows;
+    S.g = s_g; S.UW = s_UW;
     // u8 patches whose rows are whole 16-byte pieces come in with one 16-byte load per channel and thread
     const bool vec = sizeof(T) == 1 && (ps & 15) == 0 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0;
 
@@ -492,9 +487,9 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
                 V.nrow_rp = rhi - V.rlo + 1;
             }
         };
-        // transposed mask: lane c collects column c, one bit per mask row (three instructions a row); each of the first four
-        // waves does 16 rows and puts its 16 bits down as one quarter of the lane's word
-        if (wv < 4) {
+        // transposed mask: lane c collects column c, one bit per mask row (three instructions a row); wave w does rows
+        // 16w .. 16w+15 and puts its 16 bits down as one quarter of the lane's word
+        {
             unsigned acc = 0u;
             const unsigned wlo = (unsigned)wrow, whi = (unsigned)(wrow >> 32);
             const int Ra = rmin > 16 * wv ? rmin : 16 * wv, Rb = rmax < 16 * wv + 15 ? rmax : 16 * wv + 15;
