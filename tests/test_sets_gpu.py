@@ -100,3 +100,17 @@ def test_device_memory_entry_equals_host_entry(nfx, ctx):
     torch.cuda.synchronize()
     ctx.set_stream(0)
     assert np.array_equal(dev.cpu().numpy(), host, equal_nan=True)
+
+
+@pytest.mark.parametrize("ps,n", [(32, 30000), (48, 9000)])
+def test_glcm_list_hand_out_shapes(nfx, ctx, ps, n):
+    """The three ways a GLCM launch walks its class lists (k_glcm.hip): one launch of the top class for a call of a few
+    hundred nuclei (every other test), single entries per cursor visit when a list is short against the grid (9 000 nuclei),
+    pairs from the class cursor when it is long (30 000 nuclei at 32x32: 25 000 masks in one class, 5 632 waves).  Counts and
+    columns against the oracle; the rows must not depend on which wave took which nucleus."""
+    off, xy, pu8 = par.make_inputs(300 + ps, n, ps)
+    want, _ = orc.extract([2], off, xy, pu8, ps, batch_size=100, threads=16)
+    got, _ = ctx.extract([2], off, xy, pu8, ps, batch_size=100)
+    par.assert_rows_close(got, want, par.column_scales(nfx, [2], ps), what=f"glcm ps={ps} n={n}")
+    again, _ = ctx.extract([2], off, xy, pu8, ps, batch_size=100)
+    assert np.array_equal(got, again, equal_nan=True)   # dynamic hand-out, same bits
