@@ -189,6 +189,13 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
                     const unsigned gg[4] = {pre[1][k].x, pre[1][k].y, pre[1][k].z, pre[1][k].w};
                     const unsigned bb[4] = {pre[2][k].x, pre[2][k].y, pre[2][k].z, pre[2][k].w};
                     unsigned (&packed)[4] = lvl[k];
+                    // a band of sixteen rows above or below the nucleus holds no mask pixel in any lane's piece: nothing to quantise
+                    if (__ballot(mrow != 0u) == 0ull) {
+                        packed[0] = packed[1] = packed[2] = packed[3] = 0xFFFFFFFFu;
+                        unsigned *dst0 = reinterpret_cast<unsigned *>(s_q + r * QS + c0);
+                        dst0[0] = dst0[1] = dst0[2] = dst0[3] = 0xFFFFFFFFu;
+                        continue;
+                    }
 #pragma unroll
                     for (int w4 = 0; w4 < 4; ++w4) {
                         unsigned word = 0;
