@@ -169,6 +169,48 @@ static __device__ __forceinline__ unsigned pair_acc(bool fwd, unsigned a, unsign
     return fwd ? (diag ? (unsigned)GL_RANKS : 0u) + rk : 0u;
 }
 
+// ---- the two list entries of an iteration side by side in the halves of one register ------------------------------
+// Levels are at most 253, triangular indices of the dense tables at most 2079 and cell keys at most 0xFDFD: the
+// ordering, the differences, the table indices and the hash keys of BOTH entries are packed 16-bit instructions, and the
+// sums of |a-b| and (a-b)^2 take one v_dot2_u32_u16 each for the pair.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ u16x2 as_u16x2(unsigned v) { return __builtin_bit_cast(u16x2, v); }
+static __device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
+struct Ordered2 { u16x2 lo, hi, dd; }; // min, max and difference of the entries' two levels (.x: first entry, .y: second)
+static __device__ __forceinline__ Ordered2 order2(u16x2 a, u16x2 b)
+{
+    Ordered2 p;
+    p.lo = __builtin_elementwise_min(a, b);
+    p.hi = __builtin_elementwise_max(a, b);
+    p.dd = p.hi - p.lo;
+    return p;
+}
+static __device__ __forceinline__ u16x2 tri_index2(const Ordered2 &p) { return ((p.hi * (p.hi + (u16x2){1, 1})) >> (u16x2){1, 1}) + p.lo; }
+static __device__ __forceinline__ u16x2 cell_key2(const Ordered2 &p) { return (p.hi << (u16x2){8, 8}) | p.lo; }
+// byte `B` of x in the low half, byte `B` of y in the high half (one v_perm_b32)
+template <int B>
+static __device__ __forceinline__ u16x2 bytes2(unsigned x, unsigned y)
+{
+    return as_u16x2(__builtin_amdgcn_perm(y, x, 0x0c000c00u | (unsigned)B | ((unsigned)(4 + B) << 16)));
+}
+
+// pair_acc for both entries at one level; fmask = 0xFFFF in the half of an entry that owns a pair
+static __device__ __forceinline__ void pair_acc2(bool fx, bool fy, unsigned fmask, const Ordered2 &p, unsigned rkx, unsigned rky, LevelAcc &A,
+                                                 unsigned &idx_x, unsigned &idx_y)
+{
+    const u16x2 d = as_u16x2(as_u32(p.dd) & fmask); // the sums over s = a + b come out of the sum histogram when it is folded
+    A.D1 = __builtin_amdgcn_udot2(d, (u16x2){1, 1}, A.D1, false);
+    A.D2 = __builtin_amdgcn_udot2(d, d, A.D2, false);
+    const u16x2 d2 = d * d;                                             // <= 253^2 = 64 009
+    A.idm += fx ? __builtin_amdgcn_rcpf(1.0f + (float)d2.x) : 0.0f;     // 1/(1+d^2), 1 ulp; first entry first, as pair_acc
+    A.idm += fy ? __builtin_amdgcn_rcpf(1.0f + (float)d2.y) : 0.0f;
+    const bool dgx = p.dd.x == 0, dgy = p.dd.y == 0;
+    A.asmn += fx ? (dgx ? 4u : 2u) * (2u * rkx + 1u) : 0u;
+    A.asmn += fy ? (dgy ? 4u : 2u) * (2u * rky + 1u) : 0u;
+    idx_x = fx ? (dgx ? (unsigned)GL_RANKS : 0u) + rkx : 0u;
+    idx_y = fy ? (dgy ? (unsigned)GL_RANKS : 0u) + rky : 0u;
+}
+
 static __device__ __forceinline__ unsigned dense_rank_if(unsigned *tab, unsigned idx, bool fwd)
 {
     const unsigned sh = (idx & 1u) * 16u;
@@ -513,32 +555,35 @@ __global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048
                     for (int l = 0; l < 3; ++l) ev[u][l] = rank_tab[pend[u][l]];
                 const Located X = locate(e, true, ps, dy, dx, s_q, s_rows1, s_rowstart);
                 const Located Y = locate(e + 64, e + 64 < K, ps, dy, dx, s_q, s_rows1, s_rowstart);
-                const unsigned xa2 = (X.qa >> 8) & 127u, xb2 = (X.qb >> 8) & 127u, ya2 = (Y.qa >> 8) & 127u, yb2 = (Y.qb >> 8) & 127u;
-                const unsigned xa1 = xa2 >> 1, xb1 = xb2 >> 1, ya1 = ya2 >> 1, yb1 = yb2 >> 1;
-                const unsigned xa0 = xa2 >> 2, xb0 = xb2 >> 2, ya0 = ya2 >> 2, yb0 = yb2 >> 2;
+                // levels of both entries packed: .x = entry e, .y = entry e + 64 (level128 is byte 1 of a list word; 64 and 32 by shift)
+                const u16x2 a2 = bytes2<1>(X.qa, Y.qa), b2 = bytes2<1>(X.qb, Y.qb);
+                const u16x2 a1 = a2 >> (u16x2){1, 1}, b1 = b2 >> (u16x2){1, 1};
+                const u16x2 a0 = a2 >> (u16x2){2, 2}, b0 = b2 >> (u16x2){2, 2};
+                const Ordered2 P0 = order2(a0, b0), P1 = order2(a1, b1), P2 = order2(a2, b2);
+                const unsigned fmask = (X.fwd ? 0xFFFFu : 0u) | (Y.fwd ? 0xFFFF0000u : 0u);
                 s_memo[e] = (unsigned char)X.memo;
                 s_memo[e + 64] = (unsigned char)Y.memo;
-                atomicAdd(&s_hist[xa2], X.deg);
-                atomicAdd(&s_hist[ya2], Y.deg);
+                atomicAdd(&s_hist[a2.x], X.deg);
+                atomicAdd(&s_hist[a2.y], Y.deg);
                 np += (X.fwd ? 1u : 0u) + (Y.fwd ? 1u : 0u);
-                const unsigned rx0 = dense_rank_if(s_tab, tri_index(xa0, xb0), X.fwd);
-                const unsigned ry0 = dense_rank_if(s_tab, tri_index(ya0, yb0), Y.fwd);
-                const unsigned rx1 = dense_rank_if(s_tab + GL_D64_OFF, tri_index(xa1, xb1), X.fwd);
-                const unsigned ry1 = dense_rank_if(s_tab + GL_D64_OFF, tri_index(ya1, yb1), Y.fwd);
-                atomicAdd(&s_hist[128 + xa0 + xb0], X.fwd ? 1u : 0u);
-                atomicAdd(&s_hist[128 + ya0 + yb0], Y.fwd ? 1u : 0u);
-                atomicAdd(&s_hist[192 + xa1 + xb1], X.fwd ? 1u : 0u);
-                atomicAdd(&s_hist[192 + ya1 + yb1], Y.fwd ? 1u : 0u);
-                atomicAdd(&s_hist[320 + xa2 + xb2], X.fwd ? 1u : 0u);
-                atomicAdd(&s_hist[320 + ya2 + yb2], Y.fwd ? 1u : 0u);
+                const u16x2 t0 = tri_index2(P0), t1 = tri_index2(P1);
+                const unsigned rx0 = dense_rank_if(s_tab, t0.x, X.fwd);
+                const unsigned ry0 = dense_rank_if(s_tab, t0.y, Y.fwd);
+                const unsigned rx1 = dense_rank_if(s_tab + GL_D64_OFF, t1.x, X.fwd);
+                const unsigned ry1 = dense_rank_if(s_tab + GL_D64_OFF, t1.y, Y.fwd);
+                const u16x2 s0 = a0 + b0, s1 = a1 + b1, s2 = a2 + b2;
+                atomicAdd(&s_hist[128 + s0.x], X.fwd ? 1u : 0u);
+                atomicAdd(&s_hist[128 + s0.y], Y.fwd ? 1u : 0u);
+                atomicAdd(&s_hist[192 + s1.x], X.fwd ? 1u : 0u);
+                atomicAdd(&s_hist[192 + s1.y], Y.fwd ? 1u : 0u);
+                atomicAdd(&s_hist[320 + s2.x], X.fwd ? 1u : 0u);
+                atomicAdd(&s_hist[320 + s2.y], Y.fwd ? 1u : 0u);
                 unsigned rx2, ry2;
-                hash_rank2<SLOTS>(s_tab + GL_H128_OFF, s_dummy + (lane & 7), cell_key(xa2, xb2), X.fwd, cell_key(ya2, yb2), Y.fwd, rx2, ry2);
-                pend[0][0] = pair_acc(X.fwd, xa0, xb0, rx0, A0);
-                pend[1][0] = pair_acc(Y.fwd, ya0, yb0, ry0, A0);
-                pend[0][1] = pair_acc(X.fwd, xa1, xb1, rx1, A1);
-                pend[1][1] = pair_acc(Y.fwd, ya1, yb1, ry1, A1);
-                pend[0][2] = pair_acc(X.fwd, xa2, xb2, rx2, A2);
-                pend[1][2] = pair_acc(Y.fwd, ya2, yb2, ry2, A2);
+                const u16x2 k2 = cell_key2(P2);
+                hash_rank2<SLOTS>(s_tab + GL_H128_OFF, s_dummy + (lane & 7), k2.x, X.fwd, k2.y, Y.fwd, rx2, ry2);
+                pair_acc2(X.fwd, Y.fwd, fmask, P0, rx0, ry0, A0, pend[0][0], pend[1][0]);
+                pair_acc2(X.fwd, Y.fwd, fmask, P1, rx1, ry1, A1, pend[0][1], pend[1][1]);
+                pair_acc2(X.fwd, Y.fwd, fmask, P2, rx2, ry2, A2, pend[0][2], pend[1][2]);
                 A0.ents += ev[0][0] + ev[1][0]; A1.ents += ev[0][1] + ev[1][1]; A2.ents += ev[0][2] + ev[1][2];
             }
             A0.ents += rank_tab[pend[0][0]] + rank_tab[pend[1][0]];
@@ -612,15 +657,18 @@ __global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048
                 const double ev30 = rank_tab[pend3[0]], ev31 = rank_tab[pend3[1]];
                 const Located X = relocate(e, true, s_q, s_memo);
                 const Located Y = relocate(e + 64, e + 64 < K, s_q, s_memo);
-                const unsigned xa = X.qa & 255u, xb = X.qb & 255u, ya = Y.qa & 255u, yb = Y.qb & 255u;
-                atomicAdd(&s_hist[xa], X.deg);
-                atomicAdd(&s_hist[ya], Y.deg);
-                atomicAdd(&s_hist[256 + xa + xb], X.fwd ? 1u : 0u);
-                atomicAdd(&s_hist[256 + ya + yb], Y.fwd ? 1u : 0u);
+                const u16x2 a3 = bytes2<0>(X.qa, Y.qa), b3 = bytes2<0>(X.qb, Y.qb); // level254 is byte 0 of a list word
+                const Ordered2 P3 = order2(a3, b3);
+                const unsigned fmask = (X.fwd ? 0xFFFFu : 0u) | (Y.fwd ? 0xFFFF0000u : 0u);
+                atomicAdd(&s_hist[a3.x], X.deg);
+                atomicAdd(&s_hist[a3.y], Y.deg);
+                const u16x2 s3 = a3 + b3;
+                atomicAdd(&s_hist[256 + s3.x], X.fwd ? 1u : 0u);
+                atomicAdd(&s_hist[256 + s3.y], Y.fwd ? 1u : 0u);
                 unsigned rx, ry;
-                hash_rank2<TAB_WORDS>(s_tab, s_dummy + (lane & 7), cell_key(xa, xb), X.fwd, cell_key(ya, yb), Y.fwd, rx, ry);
-                pend3[0] = pair_acc(X.fwd, xa, xb, rx, A3);
-                pend3[1] = pair_acc(Y.fwd, ya, yb, ry, A3);
+                const u16x2 k3 = cell_key2(P3);
+                hash_rank2<TAB_WORDS>(s_tab, s_dummy + (lane & 7), k3.x, X.fwd, k3.y, Y.fwd, rx, ry);
+                pair_acc2(X.fwd, Y.fwd, fmask, P3, rx, ry, A3, pend3[0], pend3[1]);
                 A3.ents += ev30 + ev31;
             }
             A3.ents += rank_tab[pend3[0]] + rank_tab[pend3[1]];
