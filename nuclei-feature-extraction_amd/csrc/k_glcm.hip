@@ -23,7 +23,8 @@
 //     resident; the look-up for a pair is issued one loop iteration after its rank is known), so the
 //     multiplicities are never read back and no cell needs an owner;
 //   * L=32 and L=64 use dense triangular tables of packed 16-bit counters (5 KB); L=128 and L=254 use
-//     open-addressing HASH tables sized 2x the pair capacity (4 KB for masks up to 512 pixels) instead
+//     open-addressing HASH tables -- 3/4 slot per mask pixel of the class's capacity for the typical texture, with a
+//     hand-over to the next class for the nucleus that fills it (template parameter FULL) -- instead
 //     of 16.5 / 64.8 KB dense ones, keyed by hi << 8 | lo and filled insert-first (a new cell costs one LDS
 //     round trip): a wave's whole state is 16 KB, ten nuclei in flight per CU.  Tables are reset by sweeping
 //     them with 16-byte stores;
@@ -236,7 +237,7 @@ static __device__ __forceinline__ void probe_step(unsigned *tab, unsigned *dummy
 
 template <int SLOTS>
 static __device__ __forceinline__ void hash_rank2(unsigned *tab, unsigned *dummy, unsigned key0, bool act0, unsigned key1, bool act1,
-                                                  unsigned &rk0, unsigned &rk1)
+                                                  unsigned &rk0, unsigned &rk1, bool &full)
 {
     static_assert(SLOTS > 0 && SLOTS <= 65536, "table size");
     // HIP's __umul24 returns int: shift the product as unsigned, or half of the keys start at a negative slot
@@ -268,11 +269,13 @@ static __device__ __forceinline__ void hash_rank2(unsigned *tab, unsigned *dummy
         const bool both = act0 && act1;
         int rounds = 0; // a full sweep of the table always ends a search; the bound only guards against a corrupted table
         while (act && ++rounds <= SLOTS) probe_step<SLOTS>(tab, dummy, key, h, act, rk);
+        full = full || act; // a whole sweep without a free slot or the key: the table is full (typical-size tables, see k_glcm)
         // (`rk` stays 0 for a search that ended by claiming an empty slot)
         if (second) rk1 = (act1 ? rk : rk1); else rk0 = (act0 ? rk : rk0);
         if (__any(both)) { // both searches of a lane were unsettled: now its second one
             act = both; key = key1; h = h1; rk = 0u; rounds = 0;
             while (act && ++rounds <= SLOTS) probe_step<SLOTS>(tab, dummy, key, h, act, rk);
+            full = full || act;
             if (both) rk1 = rk;
         }
     }
@@ -389,15 +392,23 @@ static __device__ void glcm_features(const double (&a)[GL_NACC], const GlcmLuts 
 // ---- the kernel -------------------------------------------------------------------------------------------
 // QCAP: size class; serves the nuclei of its class list (K <= QCAP mask pixels).
 // NPRE: 16-byte pieces of a u8 patch per lane (3 ps^2 / 1024 rounded up: 3, 7 or 12 for ps <= 32, 48, 64)
-template <typename T, int QCAP, int NPRE>
-__global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048 ? 2 : 1))) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int *__restrict__ cursor, int ps,
+// FULL: the class's hash table holds a cell per list entry at 8/11 load, whatever the texture (the top class of a patch size, and
+//       a small call's single launch).  Otherwise the table is sized for the TYPICAL nucleus -- 3/4 slot per entry: on tissue-like
+//       textures a third to a half of the pairs open a new cell -- which is one more wave per CU in every class; a nucleus whose
+//       cells do not fit (white noise) is abandoned at the end of the pass that filled the table and handed to the next class,
+//       whose table holds a cell for every pair it can have (3/4 of a capacity at least 4/3 as large).
+template <typename T, int QCAP, int NPRE, bool FULL>
+__global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3 : (QCAP <= 2048 ? 2 : 1))) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int *__restrict__ cursor,
+                                             int *__restrict__ next_list, int *__restrict__ next_count, int ps,
                                              const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
                                              const GlcmLuts *__restrict__ lut, double *__restrict__ slots, float *__restrict__ out, int F,
                                              int col0, int64_t *__restrict__ dbg)
 {
-    // hash slots per list entry: 11/8 -- the LDS saved against 2 buys another wave per CU -- except in the first class of
-    // 64x64 patches, whose table memory doubles as the staging area of the 12 KB patch
-    constexpr int SLOTS = (QCAP == 512 && NPRE > 7) ? 2 * QCAP : 11 * QCAP / 8;
+    // never less than what lets the table memory double as the staging area of the NPRE KiB patch
+    constexpr int SLOTS_MIN = NPRE * 256 - GL_HIST_WORDS - GL_H128_OFF;
+    constexpr int SLOTS_WANT = FULL ? 11 * QCAP / 8 : 3 * QCAP / 4;
+    constexpr int SLOTS = SLOTS_WANT > SLOTS_MIN ? SLOTS_WANT : SLOTS_MIN;
+    static_assert(FULL || GL_H128_OFF + SLOTS >= QCAP, "the level-254 pass hashes into the whole table memory: a cell per pair fits");
     constexpr int TAB_WORDS = GL_H128_OFF + SLOTS;
     __shared__ __attribute__((aligned(16))) unsigned s_mem[TAB_WORDS + GL_HIST_WORDS]; // tables | histograms
     __shared__ unsigned s_q[QCAP + 1];         // list entry: r << 24 | c << 16 | level128 << 8 | level254 (levels 64 and 32
@@ -533,6 +544,7 @@ __global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048
         wave_lds_fence();
         sweep(s_hist, GL_HIST_WORDS, 0u, lane);
         if (lane < 8) s_dummy[lane] = GL_DUMMY;
+        bool abandoned = false;
 #pragma unroll 1
         for (int oi = 0; oi < 4; ++oi) {
             const int dy = kGlcmOffsets[oi][0], dx = kGlcmOffsets[oi][1];
@@ -546,6 +558,7 @@ __global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048
             LevelAcc A0 = {0, 0, 0, 0, 0, 0.0f, 0.0}, A1 = A0, A2 = A0, A3 = A0;
             unsigned np = 0;
             unsigned pend[2][3] = {{0u, 0u, 0u}, {0u, 0u, 0u}}; // rank-table indices of the previous iteration (entry 0 holds 0.0)
+            bool table_full = false;
 #pragma unroll 1
             for (int e = lane; e < K; e += 128) {
                 double ev[2][3];
@@ -580,7 +593,7 @@ __global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048
                 atomicAdd(&s_hist[320 + s2.y], Y.fwd ? 1u : 0u);
                 unsigned rx2, ry2;
                 const u16x2 k2 = cell_key2(P2);
-                hash_rank2<SLOTS>(s_tab + GL_H128_OFF, s_dummy + (lane & 7), k2.x, X.fwd, k2.y, Y.fwd, rx2, ry2);
+                hash_rank2<SLOTS>(s_tab + GL_H128_OFF, s_dummy + (lane & 7), k2.x, X.fwd, k2.y, Y.fwd, rx2, ry2, table_full);
                 pair_acc2(X.fwd, Y.fwd, fmask, P0, rx0, ry0, A0, pend[0][0], pend[1][0]);
                 pair_acc2(X.fwd, Y.fwd, fmask, P1, rx1, ry1, A1, pend[0][1], pend[1][1]);
                 pair_acc2(X.fwd, Y.fwd, fmask, P2, rx2, ry2, A2, pend[0][2], pend[1][2]);
@@ -590,6 +603,7 @@ __global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048
             A1.ents += rank_tab[pend[0][1]] + rank_tab[pend[1][1]];
             A2.ents += rank_tab[pend[0][2]] + rank_tab[pend[1][2]];
             wave_lds_fence();
+            if (!FULL && __any(table_full)) { abandoned = true; break; } // wave-uniform
             unsigned np_w;
             {
                 // fold: read and clear the histogram words, request every x ln x together, and only then do the
@@ -652,6 +666,7 @@ __global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048
             // ================= pass B: level 254 ===================================================================
             // histogram words: hx 0..253 | hs 256..762
             unsigned pend3[2] = {0u, 0u};
+            bool table_full_b = false; // (cannot happen: TAB_WORDS >= QCAP, asserted above)
 #pragma unroll 1
             for (int e = lane; e < K; e += 128) {
                 const double ev30 = rank_tab[pend3[0]], ev31 = rank_tab[pend3[1]];
@@ -667,7 +682,7 @@ __global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048
                 atomicAdd(&s_hist[256 + s3.y], Y.fwd ? 1u : 0u);
                 unsigned rx, ry;
                 const u16x2 k3 = cell_key2(P3);
-                hash_rank2<TAB_WORDS>(s_tab, s_dummy + (lane & 7), k3.x, X.fwd, k3.y, Y.fwd, rx, ry);
+                hash_rank2<TAB_WORDS>(s_tab, s_dummy + (lane & 7), k3.x, X.fwd, k3.y, Y.fwd, rx, ry, table_full_b);
                 pair_acc2(X.fwd, Y.fwd, fmask, P3, rx, ry, A3, pend3[0], pend3[1]);
                 A3.ents += ev30 + ev31;
             }
@@ -705,6 +720,10 @@ __global__ __launch_bounds__(64, ((QCAP <= 768 && NPRE <= 7) ? 3 : (QCAP <= 2048
             wave_lds_fence();
             // lane-0 stores straight to memory would touch five partial lines per combination
             if (lane < 4 * GL_NACC) slot[oi * 4 * GL_NACC + lane] = s_sums[lane];
+        }
+        if (abandoned) { // more distinct level-128 cells than the typical-size table holds: the next class takes the nucleus
+            if (lane == 0) next_list[atomicAdd(next_count, 1)] = (int)i;
+            i_done = -1; // nothing of it is evaluated here
         }
         j = jn;
     }
@@ -825,7 +844,7 @@ __global__ __launch_bounds__(256) void k_glcm_wide(int64_t n, int ps, const T *_
 #ifndef NFX_GL_ROUNDS
 #define NFX_GL_ROUNDS 2
 #endif
-static constexpr int GL_MAX_GRID = 256 * 11 * NFX_GL_ROUNDS; // resident single-wave workgroups of the largest launch = parking slots
+static constexpr int GL_MAX_GRID = 256 * 12 * NFX_GL_ROUNDS; // resident single-wave workgroups of the largest launch = parking slots
 static size_t glcm_slots_bytes() { return sizeof(double) * 16 * GL_NACC * (size_t)GL_MAX_GRID; }
 static constexpr int GW_GRID = 256; // workgroups (and dense slabs) of the wide kernel
 size_t glcm_scratch_bytes(const Job &job)
@@ -859,33 +878,43 @@ hipError_t prepare_glcm(nfx_ctx *ctx)
 // One launch per size class whose capacity the patch can reach.  The grid is four rounds of the workgroups a CU really
 // holds (asked of the runtime once per instantiation: LDS allocation granularity and register budget included); blocks
 // beyond a list's length exit at once.
-template <typename T, int QCAP, int NPRE>
+template <typename T, int QCAP, int NPRE, bool FULL>
 static void launch_class(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *slots, const int *lists, const int *counts, int cls, int col0)
 {
     static int wgs_per_cu = 0; // same answer for every context: one device type per process
     if (wgs_per_cu == 0) {
         int b = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_glcm<T, QCAP, NPRE>, 64, 0) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 1; }
-        wgs_per_cu = b > 11 ? 11 : b;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_glcm<T, QCAP, NPRE, FULL>, 64, 0) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 1; }
+        wgs_per_cu = b > 12 ? 12 : b;
     }
     const int64_t m = 256ll * wgs_per_cu * NFX_GL_ROUNDS;
-    static_assert(256 * 11 * NFX_GL_ROUNDS <= GL_MAX_GRID, "every launch's waves have a parking slot");
+    static_assert(256 * 12 * NFX_GL_ROUNDS <= GL_MAX_GRID, "every launch's waves have a parking slot");
     const unsigned grid = (unsigned)(job.n < m ? job.n : m);
-    hipLaunchKernelGGL((k_glcm<T, QCAP, NPRE>), dim3(grid), dim3(64), 0, ctx->stream, lists + (int64_t)cls * job.n, counts + cls, const_cast<int *>(counts) + GL_CLASSES + cls, job.ps,
+    // a nucleus that does not fit a typical-size table moves on to the next class's list (that launch has not started yet)
+    int *next_list = FULL ? nullptr : const_cast<int *>(lists) + (int64_t)(cls + 1) * job.n;
+    int *next_count = FULL ? nullptr : const_cast<int *>(counts) + cls + 1;
+    hipLaunchKernelGGL((k_glcm<T, QCAP, NPRE, FULL>), dim3(grid), dim3(64), 0, ctx->stream, lists + (int64_t)cls * job.n, counts + cls, const_cast<int *>(counts) + GL_CLASSES + cls,
+                       next_list, next_count, job.ps,
                        reinterpret_cast<const T *>(job.patches), job.mask_rows, lut, slots, job.out, job.F, col0, job.dbg_glcm);
 }
 
 template <typename T, int NPRE>
 static void launch_classes(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *slots, const int *lists, const int *counts, int col0, int only)
 {
-    const int P = job.ps * job.ps;
-    auto want = [&](int cls, int reach) { return P > reach && (only < 0 || only == cls); };
-    if (want(0, 0)) launch_class<T, 512, NPRE>(ctx, job, lut, slots, lists, counts, 0, col0);
-    if (want(1, 512)) launch_class<T, 768, NPRE>(ctx, job, lut, slots, lists, counts, 1, col0);
-    if (want(2, 768)) launch_class<T, 1024, NPRE>(ctx, job, lut, slots, lists, counts, 2, col0);
-    if (want(3, 1024)) launch_class<T, 1536, NPRE>(ctx, job, lut, slots, lists, counts, 3, col0);
-    if (want(4, 1536)) launch_class<T, 2048, NPRE>(ctx, job, lut, slots, lists, counts, 4, col0);
-    if (want(5, 2048)) launch_class<T, 4096, NPRE>(ctx, job, lut, slots, lists, counts, 5, col0);
+    const int top = glcm_class(job.ps * job.ps); // the class every mask of this patch size fits: its tables are full-size
+    auto run = [&](int cls) { return cls <= top && (only < 0 || only == cls); };
+#define NFX_GL_CLASS(CLS, QCAP)                                                                                         \
+    if (run(CLS)) {                                                                                                     \
+        if (CLS == top) launch_class<T, QCAP, NPRE, true>(ctx, job, lut, slots, lists, counts, CLS, col0);              \
+        else launch_class<T, QCAP, NPRE, false>(ctx, job, lut, slots, lists, counts, CLS, col0);                        \
+    }
+    NFX_GL_CLASS(0, 512)
+    NFX_GL_CLASS(1, 768)
+    NFX_GL_CLASS(2, 1024)
+    NFX_GL_CLASS(3, 1536)
+    NFX_GL_CLASS(4, 2048)
+    NFX_GL_CLASS(5, 4096)
+#undef NFX_GL_CLASS
 }
 
 hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)

@@ -114,3 +114,22 @@ def test_glcm_list_hand_out_shapes(nfx, ctx, ps, n):
     par.assert_rows_close(got, want, par.column_scales(nfx, [2], ps), what=f"glcm ps={ps} n={n}")
     again, _ = ctx.extract([2], off, xy, pu8, ps, batch_size=100)
     assert np.array_equal(got, again, equal_nan=True)   # dynamic hand-out, same bits
+
+
+@pytest.mark.parametrize("ps,n", [(48, 2500), (64, 1500)])
+def test_glcm_noise_textures_move_on_to_the_next_size_class(nfx, ctx, ps, n):
+    """Every size class but the top one of a patch size keeps a hash table for the TYPICAL nucleus (3/4 slot per mask pixel).
+    White noise opens a new level-128 cell with nearly every pair, so the larger nuclei of each class fill that table: the kernel
+    abandons them and appends them to the next class's list (k_glcm.hip, FULL).  More nuclei than the single-launch path
+    takes (768), a third of them noise, the rest tissue-like; rows against the oracle, and identical between runs although
+    which wave meets which nucleus -- and the order of the handed-over nuclei -- differs."""
+    off, xy, pu8 = par.make_inputs(500 + ps, n, ps)
+    rng = np.random.default_rng(ps)
+    noisy = np.arange(n) % 3 == 0
+    pu8 = pu8.copy()
+    pu8[noisy] = rng.integers(0, 256, (int(noisy.sum()), 3, ps, ps), dtype=np.uint8)
+    want, _ = orc.extract([2], off, xy, pu8, ps, batch_size=100, threads=16)
+    got, _ = ctx.extract([2], off, xy, pu8, ps, batch_size=100)
+    par.assert_rows_close(got, want, par.column_scales(nfx, [2], ps), what=f"glcm noise ps={ps}")
+    again, _ = ctx.extract([2], off, xy, pu8, ps, batch_size=100)
+    assert np.array_equal(got, again, equal_nan=True)
