@@ -53,7 +53,13 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles, 2.4 GHz
-VALU_ISSUE_PEAK = 256 * 4 * 0.5 * 2.4e9   # wave-instructions per second
+VALU_ISSUE_PEAK = 256 * 4 * 0.5 * 2.4e9   # wave-instructions per second (nominal)
+# what back-to-back independent plain FMAs really reach on this chip (scripts/valu_probe.hip, DESIGN.md §6: 6.7e11 of the nominal
+# 1.23e12, i.e. ~4 cycles per wave64 instruction and SIMD): the second basis `issue.frac_of_probe` is quoted against
+VALU_ISSUE_PROBE = 6.7e11
+LDS_CU_CYCLES_PEAK = 256 * 2.4e9          # CU-cycles per second: one LDS pipe per CU
+# which unit limits a kernel when its counters are at hand; everything else on this path is VALU-issue-bound
+LDS_BOUND_KERNELS = ("k_glcm",)
 
 
 def csrc_stamp():
@@ -69,20 +75,20 @@ def csrc_stamp():
 
 
 def committed_counters(workload, kernel):
-    """(traffic bytes per launch, VALU wave-instructions per nucleus, source) from profiles/pmc_current.json when it
-    was taken on this build of csrc/ for this workload and kernel, else (None, None, why)."""
+    """(counter summary of the workload's dominant kernel, source) from profiles/pmc_current.json when it was taken on this build
+    of csrc/ for this workload and kernel, else (None, why)."""
     path = os.path.join(ROOT, "profiles", "pmc_current.json")
     try:
         with open(path) as fh:
             doc = json.load(fh)
     except (OSError, ValueError):
-        return None, None, "no profiles/pmc_current.json"
+        return None, "no profiles/pmc_current.json"
     if doc.get("csrc_stamp") != csrc_stamp():
-        return None, None, f"profiles/pmc_current.json was taken on csrc {doc.get('csrc_stamp')}, this is {csrc_stamp()}"
+        return None, f"profiles/pmc_current.json was taken on csrc {doc.get('csrc_stamp')}, this is {csrc_stamp()}"
     t = doc.get(workload)
     if not t or t.get("kernel") != kernel:
-        return None, None, f"profiles/pmc_current.json holds no counters for {workload}/{kernel}"
-    return t.get("traffic_bytes_per_launch"), t.get("valu_insts_per_nucleus"), doc.get("source", "profiles/pmc_current.json")
+        return None, f"profiles/pmc_current.json holds no counters for {workload}/{kernel}"
+    return t, doc.get("source", "profiles/pmc_current.json")
 
 
 def parse_args():
@@ -108,6 +114,13 @@ def parse_args():
                     help="nuclei per GPU of the full-feature-set (configs[4] shard) measurement; default: 1.25M when the headline runs at "
                          "full size, else skipped")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--gather", default="rank0", choices=["rank0", "none"],
+                    help="N>1: rank0 (default) = every rank's rows are gathered to rank 0 inside the timed region (the reference's vstack, "
+                         "main.rs:96-108); none = rows stay on the rank that computed them (compute-only scaling).  With rank0 the line also "
+                         "carries `also.weak_scaling_compute_only`, measured in the same run")
+    ap.add_argument("--ipc-legacy", default="env", choices=["env", "0", "1"],
+                    help="N>1: HSA_ENABLE_IPC_MODE_LEGACY for the ranks (RCCL peer access across processes).  env (default) = whatever the "
+                         "environment holds, 0 if it holds nothing (dmabuf IPC: what this pool's host driver supports); recorded in the line")
     return ap.parse_args()
 
 
@@ -170,32 +183,84 @@ def timed(torch, dist, use_dist, ctx, steps, warmup, step, fence):
 
 
 def roofline_of(timing, steps, res, workload, full_size):
+    """The dominant kernel against the unit that limits it.  `hbm` (always present) is the figure the metric asks for: algorithmic
+    bytes per launch / average launch time / 8 TB/s.  When the committed counter summary was taken on this very csrc/, the top-level
+    bound / achieved / peak / frac describe the unit that really saturates first -- the LDS pipe for k_glcm, VALU issue for the
+    rest -- else they fall back to the HBM figure and say so."""
     dom_name, dom_t = max(timing.items(), key=lambda kv: kv[1]["total_ms"])
     dom_avg_ms = dom_t["total_ms"] / max(1, dom_t["launches"])
     launches_per_step = max(1, dom_t["launches"] // max(1, steps))
     nuclei_per_launch = res.n / launches_per_step    # a kernel launched once per step processes the rank's nuclei
-    achieved = res.bytes_per_nucleus * nuclei_per_launch / (dom_avg_ms * 1e-3) / 1e9
-    traffic, valu, src = (None, None, "not the full-size workload") if not full_size else committed_counters(workload, dom_name)
-    issue = None
-    if valu is not None:
-        rate = valu * nuclei_per_launch / (dom_avg_ms * 1e-3)
-        issue = {"unit": "valu", "insts_per_nucleus": valu, "achieved": round(rate / 1e9, 2), "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
-                 "rate_unit": "G wave-instructions/s", "frac": round(rate / VALU_ISSUE_PEAK, 4)}
-    return {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "issue": issue, "counters_source": src,
-            "limiter": "VALU issue + LDS atomics (DESIGN.md §3): no kernel of this path is HBM-bound at these byte counts; the HBM "
-                       "fraction is reported because the metric asks for it",
-            "algorithmic_bytes_per_nucleus": round(res.bytes_per_nucleus, 1), "avg_launch_ms": round(dom_avg_ms, 4),
+    sec = dom_avg_ms * 1e-3
+    achieved = res.bytes_per_nucleus * nuclei_per_launch / sec / 1e9
+    hbm = {"achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+           "algorithmic_bytes_per_nucleus": round(res.bytes_per_nucleus, 1)}
+    ctr, src = (None, "not the full-size workload") if not full_size else committed_counters(workload, dom_name)
+    issue = lds = None
+    traffic = None
+    if ctr is not None:
+        traffic = ctr.get("traffic_bytes_per_launch")
+        valu = ctr.get("valu_insts_per_nucleus")
+        if valu is not None:
+            rate = valu * nuclei_per_launch / sec
+            issue = {"unit": "valu", "insts_per_nucleus": valu, "achieved": round(rate / 1e9, 2), "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
+                     "rate_unit": "G wave-instructions/s", "frac": round(rate / VALU_ISSUE_PEAK, 4),
+                     "basis": "nominal: 256 CUs x 4 SIMDs x one wave64 instruction per 2 cycles x 2.4 GHz",
+                     "frac_of_probe": round(rate / VALU_ISSUE_PROBE, 4),
+                     "probe_basis": "6.7e11 wave-instructions/s: what scripts/valu_probe.hip reaches with back-to-back independent plain FMAs "
+                                    "(~4 cycles per wave64 instruction and SIMD)"}
+        lds_cyc = ctr.get("lds_idx_active_cycles_per_nucleus")
+        if lds_cyc is not None:
+            busy = lds_cyc * nuclei_per_launch / sec
+            lds = {"unit": "lds", "active_cycles_per_nucleus": lds_cyc, "achieved": round(busy / 1e9, 2), "peak": round(LDS_CU_CYCLES_PEAK / 1e9, 1),
+                   "rate_unit": "G CU-cycles/s with the LDS pipe active (SQ_LDS_IDX_ACTIVE)", "frac": round(busy / LDS_CU_CYCLES_PEAK, 4),
+                   "same_address_conflict_share": ctr.get("lds_addr_conflict_over_idx_active"),
+                   "bank_conflict_share": ctr.get("lds_bank_conflict_over_idx_active")}
+    top = dict(hbm, bound="hbm")
+    if dom_name in LDS_BOUND_KERNELS and lds is not None:
+        top = {"bound": "lds", "achieved": lds["achieved"], "peak": lds["peak"], "unit": lds["rate_unit"], "frac": lds["frac"]}
+    elif issue is not None:
+        top = {"bound": "valu", "achieved": issue["achieved"], "peak": issue["peak"], "unit": issue["rate_unit"], "frac": issue["frac"]}
+    note = ("VALU issue + LDS atomics (DESIGN.md §3): no kernel of this path is HBM-bound at these byte counts; `hbm` is reported because "
+            "the metric asks for it")
+    if top["bound"] == "hbm":
+        note += "; bound says hbm only because no counter summary of this csrc/ is committed (counters_source)"
+    return {"bound": top["bound"], "kernel": dom_name, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
+            "frac": top["frac"], "traffic": traffic, "hbm": hbm, "issue": issue, "lds": lds, "counters_source": src, "limiter": note,
+            "avg_launch_ms": round(dom_avg_ms, 4),
             "kernels_ms_per_step": {k: round(v["total_ms"] / steps, 4) for k, v in timing.items() if v["launches"]}}
+
+
+def aten_twin_baseline(args, ps, n):
+    """BASELINE.md §3's "restatement of the libtorch-CPU path" for the geometry workload: tests/_twin_baseline.py as a child
+    process, run to completion BEFORE this process touches a GPU (its workers are forked CPU processes)."""
+    import subprocess
+    cores = int(os.environ.get("NFX_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "_twin_baseline.py"), "--ps", str(ps), "--nuclei", str(n), "--batch", str(args.batch_size),
+           "--procs", str(cores), "--seconds", str(min(args.cpu_seconds, 12.0))]
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        return json.loads(line[-1]) if out.returncode == 0 and line else {"error": (out.stderr or "no output")[-300:]}
+    except Exception as e:   # a reported baseline, never a reason for the bench to fail
+        return {"error": repr(e)[:300]}
 
 
 def main():
     args = parse_args()
     world_env = os.environ.get("WORLD_SIZE")
+    if args.ipc_legacy != "env":
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = args.ipc_legacy     # explicit: recorded in the line as asked
+    elif args.gpus > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC, the only mode this pool's host driver supports
     if args.gpus > 1 and world_env is None:
         # bare `python bench.py --gpus N`: start the N ranks as children BEFORE this process touches a GPU
         D = importlib.import_module(PKG + ".distributed")
         sys.exit(D.launch_ranks(os.path.abspath(__file__), args.gpus, sys.argv[1:]))
+    # the libtorch-shaped CPU data point of the geometry workload (BASELINE.md §3): a child process, finished before any GPU call here
+    cpu_torch = None
+    if args.workload == "config2" and int(world_env or "1") == 1 and not args.no_cpu_baseline and not args.sets:
+        cpu_torch = aten_twin_baseline(args, WORKLOADS["config2"][1], args.nuclei or WORKLOADS["config2"][0])
 
     import torch
     import torch.distributed as dist
@@ -283,7 +348,7 @@ def main():
         def step():
             pipeline.extract_streamed(ctx, sets, res.off, res.xy, h_patches, ps, batch_size=B, chunk_nuclei=args.chunk, out=d_out,
                                       host_rows=h_rows, want_centroids=False)
-    elif use_dist:
+    elif use_dist and args.gather == "rank0":
         sx = D.ShardedExtraction(world * n_local, F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if rehearsal else None)
         assert (sx.i0, sx.i1) == (rank * n_local, (rank + 1) * n_local)
 
@@ -303,6 +368,17 @@ def main():
         if rank == 0:
             also["gather_checksums_match"] = bool(all(ok))
         d_out = sx.local_rows()
+
+    if sx is not None and not args.no_also:
+        # the same shards with the rows left where they were computed: if the incast into rank 0 (world-1 streams of n_local x F
+        # x 4 B per step over its xGMI links) does not hide behind compute, this figure says what the extraction alone scales to
+        el_c, _ = timed(torch, dist, True, ctx, args.steps, 1, lambda: res.extract(ctx, 0, n_local, d_out, B), fence)
+        if rank == 0:
+            also["weak_scaling_compute_only"] = {
+                "value": round(total_nuclei * args.steps / el_c, 1), "unit": "nuclei/s", "ms_per_step": round(el_c / args.steps * 1e3, 3),
+                "scaling": "weak", "what": "the headline's shards extracted with NO gather (rows stay on the rank that computed them): "
+                "compute-only scaling, beside the gathered headline measured in the same run",
+                "gather_cost_ms_per_step": round((elapsed - el_c) / args.steps * 1e3, 3)}
 
     # ---- CPU baseline: the oracle port on a bounded sample, rank 0 at N=1 only ------------------------------------------
     cpu = None
@@ -405,7 +481,10 @@ def main():
 
     if rank == 0:
         sharding = "single GPU"
-        if world > 1:
+        if world > 1 and (stream_mode or args.gather == "none"):
+            sharding = f"index-sharded x{world}, NO gather: rows stay on the rank that computed them" + (
+                " (in its pinned host memory)" if stream_mode else "") + (" -- REHEARSAL on fewer GPUs than ranks" if rehearsal else "")
+        elif world > 1:
             sharding = f"index-sharded x{world}, rows gathered to rank 0 " + ("(gloo through host memory: REHEARSAL on fewer GPUs than "
                                                                              "ranks, not a scaling measurement)" if rehearsal else "(RCCL)")
         line = {
@@ -417,9 +496,13 @@ def main():
                        "inputs": "packed u8 patches + polygons resident in HBM" if not stream_mode else
                                  f"patches streamed from pinned host memory every step in chunks of {args.chunk}, rows copied back to "
                                  "pinned host memory (PCIe-inclusive; NOT the headline metric)",
-                       "gen_seconds": round(gen_s, 1), "csrc_stamp": csrc_stamp()},
+                       "gen_seconds": round(gen_s, 1), "csrc_stamp": csrc_stamp(),
+                       "gather": ("none" if (stream_mode or args.gather == "none") else "rank0") if world > 1 else None,
+                       "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") if use_dist else None},
             "roofline": roofline, "cpu_baseline": cpu, "also": also or None,
         }
+        if cpu_torch is not None:
+            line["cpu_baseline_torch"] = cpu_torch
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

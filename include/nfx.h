@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define NFX_VERSION 200 /* 0.2.0 */
+#define NFX_VERSION 300 /* 0.3.0 */
 
 typedef struct nfx_ctx nfx_ctx;
 
@@ -110,7 +110,7 @@ const char *nfx_last_error(const nfx_ctx *ctx);
 /* hipStream_t the NFX_MEM_DEVICE calls are enqueued on (NULL = the default stream).  NFX_MEM_HOST calls are synchronous
    and run on a private non-blocking stream of the context, so contexts driven from different host threads (the reference's
    rayon workers, main.rs:146-151) overlap on the GPU; such a call first waits for the device calls still in flight on
-   this context, whose workspace it shares. */
+   this context (the device tables are shared; staging and scratch live in an arena of their own). */
 nfx_status nfx_ctx_set_stream(nfx_ctx *ctx, void *hip_stream);
 /* How nfx_extract_tile / nfx_gather_patches place the ps x ps window around a centroid.  The reference has two loaders:
      NFX_ADDR_IMAGE  load_image_dataset (png/jpg), utils.rs:159-191: box [trunc(c-ps/2), trunc(c+ps/2)) as i64, clipped
@@ -130,8 +130,18 @@ nfx_status nfx_ctx_synchronize(nfx_ctx *ctx);
    After a reservation NFX_MEM_DEVICE calls never allocate, free or synchronise: a call that does not fit fails with
    NFX_ERR_OUT_OF_MEMORY instead of growing the workspace.  WITHOUT a reservation the first device-memory call of a larger
    shape grows the workspace itself (hipStreamSynchronize + hipFree + hipMalloc) and builds missing tables with a synchronous
-   copy -- legal only outside stream capture; during a capture such a call fails with NFX_ERR_INVALID_ARGUMENT. */
+   copy -- legal only outside stream capture; during a capture such a call fails with NFX_ERR_INVALID_ARGUMENT.
+
+   Captured graphs and the workspace.  A HIP graph captured from a device-memory call holds addresses inside the workspace of
+   the device-memory calls.  That workspace moves in exactly one situation once a capture has been seen on the context: a
+   later nfx_ctx_reserve for a LARGER shape (it frees and reallocates; every graph captured before it must be captured again --
+   nfx_ctx_workspace_generation tells).  Nothing else moves it: NFX_MEM_HOST calls stage and compute in an arena of their own,
+   whatever their size, and build missing device tables (separate allocations) also on a reserved context; an unreserved
+   device-memory call that would outgrow the workspace after a capture fails with NFX_ERR_OUT_OF_MEMORY instead of growing. */
 nfx_status nfx_ctx_reserve(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t n_vertices, int ps, int batch_size);
+/* Number of times the workspace of the device-memory calls has been reallocated.  A graph captured while this read g is valid
+   for as long as it still reads g. */
+uint64_t nfx_ctx_workspace_generation(const nfx_ctx *ctx);
 
 /* Per-kernel device timing with HIP events on the context's stream (off by default).
    nfx_ctx_kernel_timing synchronises, then reports for kernel slot k: name, number of launches

@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "nfx_version", "nfx_feature_set_count", "nfx_feature_set_name", "nfx_feature_set_cli_name",
     "nfx_feature_set_num_columns", "nfx_feature_set_column_name", "nfx_parse_feature_sets", "nfx_centroid_key",
     "nfx_ctx_create", "nfx_ctx_destroy", "nfx_last_error", "nfx_ctx_set_stream", "nfx_ctx_synchronize",
-    "nfx_ctx_set_patch_addressing", "nfx_ctx_reserve", "nfx_feature_set_column_dtype",
+    "nfx_ctx_set_patch_addressing", "nfx_ctx_reserve", "nfx_ctx_workspace_generation", "nfx_feature_set_column_dtype",
     "nfx_polygon_features_f64", "nfx_debug_texture_counts",
     "nfx_ctx_enable_timing", "nfx_ctx_kernel_timing", "nfx_ctx_reset_timing",
     "nfx_preprocess_polygons", "nfx_rasterize_polygons", "nfx_compute_features_batched",
@@ -83,6 +83,8 @@ def lib() -> C.CDLL:
     L.nfx_extract_tile.argtypes = [vp, i32p, C.c_int, i64, i64, u32p, f32p, u8p, i64, i64, C.c_int, C.c_int, f32p, f32p, C.c_int]
     L.nfx_gather_patches.argtypes = [vp, i64, f32p, u8p, i64, i64, C.c_int, u8p, C.c_int]
     L.nfx_ctx_reserve.argtypes = [vp, i32p, C.c_int, i64, i64, C.c_int, C.c_int]
+    L.nfx_ctx_workspace_generation.argtypes = [vp]
+    L.nfx_ctx_workspace_generation.restype = C.c_uint64
     L.nfx_feature_set_column_dtype.argtypes = [C.c_int, C.c_int]
     L.nfx_polygon_features_f64.argtypes = [vp, i64, i64, u32p, f32p, vp, C.c_int]
     L.nfx_debug_texture_counts.argtypes = [vp, i64, i64, u32p, f32p, u8p, C.c_int, vp, vp, C.c_int]
@@ -222,6 +224,10 @@ class Context:
         such calls never allocate or synchronise (and fail instead of growing)."""
         sets_arr = (C.c_int * len(sets))(*sets)
         self._check(lib().nfx_ctx_reserve(self._h, sets_arr, len(sets), n, n_vertices, ps, batch_size))
+
+    def workspace_generation(self) -> int:
+        """nfx_ctx_workspace_generation: reallocations of the device-call workspace so far (a captured graph is valid while it is unchanged)."""
+        return int(lib().nfx_ctx_workspace_generation(self._h))
 
     def enable_timing(self, on: bool = True):
         self._check(lib().nfx_ctx_enable_timing(self._h, int(on)))

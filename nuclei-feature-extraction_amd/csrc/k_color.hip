@@ -470,7 +470,7 @@ size_t color_scratch_bytes(const Job &job)
 hipError_t prepare_color(nfx_ctx *ctx)
 {
     if (ctx->od_lut) return hipSuccess;
-    if (ctx->reserved || stream_capturing(ctx)) return hipErrorNotReady; // tables are built by nfx_ctx_reserve or before a capture
+    if (tables_locked(ctx)) return hipErrorNotReady; // device-memory calls on a reserved context and captures never allocate: nfx_ctx_reserve builds the tables
     float h[256];
     for (int u = 0; u < 256; ++u) {
         const float x = (float)u / 255.0f;

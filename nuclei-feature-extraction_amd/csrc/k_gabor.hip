@@ -765,7 +765,7 @@ static const GaborTables &gabor_tables()
 hipError_t prepare_gabor(nfx_ctx *ctx)
 {
     if (ctx->gabor_tab) return hipSuccess;
-    if (ctx->reserved || stream_capturing(ctx)) return hipErrorNotReady; // tables are built by nfx_ctx_reserve or before a capture
+    if (tables_locked(ctx)) return hipErrorNotReady; // device-memory calls on a reserved context and captures never allocate: nfx_ctx_reserve builds the tables
     const GaborTables &T = gabor_tables();
     if (T.n_groups < 1 || T.n_groups > GB_MAX_GROUPS || T.n_filters < 1 || T.n_filters > GB_MAX_FILTERS) return hipErrorInvalidValue;
     float *tab = nullptr;

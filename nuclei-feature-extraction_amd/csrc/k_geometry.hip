@@ -518,6 +518,22 @@ static __device__ __forceinline__ double cross3(const pt &o, const pt &a, const 
 }
 
 static constexpr int PG_MAXV = 64;                 // ring length served from LDS
+#ifndef NFX_PG_LPR
+#define NFX_PG_LPR 8 // lanes per ring of the group-parallel kernel = partial sums of every edge total (both kernels)
+#endif
+
+// the butterfly of group_total_f64 below, on one lane's array of partials
+static __device__ __forceinline__ double partial_tree(const double (&p)[NFX_PG_LPR])
+{
+    double q[NFX_PG_LPR];
+#pragma unroll
+    for (int j = 0; j < NFX_PG_LPR; ++j) q[j] = p[j];
+#pragma unroll
+    for (int w = 1; w < NFX_PG_LPR; w *= 2)
+#pragma unroll
+        for (int j = 0; j < NFX_PG_LPR; j += 2 * w) q[j] = q[j] + q[j + w];
+    return q[0];
+}
 
 size_t polygon_scratch_bytes(int64_t n, int64_t total_vertices)
 {
@@ -530,19 +546,28 @@ static __device__ __forceinline__ void polygon_one(VP v, int V, IDX *srt, IDX *h
 {
     auto P = [&](int k) { const float2 f = v[k]; return pt{(double)f.x, (double)f.y}; };
     const double PI = 3.14159265358979323846;
-    // shoelace + perimeter in ring order
-    double sh = 0.0, perim = 0.0;
+    // shoelace + perimeter.  SUMMATION ORDER (shared with the group-parallel k_polygon below, so that the same ring gives the same
+    // bits whichever kernel a call happens to take): edge k goes to partial k mod NFX_PG_LPR, every partial is summed in ring
+    // order, the partials are joined by the butterfly ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7)).
+    double sh_p[NFX_PG_LPR], pe_p[NFX_PG_LPR];
+#pragma unroll
+    for (int j = 0; j < NFX_PG_LPR; ++j) { sh_p[j] = 0.0; pe_p[j] = 0.0; }
     if (V > 0) {
-        pt a = P(0);
-        const pt first = a;
-        for (int k = 0; k < V; ++k) {
-            const pt b = (k + 1 == V) ? first : P(k + 1);
-            sh += a.x * b.y - b.x * a.y;
-            const double dx = b.x - a.x, dy = b.y - a.y;
-            perim += sqrt(dx * dx + dy * dy);
-            a = b;
+        const pt first = P(0);
+        for (int k0 = 0; k0 < V; k0 += NFX_PG_LPR) {
+#pragma unroll
+            for (int j = 0; j < NFX_PG_LPR; ++j) {
+                const int k = k0 + j;
+                if (k < V) {
+                    const pt a = P(k), b = (k + 1 == V) ? first : P(k + 1);
+                    sh_p[j] += a.x * b.y - b.x * a.y;
+                    const double dx = b.x - a.x, dy = b.y - a.y;
+                    pe_p[j] += sqrt(dx * dx + dy * dy);
+                }
+            }
         }
     }
+    const double sh = partial_tree(sh_p), perim = partial_tree(pe_p);
     const double area = fabs(sh) * 0.5;
     const double eq_perim = 2.0 * sqrt(PI * area);
     const double compacity = 4.0 * PI * area / (perim * perim);
@@ -617,18 +642,31 @@ static __device__ __forceinline__ void polygon_one(VP v, int V, IDX *srt, IDX *h
         hull[m++] = srt[k];
     }
     if (m > 1) --m;
-    double hsh = 0.0, hperim = 0.0;
-    if (m > 0) {
-        pt a = P(hull[0]);
-        const pt first = a;
-        for (int k = 0; k < m; ++k) {
-            const pt b = (k + 1 == m) ? first : P(hull[k + 1]);
-            hsh += a.x * b.y - b.x * a.y;
-            const double dx = b.x - a.x, dy = b.y - a.y;
-            hperim += sqrt(dx * dx + dy * dy);
-            a = b;
+    // hull area and perimeter in the same order as k_polygon: the hull is the lower chain (hull[0 .. nlow-1], nlow-1 edges) followed by
+    // the upper chain (its edges continue from hull[nlow-1] back to hull[0]); edge e of a CHAIN goes to partial e mod NFX_PG_LPR, lower
+    // chain first.
+    double hs_p[NFX_PG_LPR], hp_p[NFX_PG_LPR];
+#pragma unroll
+    for (int j = 0; j < NFX_PG_LPR; ++j) { hs_p[j] = 0.0; hp_p[j] = 0.0; }
+    const int nlow = lower - 1;          // points of the lower chain
+    if (m > 1 || (m == 1 && V > 1)) {
+        for (int c0 = 0; c0 < 2; ++c0) {
+            const int e_begin = c0 == 0 ? 0 : nlow - 1, e_end = c0 == 0 ? nlow - 1 : m; // hull edges k -> k + 1 (mod m) of this chain
+            for (int k0 = e_begin; k0 < e_end; k0 += NFX_PG_LPR) {
+#pragma unroll
+                for (int j = 0; j < NFX_PG_LPR; ++j) {
+                    const int k = k0 + j;
+                    if (k < e_end) {
+                        const pt a = P(hull[k]), b = P(hull[k + 1 == m ? 0 : k + 1]);
+                        hs_p[j] += a.x * b.y - b.x * a.y;
+                        const double dx = b.x - a.x, dy = b.y - a.y;
+                        hp_p[j] += sqrt(dx * dx + dy * dy);
+                    }
+                }
+            }
         }
     }
+    const double hsh = partial_tree(hs_p), hperim = partial_tree(hp_p);
     const double harea = fabs(hsh) * 0.5;
     const double deviation = (harea - area) / harea;
     if (o) { // columns of the geometry block (shape.rs:116-127), rounded once
@@ -707,10 +745,6 @@ __global__ __launch_bounds__(64) void k_polygon_serial(int64_t n, const uint32_t
 //     with the top two hull points in registers (a push costs no LDS read, a pop one);
 //   * hull area and perimeter are again per-edge terms over the group.
 // Rings longer than PG_MAXV keep the serial program (polygon_one on global memory), run by their group's first lane.
-#ifndef NFX_PG_LPR
-#define NFX_PG_LPR 8
-#endif
-
 template <int LPR>
 static __device__ __forceinline__ double group_total_f64(double v)
 {

@@ -857,7 +857,7 @@ size_t glcm_scratch_bytes(const Job &job)
 hipError_t prepare_glcm(nfx_ctx *ctx)
 {
     if (ctx->glcm_lut) return hipSuccess;
-    if (ctx->reserved || stream_capturing(ctx)) return hipErrorNotReady; // tables are built by nfx_ctx_reserve or before a capture
+    if (tables_locked(ctx)) return hipErrorNotReady; // device-memory calls on a reserved context and captures never allocate: nfx_ctx_reserve builds the tables
     std::vector<double> h(2 * GL_RANKS + GL_COUNTS);
     auto xl = [](double x) { return x > 0.0 ? x * std::log(x) : 0.0; };
     for (int k = 0; k < GL_RANKS; ++k) {

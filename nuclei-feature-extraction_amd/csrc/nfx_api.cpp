@@ -168,53 +168,71 @@ bool stream_capturing(nfx_ctx *ctx)
     return st != hipStreamCaptureStatusNone;
 }
 
-static nfx_status ws_grow(nfx_ctx *ctx, size_t bytes)
+bool tables_locked(nfx_ctx *ctx) { return (ctx->reserved && ctx->call_mem == NFX_MEM_DEVICE) || stream_capturing(ctx); }
+
+// Reallocates an arena (synchronise + free + malloc).  For dev_ws this moves addresses a captured graph may hold: the callers
+// below decide when that is allowed, and every such move is counted (nfx_ctx_workspace_generation).
+static nfx_status arena_grow(nfx_ctx *ctx, Arena &a, size_t bytes)
 {
-    if (ctx->ws) {
+    if (a.base) {
         (void)hipStreamSynchronize(ctx->stream);
         if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
-        (void)hipFree(ctx->ws);
-        ctx->ws = nullptr;
-        ctx->ws_cap = 0;
+        (void)hipFree(a.base);
+        a.base = nullptr;
+        a.cap = 0;
+        if (&a == &ctx->dev_ws) ++ctx->ws_generation;
     }
     const size_t cap = bytes + (bytes >> 3) + (1u << 20);
-    if (hipMalloc(reinterpret_cast<void **>(&ctx->ws), cap) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void **>(&a.base), cap) != hipSuccess) {
         (void)hipGetLastError();
         ctx->err = "device workspace: out of memory";
         return NFX_ERR_OUT_OF_MEMORY;
     }
-    ctx->ws_cap = cap;
+    a.cap = cap;
     return NFX_OK;
 }
 
 nfx_status ws_reserve(nfx_ctx *ctx, size_t bytes, nfx_mem mem)
 {
-    ctx->ws_off = 0;
-    if (bytes <= ctx->ws_cap) return NFX_OK;
+    Arena &a = *ctx->ws; // host_ws for a NFX_MEM_HOST call (StreamScope), dev_ws otherwise
+    a.off = 0;
     if (mem == NFX_MEM_DEVICE) {
+        const bool capturing = stream_capturing(ctx);
+        if (capturing) ctx->capture_seen = true;
+        if (bytes <= a.cap) return NFX_OK;
         // stream-ordered calls promise not to synchronise or allocate (nfx.h): honoured strictly once the caller has made a
         // reservation, and always during a capture (a hipMalloc there would invalidate the capture anyway)
         if (ctx->reserved) {
-            ctx->err = "device-memory call exceeds the context's reservation (" + std::to_string(bytes) + " > " + std::to_string(ctx->ws_cap) +
+            ctx->err = "device-memory call exceeds the context's reservation (" + std::to_string(bytes) + " > " + std::to_string(a.cap) +
                        " bytes): call nfx_ctx_reserve for this shape first";
             return NFX_ERR_OUT_OF_MEMORY;
         }
-        if (stream_capturing(ctx)) {
+        if (capturing) {
             ctx->err = "device-memory call during stream capture needs a workspace that is not there yet: call nfx_ctx_reserve before capturing";
             return NFX_ERR_INVALID_ARGUMENT;
         }
+        if (ctx->capture_seen) {
+            // a graph captured earlier on this context holds addresses inside the workspace: growing it here, silently, would
+            // leave that graph replaying into freed memory.  nfx_ctx_reserve is the explicit way (it counts the move).
+            ctx->err = "device-memory call needs a larger workspace (" + std::to_string(bytes) + " > " + std::to_string(a.cap) +
+                       " bytes) on a context a graph was captured from: call nfx_ctx_reserve for this shape and capture again";
+            return NFX_ERR_OUT_OF_MEMORY;
+        }
+    } else if (bytes <= a.cap) {
+        return NFX_OK;
     }
-    return ws_grow(ctx, bytes);
+    return arena_grow(ctx, a, bytes);
 }
 
 static size_t al(size_t b) { return (b + 255) & ~size_t(255); }
 
 void *ws_alloc(nfx_ctx *ctx, size_t bytes)
 {
+    Arena &w = *ctx->ws;
     const size_t a = al(bytes);
-    if (ctx->ws_off + a > ctx->ws_cap) return nullptr;
-    void *p = ctx->ws + ctx->ws_off;
-    ctx->ws_off += a;
+    if (w.off + a > w.cap) return nullptr;
+    void *p = w.base + w.off;
+    w.off += a;
     return p;
 }
 
@@ -294,7 +312,8 @@ void nfx_ctx_destroy(nfx_ctx *ctx)
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (auto &t : ctx->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->dev_ws.base) (void)hipFree(ctx->dev_ws.base);
+    if (ctx->host_ws.base) (void)hipFree(ctx->host_ws.base);
     if (ctx->gabor_tab) (void)hipFree(ctx->gabor_tab);
     if (ctx->gabor_dense) (void)hipFree(ctx->gabor_dense);
     if (ctx->od_lut) (void)hipFree(ctx->od_lut);
@@ -318,6 +337,8 @@ nfx_status nfx_ctx_set_patch_addressing(nfx_ctx *ctx, nfx_addressing mode)
     ctx->addressing = mode;
     return NFX_OK;
 }
+
+uint64_t nfx_ctx_workspace_generation(const nfx_ctx *ctx) { return ctx ? ctx->ws_generation : 0; }
 
 nfx_status nfx_ctx_synchronize(nfx_ctx *ctx)
 {
@@ -380,19 +401,27 @@ static nfx_status check_offsets(nfx_ctx *ctx, const uint32_t *off, int64_t n, in
     return NFX_OK;
 }
 
-// A synchronous (host-memory) call runs on the context's own stream.  It first waits for whatever the caller still has in
-// flight on the device-call stream: both kinds of call share the context's workspace.
+// A synchronous (host-memory) call runs on the context's own stream and in the context's host arena (its staging buffers and
+// scratch never touch the workspace of the device-memory calls, whose addresses a captured graph may hold).  It first waits
+// for whatever the caller still has in flight on the device-call stream: both kinds of call share the device tables.
 struct StreamScope {
     nfx_ctx *ctx;
     hipStream_t saved;
     StreamScope(nfx_ctx *c, nfx_mem mem) : ctx(c), saved(c->stream)
     {
+        c->call_mem = mem;
+        c->ws = mem == NFX_MEM_HOST ? &c->host_ws : &c->dev_ws;
         if (mem == NFX_MEM_HOST && c->own_stream) {
             (void)hipStreamSynchronize(saved);
             c->stream = c->own_stream;
         }
     }
-    ~StreamScope() { ctx->stream = saved; }
+    ~StreamScope()
+    {
+        ctx->stream = saved;
+        ctx->ws = &ctx->dev_ws;
+        ctx->call_mem = NFX_MEM_DEVICE;
+    }
 };
 
 static int sets_total_columns(const int *sets, int n_sets)
@@ -589,8 +618,10 @@ nfx_status nfx_ctx_reserve(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n,
     }
     const bool was = ctx->reserved;
     ctx->reserved = false; // the builders below are the one place allowed to allocate
+    ctx->ws = &ctx->dev_ws;
     st = prepare_sets(ctx, sets, n_sets);
-    if (st == NFX_OK && need > ctx->ws_cap) st = ws_grow(ctx, need);
+    // growing an existing workspace moves it: graphs captured earlier hold the old addresses (nfx.h, nfx_ctx_workspace_generation)
+    if (st == NFX_OK && need > ctx->dev_ws.cap) st = arena_grow(ctx, ctx->dev_ws, need);
     ctx->reserved = was || st == NFX_OK;
     return st;
 }

@@ -36,6 +36,11 @@ struct Timing {
     int slot;
 };
 
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, off = 0;
+};
+
 }  // namespace nfx
 
 struct nfx_ctx {
@@ -47,10 +52,17 @@ struct nfx_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr; // here, beside the rasteriser and the pixel kernels of the same call
     nfx_addressing addressing = NFX_ADDR_IMAGE;
     std::string err;
-    // grow-only device workspace with a bump pointer, reset at the start of every API call
-    char *ws = nullptr;
-    size_t ws_cap = 0, ws_off = 0;
-    bool reserved = false; // nfx_ctx_reserve was called: device-memory calls never grow the workspace or build tables
+    // Two grow-only device workspaces with a bump pointer each, rewound at the start of every API call:
+    //   dev_ws   everything a NFX_MEM_DEVICE call needs.  A HIP graph captured from such a call holds addresses inside it, so it is
+    //            reallocated only where nfx.h says so: by nfx_ctx_reserve (always) and by an unreserved call that outgrows it as long
+    //            as no capture has been seen on the context.  `ws_generation` counts its reallocations.
+    //   host_ws  staging and scratch of the synchronous NFX_MEM_HOST calls; grows freely, never seen by a captured graph.
+    nfx::Arena dev_ws, host_ws;
+    nfx::Arena *ws = &dev_ws;       // the arena of the API call in progress (StreamScope)
+    nfx_mem call_mem = NFX_MEM_DEVICE; // memory kind of the API call in progress
+    bool reserved = false;     // nfx_ctx_reserve was called: device-memory calls never grow the workspace or build tables
+    bool capture_seen = false; // a device-memory call was enqueued into a stream capture: dev_ws must stay where it is
+    uint64_t ws_generation = 0;
     // timing
     bool timing = false;
     std::vector<nfx::Timing> pending;
@@ -128,7 +140,8 @@ size_t glcm_scratch_bytes(const Job &job);
 hipError_t launch_glrlm(nfx_ctx *ctx, const Job &job, int col0);
 hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0);
 // device tables of a feature set (no-ops once built).  Building allocates and copies synchronously: nfx_ctx_reserve does it
-// up front; a launcher that finds its table missing builds it on the spot unless the stream is capturing
+// up front; a launcher that finds its table missing builds it on the spot unless tables_locked(ctx)
+bool tables_locked(nfx_ctx *ctx); // a device-memory call on a reserved context, or a stream capture in progress: no allocation allowed
 hipError_t prepare_color(nfx_ctx *ctx);
 hipError_t prepare_glcm(nfx_ctx *ctx);
 hipError_t prepare_gabor(nfx_ctx *ctx);

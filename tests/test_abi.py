@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol(nfx):
     L = nfx.lib()
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.nfx_version() == 200
+    assert L.nfx_version() == 300
 
 
 def test_registry_names_and_counts(nfx):

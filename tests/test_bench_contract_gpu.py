@@ -28,8 +28,16 @@ def test_bench_line(workload):
     rf = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in rf, key
-    assert rf["bound"] in ("hbm", "mfma") and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6
+    # `bound` names the unit that limits the dominant kernel when a counter summary of this csrc/ is committed (lds / valu), else
+    # hbm; the HBM figure the metric asks for is always there as roofline.hbm
+    assert rf["bound"] in ("hbm", "lds", "valu")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    hb = rf["hbm"]
+    assert hb["peak"] == 8000.0 and hb["unit"] == "GB/s" and abs(hb["frac"] - hb["achieved"] / hb["peak"]) < 1e-6
+    assert rf["bound"] == "hbm" and rf["achieved"] == hb["achieved"]      # a 3000-nucleus run is not the profiled workload
+    if workload == "config2":   # the libtorch-shaped data point of the geometry workload
+        ct = d["cpu_baseline_torch"]
+        assert ct["kind"] == "aten-twin" and ct["value"] > 0 and ct["cores"] >= 1 and "sample" in ct
     cb = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
@@ -53,8 +61,32 @@ def test_bench_launches_its_own_ranks_and_checks_the_gather():
     assert ("REHEARSAL" in d["config"]["sharding"]) == (torch.cuda.device_count() < 2)
     a = d["also"]
     assert a["gather_checksums_match"] is True
+    assert d["config"]["gather"] == "rank0" and d["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    c = a["weak_scaling_compute_only"]     # the same shards without the gather, beside the gathered headline
+    assert c["scaling"] == "weak" and c["value"] > 0
     s = a["strong_scaling_config4"]
     assert s["scaling"] == "strong" and s["shard_nuclei"] == [1900, 1800]           # 37 batches of 100: 19 + 18
     assert s["gather_checksums_match"] is True and s["gathered_equals_single_gpu"] is True
     f = a["full_feature_set"]
     assert f["n_gpus"] == 2 and f["config"]["columns"] == 418 and f["gather_checksums_match"] is True and f["value"] > 0
+
+
+def test_one_rank_over_rccl_and_gather_none():
+    """The NCCL (= RCCL) code path with a real communicator, on the one GPU this box has: `NFX_BENCH_FORCE_DIST=1` under
+    torch.distributed.run with one rank takes init_process_group("nccl"), the sliced asynchronous gathers, the barriers and the
+    transport checksums exactly as an N > 1 run does.  And `--gather none` reports compute-only scaling and says so."""
+    env = dict(os.environ, NFX_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+            os.path.join(ROOT, "bench.py"), "--gpus", "1", "--nuclei", "4000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--full-set-nuclei", "500"]
+    r = subprocess.run(base, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["also"]["gather_checksums_match"] is True
+    assert d["also"]["full_feature_set"]["gather_checksums_match"] is True
+    assert d["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    r = subprocess.run(base + ["--gather", "none", "--no-also"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["value"] > 0 and d["also"] is None

@@ -287,3 +287,107 @@ def test_no_kernel_writes_outside_its_output_rows(nfx, ps):
     assert np.array_equal(big[guard:n + guard].cpu().numpy(), want, equal_nan=True)
     ctx.set_stream(0)
     ctx.close()
+
+
+def _capture_extract(torch, nfx, ctx, sets, d_off, d_xy, d_p, ps, out):
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ctx.set_stream(side.cuda_stream)
+        with torch.cuda.graph(g, stream=side):
+            ctx.extract(sets, d_off, d_xy, d_p, ps, out=out, want_centroids=False)
+    torch.cuda.current_stream().wait_stream(side)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    return g
+
+
+def test_a_captured_graph_survives_larger_host_calls_and_reservations_are_counted(nfx):
+    """A graph captured from nfx_extract holds addresses inside the device-call workspace.  Host-memory calls of any size stage in
+    an arena of their own, so replaying after one gives the same rows; only a larger nfx_ctx_reserve moves the workspace, and
+    nfx_ctx_workspace_generation says so."""
+    import torch
+    ps, n = 48, 200
+    off, xy, pu8 = par.make_inputs(31, 3000, ps)
+    dev = torch.device("cuda", 0)
+    s_off = torch.from_numpy(off[:n + 1].astype(np.int32)).to(dev)
+    s_xy = torch.from_numpy(xy[:off[n]]).to(dev)
+    s_p = torch.from_numpy(pu8[:n]).to(dev)
+    sets = [0, 1, 2, 3, 4]
+    out = torch.zeros((n, 418), dtype=torch.float32, device=dev)
+    ctx = nfx.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.reserve(sets, n, int(off[n]), ps, batch_size=100)
+        gen = ctx.workspace_generation()
+        g = _capture_extract(torch, nfx, ctx, sets, s_off, s_xy, s_p, ps, out)
+        g.replay()
+        torch.cuda.synchronize()
+        want = out.clone()
+        # fifteen times the nuclei through the host entry: far beyond the reservation
+        big, _ = ctx.extract(sets, off, xy, pu8, ps, batch_size=100)
+        assert ctx.workspace_generation() == gen, "a host-memory call moved the workspace a captured graph points into"
+        assert np.array_equal(big[:n], want.cpu().numpy(), equal_nan=True)
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(want)), "replay after a larger host call differs"
+        # a larger reservation is the one thing that moves it -- and it is counted
+        ctx.reserve(sets, 3000, len(xy), ps, batch_size=100)
+        assert ctx.workspace_generation() == gen + 1
+        g2 = _capture_extract(torch, nfx, ctx, sets, s_off, s_xy, s_p, ps, out)
+        out.zero_()
+        g2.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(want))
+    finally:
+        ctx.set_stream(0)
+        ctx.close()
+
+
+def test_unreserved_context_does_not_outgrow_a_captured_graph_silently(nfx):
+    """Without a reservation the workspace grows on demand -- until a capture has been seen on the context: from then on a
+    device-memory call that needs more is refused (the graph would replay into freed memory), and nfx_ctx_reserve is the way."""
+    import torch
+    ps, n = 32, 100
+    off, xy, pu8 = par.make_inputs(32, 1000, ps)
+    dev = torch.device("cuda", 0)
+    d_off = torch.from_numpy(off.astype(np.int32)).to(dev)
+    d_xy = torch.from_numpy(xy).to(dev)
+    d_p = torch.from_numpy(pu8).to(dev)
+    s_off, s_xy, s_p = d_off[:n + 1].contiguous(), d_xy[:int(off[n])].contiguous(), d_p[:n].contiguous()
+    sets = [0, 1, 3]
+    ctx = nfx.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        want, _ = ctx.extract(sets, s_off, s_xy, s_p, ps, want_centroids=False)     # eager: sizes the workspace, builds the tables
+        torch.cuda.synchronize()
+        out = torch.zeros_like(want)
+        g = _capture_extract(torch, nfx, ctx, sets, s_off, s_xy, s_p, ps, out)    # same shape: fits, nothing to allocate
+        with pytest.raises(nfx.NfxError, match="captured"):
+            ctx.extract(sets, d_off, d_xy, d_p, ps, want_centroids=False)          # ten times the nuclei
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(want))
+        ctx.reserve(sets, 1000, len(xy), ps)
+        rows, _ = ctx.extract(sets, d_off, d_xy, d_p, ps, want_centroids=False)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(rows[:n]), torch.nan_to_num(want))
+    finally:
+        ctx.set_stream(0)
+        ctx.close()
+
+
+def test_host_calls_build_missing_tables_on_a_reserved_context(nfx):
+    """nfx.h forbids allocation for NFX_MEM_DEVICE calls on a reserved context; host-memory calls synchronise anyway and may
+    build the device tables of sets the reservation did not list."""
+    ps = 48
+    off, xy, pu8 = par.make_inputs(33, 60, ps)
+    ctx = nfx.Context(0)
+    ctx.reserve([0], 60, len(xy), ps)                      # geometry only: no colour, GLCM or Gabor tables
+    rows, _ = ctx.extract([0, 1, 2, 3, 4], off, xy, pu8, ps, batch_size=30)
+    g, r = ctx.debug_texture_counts(off, xy, pu8, ps)
+    ref = nfx.Context(0)
+    want, _ = ref.extract([0, 1, 2, 3, 4], off, xy, pu8, ps, batch_size=30)
+    assert np.array_equal(rows, want, equal_nan=True)
+    assert g.any() and r.any()
+    ctx.close()
+    ref.close()

@@ -131,3 +131,27 @@ def test_polygon_columns_at_f64_width(nfx):
     ctx.synchronize()
     assert np.array_equal(d64.cpu().numpy(), p64, equal_nan=True)
     ctx.close()
+
+
+@pytest.mark.parametrize("ps", [32, 64])
+def test_both_polygon_kernels_give_the_same_bits(nfx, ps):
+    """The seven polygon columns come from two kernels: the group-parallel one when the columns are on the critical path (geometry
+    alone, the trait entry, nfx_polygon_features_f64) and the serial one on the side stream beside pixel sets.  They share one
+    summation order (edge k -> partial k mod 8, butterfly of the partials), so a nucleus does not change in its last f32 bit with
+    the other sets that were requested -- the command line mixes both in one file (f64 columns from the first, f32 rows from the
+    second)."""
+    ctx = nfx.Context(0)
+    off, xy, pu8 = par.make_inputs(41, 500, ps)
+    e_off, e_xy = par.edge_case_rings(ps)                  # incl. the 150-vertex ring (> PG_MAXV: the shared serial program) and degenerate rings
+    off, xy = par.concat_rings((off, xy), (e_off, e_xy))
+    pu8 = np.concatenate([pu8, pu8[:len(e_off) - 1]])
+    alone, _ = ctx.extract([0], off, xy, None, ps)                       # k_polygon<8>
+    beside, _ = ctx.extract([0, 1], off, xy, pu8, ps, batch_size=50)     # k_polygon_serial on the side stream
+    assert np.array_equal(alone.view(np.uint32), beside[:, :12].copy().view(np.uint32)), \
+        np.argwhere(alone.view(np.uint32) != beside[:, :12].copy().view(np.uint32))[:5]
+    _, ctr = ctx.preprocess_polygons(off, xy)
+    p64 = ctx.polygon_features_f64(off, ctr)
+    cols = [j for j, d in enumerate(nfx.column_dtypes(0)) if d == "f64"]
+    with np.errstate(invalid="ignore", over="ignore"):
+        assert np.array_equal(p64.astype(np.float32), beside[:, cols], equal_nan=True)
+    ctx.close()
