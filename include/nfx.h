@@ -26,6 +26,10 @@
  *                                                 u8 image by load_image_dataset's addressing rules
  *                                                 (utils.rs:141-206)
  *   nfx_centroid_key                              centroid_to_key_string, utils.rs:226-228
+ *   nfx_comm_* / nfx_gather_rows                  the host-side row merge append_features (vstack_mut under a
+ *                                                 mutex), main.rs:96-108, and the per-worker device choice
+ *                                                 utils.rs:211-224: one process per GPU, one gather of the
+ *                                                 rows to the root over RCCL / xGMI
  *
  * Errors: every function that can fail returns an nfx_status; nfx_last_error(ctx) gives the
  * text.  Degenerate nuclei do not fail: they yield NaN exactly where the reference's arithmetic
@@ -205,6 +209,32 @@ nfx_status nfx_polygon_features_f64(nfx_ctx *ctx, int64_t n, int64_t n_vertices,
 /* utils.rs:159-191 alone: crops [n][3][ps][ps] u8 out of image_u8 at the given centroids */
 nfx_status nfx_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids_xy, const uint8_t *image_u8, int64_t H,
                               int64_t W, int ps, uint8_t *patches_u8, nfx_mem mem);
+
+/* ---- multi-GPU: the row merge main.rs:96-108 as ONE gather over RCCL / xGMI --------------------------------------------
+   The reference merges rows on the host (vstack_mut under a mutex) from rayon workers that each picked `gpus[thread % n]`
+   (utils.rs:211-224).  Here every process drives one GPU through its own context and extracts a contiguous index shard whose
+   boundaries are multiples of the reference batch size (the hue mean couples the nuclei of a batch, color.rs:144-155); nothing is
+   exchanged during extraction.  nfx_gather_rows then moves every shard's [count, F] f32 rows once, device to device, to the
+   root: grouped ncclSend / ncclRecv (ragged shards need no padding), enqueued on the context's stream -- stream-ordered like
+   every NFX_MEM_DEVICE call, no host synchronisation.  No PyTorch / libtorch is involved: librccl is opened (dlopen) at the first
+   nfx_comm_* call; a process that never calls them never loads it.  Returns NFX_ERR_UNSUPPORTED if librccl is not there.
+
+     nfx_comm_unique_id   one rank (by convention rank 0) makes the 128-byte id; the host distributes it out of band (file, socket,
+                          environment -- ncclGetUniqueId semantics) and every rank passes the same bytes to nfx_comm_create
+     nfx_comm_create      collective: returns once all `world` ranks have called it (ncclCommInitRank); the communicator lives on
+                          ctx's device
+     nfx_gather_rows      rows [counts[rank]][F] (device), counts [world] (HOST array, the same on every rank), dst
+                          [sum counts][F] (device, root only; may be NULL elsewhere): rank r's rows land at row sum(counts[0..r)),
+                          i.e. in nucleus-index order.  Collective: every rank of the communicator calls it with the same F,
+                          counts and root. */
+#define NFX_UNIQUE_ID_BYTES 128
+typedef struct nfx_comm nfx_comm;
+nfx_status nfx_comm_unique_id(void *id_out /* NFX_UNIQUE_ID_BYTES */);
+nfx_status nfx_comm_create(nfx_ctx *ctx, int rank, int world, const void *unique_id, nfx_comm **out);
+void nfx_comm_destroy(nfx_comm *comm);
+int nfx_comm_rank(const nfx_comm *comm);
+int nfx_comm_world(const nfx_comm *comm);
+nfx_status nfx_gather_rows(nfx_ctx *ctx, nfx_comm *comm, const float *rows, int F, const int64_t *counts, float *dst, int root);
 
 /* ---- TEST HOOK (not part of the reference's surface): the exact integers behind the texture columns, for count-level
    parity checks against tch_utils::glcm::glcm / glrlm::glrlm as called at texture.rs:40-46,193-194.  Inputs as nfx_extract.

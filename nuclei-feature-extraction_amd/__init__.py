@@ -40,6 +40,7 @@ ABI_SYMBOLS = (
     "nfx_ctx_enable_timing", "nfx_ctx_kernel_timing", "nfx_ctx_reset_timing",
     "nfx_preprocess_polygons", "nfx_rasterize_polygons", "nfx_compute_features_batched",
     "nfx_extract", "nfx_extract_tile", "nfx_gather_patches",
+    "nfx_comm_unique_id", "nfx_comm_create", "nfx_comm_destroy", "nfx_comm_rank", "nfx_comm_world", "nfx_gather_rows",
 )
 
 
@@ -88,6 +89,13 @@ def lib() -> C.CDLL:
     L.nfx_feature_set_column_dtype.argtypes = [C.c_int, C.c_int]
     L.nfx_polygon_features_f64.argtypes = [vp, i64, i64, u32p, f32p, vp, C.c_int]
     L.nfx_debug_texture_counts.argtypes = [vp, i64, i64, u32p, f32p, u8p, C.c_int, vp, vp, C.c_int]
+    L.nfx_comm_unique_id.argtypes = [vp]
+    L.nfx_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.nfx_comm_destroy.argtypes = [vp]
+    L.nfx_comm_destroy.restype = None
+    L.nfx_comm_rank.argtypes = [vp]
+    L.nfx_comm_world.argtypes = [vp]
+    L.nfx_gather_rows.argtypes = [vp, vp, f32p, C.c_int, C.POINTER(C.c_int64), f32p, C.c_int]
     _lib = L
     return L
 
@@ -380,6 +388,60 @@ class Context:
             out = np.empty((n, 3, ps, ps), np.uint8)
         self._check(lib().nfx_gather_patches(self._h, n, _ptr(cen), _ptr(img), int(img.shape[1]), int(img.shape[2]), ps, _ptr(out), int(dev)))
         return out
+
+
+# ---- multi-GPU: the gather of rows over RCCL / xGMI below any framework (nfx_comm_*, nfx_gather_rows) -----------
+UNIQUE_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """nfx_comm_unique_id: the 128 bytes one rank makes and every rank passes to :class:`Comm` (distribute them out of band)."""
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    st = lib().nfx_comm_unique_id(buf)
+    if st != 0:
+        raise NfxError(f"nfx_comm_unique_id: {_STATUS.get(st, st)} (is librccl there?)")
+    return buf.raw
+
+
+class Comm:
+    """One rank of a communicator on ``ctx``'s GPU (nfx_comm_create is collective: it returns once every rank has called it)."""
+
+    def __init__(self, ctx: Context, rank: int, world: int, unique_id: bytes):
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError("unique_id: 128 bytes from comm_unique_id()")
+        self.ctx, self.rank, self.world = ctx, rank, world
+        h = C.c_void_p()
+        ctx._check(lib().nfx_comm_create(ctx._h, rank, world, C.c_char_p(unique_id), C.byref(h)))
+        self._h = h
+
+    def gather_rows(self, rows, counts: Sequence[int], dst=None, root: int = 0):
+        """nfx_gather_rows: ``rows`` [counts[rank], F] CUDA f32 tensor; on the root ``dst`` [sum(counts), F] receives every rank's
+        rows in rank (= nucleus index) order.  Stream-ordered on the context's stream; returns ``dst``."""
+        if len(counts) != self.world:
+            raise ValueError("counts: one entry per rank")
+        F = int(rows.shape[1])
+        if int(rows.shape[0]) != int(counts[self.rank]):
+            raise ValueError("rows: counts[rank] rows expected")
+        rows = _prep(rows, np.float32, True, "rows")
+        if self.rank == root:
+            if dst is None:
+                import torch
+                dst = torch.empty((int(sum(counts)), F), dtype=torch.float32, device=rows.device)
+            dst = _prep(dst, np.float32, True, "dst")
+        arr = (C.c_int64 * self.world)(*[int(c) for c in counts])
+        self.ctx._check(lib().nfx_gather_rows(self.ctx._h, self._h, _ptr(rows), F, arr, _ptr(dst) if dst is not None else None, root))
+        return dst
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().nfx_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- the reference's plugin surface ---------------------------------------------------------------

@@ -65,10 +65,14 @@ class ShardedExtraction:
     extract_fn(b0, b1, out): computes the LOCAL rows [b0, b1) (nuclei i0+b0 .. i0+b1) into `out` ([b1-b0, F]).
     wire_device: where the collective's buffers live (None = the compute device; "cpu" for a gloo group fed
                  from a GPU, the one-GPU rehearsal of bench.py).
+    transport:   "torch" (default): torch.distributed.gather per slice (c10d over RCCL or gloo).
+                 "nfx": the engine's own nfx_gather_rows (include/nfx.h: grouped ncclSend / ncclRecv below any framework, ragged
+                 shards unpadded) on a side stream of its own, ordered after each slice by an event; torch.distributed only
+                 carries the 128-byte communicator id to the ranks.
     """
 
     def __init__(self, n_total: int, F: int, batch_size: int, n_slices: int = 4, device=None, group=None, dst: int = 0,
-                 wire_device=None):
+                 wire_device=None, transport: str = "torch"):
         import torch
         import torch.distributed as dist
 
@@ -88,14 +92,54 @@ class ShardedExtraction:
         self.bufs = [torch.empty((self.m, F), dtype=torch.float32, device=self.device) for _ in range(2)]
         self.full = None
         self.blocks = None
-        if self.rank == dst:
+        if self.rank == dst and transport == "torch":
             self.full = torch.empty((self.world * self.m, F), dtype=torch.float32, device=self.wire)
             self.blocks = [self.full[r * self.m:(r + 1) * self.m] for r in range(self.world)]
         self.pending: list = []
         self.steps = 0
         self.last_buf = None
+        self.transport = transport
+        if transport == "nfx":
+            import importlib
+            nfx = importlib.import_module(__package__)
+            uid = [nfx.comm_unique_id() if self.rank == dst else None]
+            dist.broadcast_object_list(uid, src=dst, group=group)
+            self.cstream = torch.cuda.Stream(self.device)
+            self.cctx = nfx.Context(self.device.index, stream=self.cstream.cuda_stream)   # a context of its own: its stream is the gathers' stream
+            self.comm = nfx.Comm(self.cctx, self.rank, self.world, uid[0])
+            # per slice: how many rows every rank really has in it (ragged shards travel unpadded), and the root's landing block
+            nb = len(self.bounds) - 1
+            self.slice_counts = [[max(0, min(self.bounds[k + 1], c) - self.bounds[k]) for c in self.counts] for k in range(nb)]
+            self.slice_dst = [torch.empty((sum(sc), F), dtype=torch.float32, device=self.device) for sc in self.slice_counts] if self.rank == dst else [None] * nb
+            self.buf_free = [None, None]   # event: the gathers that read bufs[b] have finished
+        elif transport != "torch":
+            raise ValueError("transport is 'torch' or 'nfx'")
+
+    def _step_nfx(self, extract_fn):
+        import torch
+        b = self.steps & 1
+        buf = self.bufs[b]
+        compute = torch.cuda.current_stream(self.device)
+        if self.buf_free[b] is not None:
+            compute.wait_event(self.buf_free[b])        # the gathers of two steps ago still read this buffer
+        for k in range(len(self.bounds) - 1):
+            b0, b1 = self.bounds[k], self.bounds[k + 1]
+            e1 = min(b1, self.n_local)
+            if e1 > b0:
+                extract_fn(b0, e1, buf[b0:e1])
+            ev = torch.cuda.Event()
+            ev.record(compute)
+            self.cstream.wait_event(ev)
+            self.comm.gather_rows(buf[b0:max(b0, e1)], self.slice_counts[k], self.slice_dst[k], root=self.dst)
+        done = torch.cuda.Event()
+        done.record(self.cstream)
+        self.buf_free[b] = done
+        self.last_buf = buf
+        self.steps += 1
 
     def step(self, extract_fn: Callable[[int, int, object], None]):
+        if self.transport == "nfx":
+            return self._step_nfx(extract_fn)
         buf = self.bufs[self.steps & 1]
         works = []
         for k in range(len(self.bounds) - 1):
@@ -115,9 +159,23 @@ class ShardedExtraction:
         self.steps += 1
 
     def finish(self):
+        if self.transport == "nfx":
+            self.cstream.synchronize()
+            return
         for w in self.pending:
             w.wait()
         self.pending = []
+
+    def _received(self, r):
+        """On dst: rank r's rows of the last step as they arrived ([counts[r], F])."""
+        if self.transport == "nfx":
+            import torch
+            parts = []
+            for k, sc in enumerate(self.slice_counts):
+                o = sum(sc[:r])
+                parts.append(self.slice_dst[k][o:o + sc[r]])
+            return torch.cat(parts, dim=0)
+        return self.blocks[r][:self.counts[r]]
 
     def local_rows(self):
         """This rank's rows of the last step ([n_local, F])."""
@@ -128,9 +186,11 @@ class ShardedExtraction:
         if self.rank != self.dst:
             return None
         self.finish()
+        import torch
+        if self.transport == "nfx":
+            return torch.cat([self._received(r) for r in range(self.world)], dim=0)
         if all(c == self.m for c in self.counts):
             return self.full[:self.n_total]
-        import torch
         return torch.cat([self.blocks[r][:self.counts[r]] for r in range(self.world)], dim=0)
 
     def verify_transport(self) -> Optional[List[bool]]:
@@ -143,7 +203,14 @@ class ShardedExtraction:
         self.dist.gather(mine, got, dst=self.dst, group=self.group)
         if self.rank != self.dst:
             return None
-        return [int(got[r].item()) == row_checksum(self.blocks[r][:self.counts[r]]) for r in range(self.world)]
+        return [int(got[r].item()) == row_checksum(self._received(r)) for r in range(self.world)]
+
+    def close(self):
+        if self.transport == "nfx":
+            self.finish()
+            self.comm.close()
+            self.cctx.set_stream(0)
+            self.cctx.close()
 
 
 # ---- process launch -----------------------------------------------------------------------------------------------

@@ -1,0 +1,65 @@
+"""nfx_comm_* / nfx_gather_rows: the reference's host-side row merge (main.rs:96-108) as one gather over RCCL, through the raw C ABI
+-- no torch.distributed, no libtorch collective.  This box has one GPU, so the communicator has world size 1: that still
+initialises RCCL (ncclCommInitRank), posts the grouped ncclSend / ncclRecv on the context's stream and moves the rows device to
+device; N > 1 differs only in who the peers are.  tests/test_distributed.py covers the sharding arithmetic on CPU (gloo, 2 ranks)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _parity as par
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gather_rows_world_size_one_through_the_raw_abi(nfx):
+    import torch
+    L = nfx.lib()
+    ps, n = 32, 300
+    off, xy, pu8 = par.make_inputs(51, n, ps)
+    dev = torch.device("cuda", 0)
+    ctx = nfx.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    rows, _ = ctx.extract([0, 1], torch.from_numpy(off.astype(np.int32)).to(dev), torch.from_numpy(xy).to(dev), torch.from_numpy(pu8).to(dev), ps,
+                          want_centroids=False)
+    F = rows.shape[1]
+    uid = C.create_string_buffer(128)
+    assert L.nfx_comm_unique_id(uid) == 0
+    assert any(uid.raw), "the id is not all zeros"
+    comm = C.c_void_p()
+    st = L.nfx_comm_create(ctx._h, 0, 1, uid, C.byref(comm))
+    assert st == 0, L.nfx_last_error(ctx._h).decode()
+    assert L.nfx_comm_rank(comm) == 0 and L.nfx_comm_world(comm) == 1
+    dst = torch.full((n + 2, F), -7.0, dtype=torch.float32, device=dev)     # guard rows either side
+    counts = (C.c_int64 * 1)(n)
+    st = L.nfx_gather_rows(ctx._h, comm, C.c_void_p(rows.data_ptr()), F, counts, C.c_void_p(dst[1:].data_ptr()), 0)
+    assert st == 0, L.nfx_last_error(ctx._h).decode()
+    torch.cuda.synchronize()                                                # the gather is stream-ordered: nothing waited for it
+    assert torch.equal(dst[1:n + 1].view(torch.int32), rows.view(torch.int32)), "gathered rows differ from the rows sent (bit patterns, NaNs included)"
+    assert bool((dst[0] == -7.0).all()) and bool((dst[n + 1] == -7.0).all())
+    # errors are reported, not executed
+    assert L.nfx_gather_rows(ctx._h, comm, C.c_void_p(rows.data_ptr()), F, counts, C.c_void_p(dst.data_ptr()), 3) == 1 and b"root" in L.nfx_last_error(ctx._h)
+    assert L.nfx_gather_rows(ctx._h, comm, C.c_void_p(rows.data_ptr()), F, counts, None, 0) == 1 and b"dst" in L.nfx_last_error(ctx._h)
+    assert L.nfx_gather_rows(ctx._h, comm, None, F, counts, C.c_void_p(dst.data_ptr()), 0) == 1
+    bad = C.c_void_p()
+    assert L.nfx_comm_create(ctx._h, 2, 1, uid, C.byref(bad)) == 1 and not bad.value
+    L.nfx_comm_destroy(comm)
+    ctx.set_stream(0)
+    ctx.close()
+
+
+def test_python_mirror_and_an_empty_shard(nfx):
+    """The Comm class (what distributed.py's native transport uses) and a rank whose shard is empty (more ranks than batches)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx = nfx.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    comm = nfx.Comm(ctx, 0, 1, nfx.comm_unique_id())
+    rows = torch.arange(5 * 7, dtype=torch.float32, device=dev).reshape(5, 7)
+    out = comm.gather_rows(rows, [5])
+    torch.cuda.synchronize()
+    assert torch.equal(out, rows)
+    empty = comm.gather_rows(rows[:0], [0])
+    torch.cuda.synchronize()
+    assert empty.shape == (0, 7)
+    comm.close()
+    ctx.set_stream(0)
+    ctx.close()

@@ -349,7 +349,7 @@ def test_unreserved_context_does_not_outgrow_a_captured_graph_silently(nfx):
     device-memory call that needs more is refused (the graph would replay into freed memory), and nfx_ctx_reserve is the way."""
     import torch
     ps, n = 32, 100
-    off, xy, pu8 = par.make_inputs(32, 1000, ps)
+    off, xy, pu8 = par.make_inputs(32, 20000, ps)     # 200x the nuclei: far beyond the slack a workspace is allocated with
     dev = torch.device("cuda", 0)
     d_off = torch.from_numpy(off.astype(np.int32)).to(dev)
     d_xy = torch.from_numpy(xy).to(dev)
@@ -363,11 +363,11 @@ def test_unreserved_context_does_not_outgrow_a_captured_graph_silently(nfx):
         out = torch.zeros_like(want)
         g = _capture_extract(torch, nfx, ctx, sets, s_off, s_xy, s_p, ps, out)    # same shape: fits, nothing to allocate
         with pytest.raises(nfx.NfxError, match="captured"):
-            ctx.extract(sets, d_off, d_xy, d_p, ps, want_centroids=False)          # ten times the nuclei
+            ctx.extract(sets, d_off, d_xy, d_p, ps, want_centroids=False)
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(torch.nan_to_num(out), torch.nan_to_num(want))
-        ctx.reserve(sets, 1000, len(xy), ps)
+        ctx.reserve(sets, 20000, len(xy), ps)
         rows, _ = ctx.extract(sets, d_off, d_xy, d_p, ps, want_centroids=False)
         torch.cuda.synchronize()
         assert torch.equal(torch.nan_to_num(rows[:n]), torch.nan_to_num(want))
