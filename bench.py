@@ -231,6 +231,55 @@ def roofline_of(timing, steps, res, workload, full_size):
             "kernels_ms_per_step": {k: round(v["total_ms"] / steps, 4) for k, v in timing.items() if v["launches"]}}
 
 
+def streamed_tile_leg(nfx, synth, torch, dist, ctx, dev, workload, n, i0, B, steps, fence):
+    """BASELINE configs[4]'s input path on one GPU: this rank's nuclei [i0, i0+n) and THEIR slide (side ceil(sqrt(n (ps/1.5)^2)),
+    SURVEY.md §8d; nuclei in slide order, as segmentation tools emit them) start in pinned host memory; every step streams the
+    slide block by block through nfx_extract_tile_streamed -- copies overlapped with compute, rows copied back -- and is timed from the
+    first H2D byte to the last row on the host.  Checked bit for bit against nfx_extract_tile on the same slide resident in HBM."""
+    n_def, ps, set_names, desc, sidx = WORKLOADS[workload]
+    sets = nfx.parse_feature_sets(set_names)
+    F = sum(nfx.num_columns(s) for s in sets)
+    seed = synth.SEED_BASE + sidx
+    T = synth.tile_side(n, ps)
+    t0 = time.time()
+    cx, cy = synth.centres_slide_order(seed, i0, n, n, ps, T, T, slide_i0=i0)
+    off, xy = synth.polygons(seed, i0, n, ps, cx, cy)
+    d_off = torch.from_numpy(off.astype(np.int32)).to(dev)
+    d_xy = torch.from_numpy(xy).to(dev)
+    cen, _ = ctx.preprocess_polygons(d_off, d_xy)          # the centroids the engine will address the windows with
+    cen = cen.cpu().numpy()
+    d_p = synth.patches(seed, i0, n, ps, xp=torch, device=dev)
+    tile = synth.tile_from_patches(torch, d_p, cen[:, 0], cen[:, 1], T, T, ps, seed, dev)
+    del d_p
+    torch.cuda.empty_cache()
+    ctx.reserve(sets, n, len(xy), ps, batch_size=B)
+    ref, _ = ctx.extract_tile(sets, d_off, d_xy, tile, ps, batch_size=B)     # the slide resident in HBM: the rows to reproduce
+    torch.cuda.synchronize()
+    ref = ref.cpu().numpy()
+    h_tile = nfx.pinned_empty((3, T, T), np.uint8)         # pinned for libnfx's own HIP runtime (torch's pinned memory is not)
+    for r0 in range(0, T, 2048):
+        h_tile[:, r0:r0 + 2048] = tile[:, r0:r0 + 2048].cpu().numpy()
+    del tile
+    torch.cuda.empty_cache()
+    h_rows = nfx.pinned_empty((n, F), np.float32)
+    gen_s = time.time() - t0
+    stats = {}
+
+    def step():
+        stats.update(ctx.extract_tile_streamed(sets, off, xy, h_tile, ps, batch_size=B, out=h_rows)[2])
+    el, _ = timed(torch, dist, False, ctx, steps, 1, step, fence)
+    same = bool(np.array_equal(h_rows.view(np.uint32), ref.view(np.uint32)))
+    wire = stats["image_bytes_h2d"] + stats["other_bytes_h2d"] + stats["rows_bytes_d2h"]
+    packed = 3 * ps * ps + 8.0 * len(xy) / n + 4 + 4 * F + 8          # what the packed-patch stream moves per nucleus
+    return {"value": round(n * steps / el, 1), "unit": "nuclei/s", "ms_per_step": round(el / steps * 1e3, 3),
+            "what": f"{desc}: the nuclei's slide ({T} x {T} pixels, {3 * T * T / 1e9:.2f} GB, nuclei in slide order) starts in pinned host memory and is "
+                    "streamed every step in 2048-pixel blocks (copies overlapped with compute, nfx_extract_tile_streamed), rows copied back; timed from the "
+                    "first H2D byte to the last row on the host (SURVEY.md §8d); never the headline value",
+            "rows_equal_resident_tile_rows": same, "pcie_bytes_per_nucleus": round(wire / n, 1),
+            "pcie_bytes_per_nucleus_packed_patch_stream": round(packed, 1), "link_GBps": round(wire * steps / el / 1e9, 2),
+            "blocks_copied": stats["blocks_copied"], "blocks_total": stats["blocks_total"], "chunks": stats["chunks"], "gen_seconds": round(gen_s, 1)}
+
+
 def aten_twin_baseline(args, ps, n):
     """BASELINE.md §3's "restatement of the libtorch-CPU path" for the geometry workload: tests/_twin_baseline.py as a child
     process, run to completion BEFORE this process touches a GPU (its workers are forked CPU processes)."""
@@ -454,6 +503,8 @@ def main():
                         "byte to the last row on the host (SURVEY.md §8d); never the headline value",
                 "host_rows_equal_resident_rows": same}
             del hp, hr
+            # (iii) the same workload fed the way configs[4] asks: the TILE streamed block by block, not packed patches
+            also["streamed_tile"] = streamed_tile_leg(nfx, synth, torch, dist, ctx, dev, "config3", n_local, 0, B, max(2, args.steps // 2), fence)
         # (i) the metric's "full feature set": configs[4] per-GPU shard on every rank (weak scaling, rows gathered to rank 0 for N > 1)
         res = d_out = sx = None
         torch.cuda.empty_cache()
@@ -477,7 +528,11 @@ def main():
                 "roofline": roofline_of(t5, k5, r5, "config5", n5 == WORKLOADS["config5"][0])}
             if ok5 is not None:
                 also["full_feature_set"]["gather_checksums_match"] = bool(all(ok5))
-        r5 = None
+        r5 = o5 = None
+        torch.cuda.empty_cache()
+        if world == 1 and n5 == WORKLOADS["config5"][0]:
+            # BASELINE configs[4] as it says: one GPU's shard of the 10 M-nucleus slide, full feature set, tile streamed over the host link
+            also["streamed_tile_full_set"] = streamed_tile_leg(nfx, synth, torch, dist, ctx, dev, "config5", n5, 0, B, 2, fence)
 
     if rank == 0:
         sharding = "single GPU"

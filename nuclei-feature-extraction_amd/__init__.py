@@ -40,6 +40,7 @@ ABI_SYMBOLS = (
     "nfx_ctx_enable_timing", "nfx_ctx_kernel_timing", "nfx_ctx_reset_timing",
     "nfx_preprocess_polygons", "nfx_rasterize_polygons", "nfx_compute_features_batched",
     "nfx_extract", "nfx_extract_tile", "nfx_gather_patches",
+    "nfx_extract_tile_streamed", "nfx_host_alloc", "nfx_host_free", "nfx_host_register", "nfx_host_unregister",
     "nfx_comm_unique_id", "nfx_comm_create", "nfx_comm_destroy", "nfx_comm_rank", "nfx_comm_world", "nfx_gather_rows",
 )
 
@@ -89,6 +90,14 @@ def lib() -> C.CDLL:
     L.nfx_feature_set_column_dtype.argtypes = [C.c_int, C.c_int]
     L.nfx_polygon_features_f64.argtypes = [vp, i64, i64, u32p, f32p, vp, C.c_int]
     L.nfx_debug_texture_counts.argtypes = [vp, i64, i64, u32p, f32p, u8p, C.c_int, vp, vp, C.c_int]
+    L.nfx_extract_tile_streamed.argtypes = [vp, i32p, C.c_int, i64, i64, u32p, f32p, u8p, i64, i64, C.c_int, C.c_int, C.c_int, i64, i64, f32p, f32p, vp]
+    L.nfx_host_alloc.argtypes = [C.c_size_t]
+    L.nfx_host_alloc.restype = vp
+    L.nfx_host_free.argtypes = [vp]
+    L.nfx_host_free.restype = None
+    L.nfx_host_register.argtypes = [vp, C.c_size_t]
+    L.nfx_host_unregister.argtypes = [vp]
+    L.nfx_host_unregister.restype = None
     L.nfx_comm_unique_id.argtypes = [vp]
     L.nfx_comm_create.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.nfx_comm_destroy.argtypes = [vp]
@@ -376,6 +385,28 @@ class Context:
                                            int(img.shape[1]), int(img.shape[2]), ps, batch_size, _ptr(out), _ptr(cen), int(dev)))
         return out, cen
 
+    def extract_tile_streamed(self, sets: Sequence[int], ring_offsets, ring_xy, image_u8, ps: int, batch_size: int = 100, block: int = 0,
+                              chunk_nuclei: int = 0, cache_bytes: int = 0, out=None):
+        """nfx_extract_tile_streamed: host numpy arrays in (image [3,H,W] u8 -- a :func:`pinned_empty` array for the link's full
+        rate), rows / centroids / what-travelled out.  Bit-identical to :meth:`extract_tile` on the resident image."""
+        off = _prep(ring_offsets, np.uint32, False, "ring_offsets")
+        xy = _prep(ring_xy, np.float32, False, "ring_xy")
+        if not (isinstance(image_u8, np.ndarray) and image_u8.dtype == np.uint8 and image_u8.flags.c_contiguous):
+            image_u8 = _prep(image_u8, np.uint8, False, "image_u8")       # (keeps a pinned array as it is)
+        assert image_u8.ndim == 3 and image_u8.shape[0] == 3, "image must be [3,H,W] u8"
+        n, nv = len(off) - 1, int(xy.shape[0])
+        F = sum(num_columns(s) for s in sets)
+        sets_arr = (C.c_int * len(sets))(*sets)
+        if out is None:
+            out = np.empty((n, F), np.float32)
+        assert out.shape == (n, F) and out.dtype == np.float32 and out.flags.c_contiguous
+        cen = np.empty((n, 2), np.float32)
+        st = (C.c_int64 * 8)()
+        self._check(lib().nfx_extract_tile_streamed(self._h, sets_arr, len(sets), n, nv, _ptr(off), _ptr(xy), _ptr(image_u8), int(image_u8.shape[1]),
+                                                    int(image_u8.shape[2]), ps, batch_size, block, chunk_nuclei, cache_bytes, _ptr(out), _ptr(cen), st))
+        names = ("image_bytes_h2d", "other_bytes_h2d", "rows_bytes_d2h", "blocks_copied", "blocks_total", "block_slots", "chunks", "image_pinned")
+        return out, cen, {k: int(st[j]) for j, k in enumerate(names)}
+
     def gather_patches(self, centroids, image_u8, ps: int):
         dev = _is_torch(image_u8) and image_u8.is_cuda
         cen = _prep(centroids, np.float32, dev, "centroids")
@@ -388,6 +419,32 @@ class Context:
             out = np.empty((n, 3, ps, ps), np.uint8)
         self._check(lib().nfx_gather_patches(self._h, n, _ptr(cen), _ptr(img), int(img.shape[1]), int(img.shape[2]), ps, _ptr(out), int(dev)))
         return out
+
+
+# ---- pinned host memory of libnfx's own HIP runtime (PyTorch's pinned tensors belong to ITS runtime and count as pageable here) ----
+class _PinnedBuffer:
+    def __init__(self, nbytes):
+        self.ptr = lib().nfx_host_alloc(max(1, nbytes))
+        if not self.ptr:
+            raise MemoryError(f"nfx_host_alloc({nbytes})")
+        self.buf = (C.c_uint8 * max(1, nbytes)).from_address(self.ptr)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().nfx_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """An uninitialised numpy array in memory pinned by nfx_host_alloc (freed with the array's last reference)."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    owner = _PinnedBuffer(n)
+    owner.buf._nfx_owner = owner   # the array keeps owner.buf (its base) alive, owner.buf keeps the owner: the memory outlives every view
+    return np.frombuffer(owner.buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 # ---- multi-GPU: the gather of rows over RCCL / xGMI below any framework (nfx_comm_*, nfx_gather_rows) -----------

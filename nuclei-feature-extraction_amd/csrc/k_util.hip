@@ -99,11 +99,16 @@ static __device__ __forceinline__ int64_t rust_f32_as_i64(float v)
 
 // utils.rs:159-191: top/left/bottom/right = trunc(c -/+ ps/2) as i64, clipped to the image; the
 // crop is pasted at (-min(top,0), -min(left,0)) into a zeroed [3,ps,ps] patch.
-__global__ __launch_bounds__(1024) void k_gather_patches(int64_t n, const float *__restrict__ centroids,
-                                                        const uint8_t *__restrict__ image, int64_t H, int64_t W, int ps,
-                                                        int slide_addressing, uint8_t *__restrict__ patches)
+// The source is a WINDOW of the image: rows [wy0, wy0 + wh) x columns [wx0, wx0 + ww) of the H x W image, stored contiguously
+// as [3][wh][ww] (the whole image: window = image).  With `sel`, block b serves nucleus sel[b] of the call (the nuclei whose
+// boxes lie in this window; nfx_stream.cpp streams a slide block by block and gathers per block into one packed patch buffer).
+// A box pixel outside the window reads as 0 (cannot happen when the planner's windows cover their nuclei's boxes; the test
+// only keeps a wrong plan from becoming an out-of-bounds read).
+__global__ __launch_bounds__(1024) void k_gather_patches(int64_t n, const uint32_t *__restrict__ sel, const float *__restrict__ centroids,
+                                                        const uint8_t *__restrict__ image, int64_t H, int64_t W, int64_t wy0, int64_t wx0,
+                                                        int64_t wh, int64_t ww, int ps, int slide_addressing, uint8_t *__restrict__ patches)
 {
-    const int64_t i = blockIdx.x;
+    const int64_t i = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;
     const float cx = centroids[2 * i], cy = centroids[2 * i + 1];
     const float half = (float)ps / 2.0f;
     int64_t t0, l0, b0, r0, oy, ox;
@@ -125,11 +130,15 @@ __global__ __launch_bounds__(1024) void k_gather_patches(int64_t n, const float 
         b0 = bottom < H ? bottom : H, r0 = right < W ? right : W;
         oy = -(top < 0 ? top : 0), ox = -(left < 0 ? left : 0);
     }
+    const bool in_window = t0 >= wy0 && l0 >= wx0 && b0 <= wy0 + wh && r0 <= wx0 + ww;
+    image -= (size_t)wy0 * ww + (size_t)wx0; // window-relative addressing below: ((ch * wh + (row - wy0)) * ww + (col - wx0))
+    H = wh;                                  // (the channel stride of the stored window)
+    W = ww;
     const int P = ps * ps;
     uint8_t *dst = patches + (size_t)i * 3 * P;
     // a window that lies wholly inside the image -- all but the border nuclei -- is 3 ps rows of ps consecutive bytes each
     // way: 16 bytes per thread and trip (one unaligned load, one aligned store) instead of one
-    if (oy == 0 && ox == 0 && b0 - t0 == ps && r0 - l0 == ps && (ps & 15) == 0 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0) {
+    if (in_window && oy == 0 && ox == 0 && b0 - t0 == ps && r0 - l0 == ps && (ps & 15) == 0 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0) {
         const int cpr = ps >> 4; // 16-byte chunks per row
         const int chunks = 3 * ps * cpr;
         // four chunks per thread, all loads before the first store.  (With nuclei in random order over a large slide every
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(1024) void k_gather_patches(int64_t n, const float 
         const int pr = rem / ps, pc = rem - pr * ps;
         const int64_t sr = t0 + (pr - oy), sc = l0 + (pc - ox);
         uint8_t v = 0;
-        if (pr >= oy && pc >= ox && sr < b0 && sc < r0) v = image[((size_t)ch * H + sr) * W + sc];
+        if (in_window && pr >= oy && pc >= ox && sr < b0 && sc < r0) v = image[((size_t)ch * H + sr) * W + sc];
         dst[k] = v;
     }
 }
@@ -191,10 +200,10 @@ hipError_t launch_unpack_masks(nfx_ctx *ctx, int64_t n, const uint64_t *rows, in
     return hipGetLastError();
 }
 
-hipError_t launch_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids, const uint8_t *image, int64_t H,
-                                 int64_t W, int ps, uint8_t *patches)
+hipError_t launch_gather_patches_window(nfx_ctx *ctx, int64_t n_sel, const uint32_t *sel, const float *centroids, const uint8_t *window, int64_t H,
+                                        int64_t W, int64_t wy0, int64_t wx0, int64_t wh, int64_t ww, int ps, uint8_t *patches)
 {
-    if (n == 0) return hipSuccess;
+    if (n_sel == 0) return hipSuccess;
     ScopedTiming t(ctx, KS_GATHER);
     // one block per nucleus; when the 16-byte path applies a thread moves four chunks (128 threads for 48x48, 192 for 64x64)
     int threads = 256;
@@ -203,9 +212,15 @@ hipError_t launch_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids
         threads = ((chunks + 3) / 4 + 63) / 64 * 64; // four chunks per thread
         threads = threads > 1024 ? 1024 : threads;
     }
-    hipLaunchKernelGGL(k_gather_patches, dim3((unsigned)n), dim3((unsigned)threads), 0, ctx->stream, n, centroids, image, H, W, ps,
-                       ctx->addressing == NFX_ADDR_SLIDE ? 1 : 0, patches);
+    hipLaunchKernelGGL(k_gather_patches, dim3((unsigned)n_sel), dim3((unsigned)threads), 0, ctx->stream, n_sel, sel, centroids, window, H, W, wy0, wx0,
+                       wh, ww, ps, ctx->addressing == NFX_ADDR_SLIDE ? 1 : 0, patches);
     return hipGetLastError();
+}
+
+hipError_t launch_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids, const uint8_t *image, int64_t H,
+                                 int64_t W, int ps, uint8_t *patches)
+{
+    return launch_gather_patches_window(ctx, n, nullptr, centroids, image, H, W, 0, 0, H, W, ps, patches);
 }
 
 }  // namespace nfx

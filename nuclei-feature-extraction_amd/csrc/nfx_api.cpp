@@ -145,19 +145,16 @@ int nfx_centroid_key(float x, float y, char *buf, size_t buflen)
 // ------------------------------------------------------------------------------------------------
 // context, workspace, timing
 // ------------------------------------------------------------------------------------------------
-static nfx_status fail(nfx_ctx *ctx, nfx_status st, const std::string &msg)
+namespace nfx {
+nfx_status api_fail(nfx_ctx *ctx, nfx_status st, const std::string &msg)
 {
     if (ctx) ctx->err = msg;
     return st;
 }
+}  // namespace nfx
+static nfx_status fail(nfx_ctx *ctx, nfx_status st, const std::string &msg) { return nfx::api_fail(ctx, st, msg); }
 
-#define NFX_HIP(ctx, expr)                                                                                 \
-    do {                                                                                                   \
-        hipError_t e_ = (expr);                                                                            \
-        if (e_ != hipSuccess)                                                                              \
-            return fail(ctx, e_ == hipErrorOutOfMemory ? NFX_ERR_OUT_OF_MEMORY : NFX_ERR_DEVICE,           \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                                \
-    } while (0)
+// (NFX_HIP is defined in nfx_internal.h)
 
 namespace nfx {
 
@@ -224,7 +221,6 @@ nfx_status ws_reserve(nfx_ctx *ctx, size_t bytes, nfx_mem mem)
     return arena_grow(ctx, a, bytes);
 }
 
-static size_t al(size_t b) { return (b + 255) & ~size_t(255); }
 
 void *ws_alloc(nfx_ctx *ctx, size_t bytes)
 {
@@ -308,6 +304,12 @@ void nfx_ctx_destroy(nfx_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->rows_stream) { (void)hipStreamSynchronize(ctx->rows_stream); (void)hipStreamDestroy(ctx->rows_stream); }
+    for (int b = 0; b < 2; ++b)
+        for (hipEvent_t e : {ctx->ev_ready[b], ctx->ev_done[b], ctx->ev_rows[b], ctx->ev_bounce[b]})
+            if (e) (void)hipEventDestroy(e);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (auto &t : ctx->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
@@ -381,7 +383,8 @@ nfx_status nfx_ctx_reset_timing(nfx_ctx *ctx)
 // ------------------------------------------------------------------------------------------------
 // device-resident orchestration
 // ------------------------------------------------------------------------------------------------
-static nfx_status check_common(nfx_ctx *ctx, int64_t n, int64_t nv, int ps)
+namespace nfx {
+nfx_status check_common(nfx_ctx *ctx, int64_t n, int64_t nv, int ps)
 {
     if (!ctx) return NFX_ERR_INVALID_ARGUMENT;
     if (n < 0 || nv < 0) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "negative size");
@@ -392,7 +395,7 @@ static nfx_status check_common(nfx_ctx *ctx, int64_t n, int64_t nv, int ps)
 }
 
 // host-memory offsets are validated before anything is launched: the kernels index the vertex array with them
-static nfx_status check_offsets(nfx_ctx *ctx, const uint32_t *off, int64_t n, int64_t nv, const char *what)
+nfx_status check_offsets(nfx_ctx *ctx, const uint32_t *off, int64_t n, int64_t nv, const char *what)
 {
     if (off[0] != 0u) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, std::string(what) + "[0] != 0");
     for (int64_t i = 0; i < n; ++i)
@@ -401,30 +404,7 @@ static nfx_status check_offsets(nfx_ctx *ctx, const uint32_t *off, int64_t n, in
     return NFX_OK;
 }
 
-// A synchronous (host-memory) call runs on the context's own stream and in the context's host arena (its staging buffers and
-// scratch never touch the workspace of the device-memory calls, whose addresses a captured graph may hold).  It first waits
-// for whatever the caller still has in flight on the device-call stream: both kinds of call share the device tables.
-struct StreamScope {
-    nfx_ctx *ctx;
-    hipStream_t saved;
-    StreamScope(nfx_ctx *c, nfx_mem mem) : ctx(c), saved(c->stream)
-    {
-        c->call_mem = mem;
-        c->ws = mem == NFX_MEM_HOST ? &c->host_ws : &c->dev_ws;
-        if (mem == NFX_MEM_HOST && c->own_stream) {
-            (void)hipStreamSynchronize(saved);
-            c->stream = c->own_stream;
-        }
-    }
-    ~StreamScope()
-    {
-        ctx->stream = saved;
-        ctx->ws = &ctx->dev_ws;
-        ctx->call_mem = NFX_MEM_DEVICE;
-    }
-};
-
-static int sets_total_columns(const int *sets, int n_sets)
+int sets_total_columns(const int *sets, int n_sets)
 {
     int F = 0;
     for (int s = 0; s < n_sets; ++s) {
@@ -434,14 +414,14 @@ static int sets_total_columns(const int *sets, int n_sets)
     return F;
 }
 
-static bool any_pixel_set(const int *sets, int n_sets)
+bool any_pixel_set(const int *sets, int n_sets)
 {
     for (int s = 0; s < n_sets; ++s)
         if (sets[s] != NFX_SET_GEOMETRY) return true;
     return false;
 }
 
-static int count_set(const int *sets, int n_sets, int which)
+int count_set(const int *sets, int n_sets, int which)
 {
     int c = 0;
     for (int s = 0; s < n_sets; ++s) c += sets[s] == which;
@@ -449,7 +429,7 @@ static int count_set(const int *sets, int n_sets, int which)
 }
 
 // workspace bytes needed by extract_device (excluding host staging): mirrors its ws_alloc calls one for one
-static size_t extract_ws_bytes(const int *sets, int n_sets, int64_t n, int64_t nv, int ps, int batch_size, bool need_centroids,
+size_t extract_ws_bytes(const int *sets, int n_sets, int64_t n, int64_t nv, int ps, int batch_size, bool need_centroids,
                                bool gather)
 {
     size_t b = 0;
@@ -465,7 +445,7 @@ static size_t extract_ws_bytes(const int *sets, int n_sets, int64_t n, int64_t n
     return b + 4096;
 }
 
-static nfx_status prepare_sets(nfx_ctx *ctx, const int *sets, int n_sets)
+nfx_status prepare_sets(nfx_ctx *ctx, const int *sets, int n_sets)
 {
     if (count_set(sets, n_sets, NFX_SET_COLOR)) NFX_HIP(ctx, prepare_color(ctx));
     if (count_set(sets, n_sets, NFX_SET_GLCM)) NFX_HIP(ctx, prepare_glcm(ctx));
@@ -561,8 +541,8 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
     return NFX_OK;
 }
 
-static nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_off,
-                                 const float *ring_xy, const uint8_t *patches_u8, const uint8_t *image, int64_t H, int64_t W,
+nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_off,
+                          const float *ring_xy, const uint8_t *patches_u8, const uint8_t *image, int64_t H, int64_t W,
                                  int ps, int batch_size, float *out_rows, float *out_centroids)
 {
     bool forked = false;
@@ -577,6 +557,8 @@ static nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int6
     }
     return st;
 }
+
+}  // namespace nfx
 
 // host staging helper: copies src (host) into the workspace
 template <typename T>

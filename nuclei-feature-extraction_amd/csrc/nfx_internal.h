@@ -50,6 +50,11 @@ struct nfx_ctx {
                                       // different host threads overlap on the GPU instead of queueing on the default stream
     hipStream_t side_stream = nullptr; // the polygon kernel (64 serial programs per wave: latency-bound, hardly any issue slots) runs
     hipEvent_t ev_fork = nullptr, ev_join = nullptr; // here, beside the rasteriser and the pixel kernels of the same call
+    // nfx_extract_tile_streamed (nfx_stream.cpp): block copies + window gathers | rows back to the host, created on first use
+    hipStream_t copy_stream = nullptr, rows_stream = nullptr;
+    hipEvent_t ev_ready[2] = {}, ev_done[2] = {}, ev_rows[2] = {}, ev_bounce[2] = {};
+    void *pin = nullptr;      // grow-only pinned host staging (selection lists, rebased offsets, bounce blocks of a pageable image)
+    size_t pin_cap = 0;
     nfx_addressing addressing = NFX_ADDR_IMAGE;
     std::string err;
     // Two grow-only device workspaces with a bump pointer each, rewound at the start of every API call:
@@ -98,6 +103,52 @@ struct Job {
     uint32_t *dbg_glrlm = nullptr;      // [n][4 directions][24][16]
 };
 
+// ---- shared by the API translation units (nfx_api.cpp, nfx_stream.cpp) -----------------------------------------------------
+nfx_status api_fail(nfx_ctx *ctx, nfx_status st, const std::string &msg);
+#define NFX_HIP(ctx, expr)                                                                                 \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return nfx::api_fail(ctx, e_ == hipErrorOutOfMemory ? NFX_ERR_OUT_OF_MEMORY : NFX_ERR_DEVICE,  \
+                                 std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+static inline size_t al(size_t b) { return (b + 255) & ~size_t(255); } // workspace allocations are 256-byte aligned
+nfx_status check_common(nfx_ctx *ctx, int64_t n, int64_t nv, int ps);
+nfx_status check_offsets(nfx_ctx *ctx, const uint32_t *off, int64_t n, int64_t nv, const char *what);
+int sets_total_columns(const int *sets, int n_sets);
+bool any_pixel_set(const int *sets, int n_sets);
+int count_set(const int *sets, int n_sets, int which);
+// workspace bytes of one extract_device call (excluding staging): mirrors its ws_alloc calls one for one
+size_t extract_ws_bytes(const int *sets, int n_sets, int64_t n, int64_t nv, int ps, int batch_size, bool need_centroids, bool gather);
+nfx_status prepare_sets(nfx_ctx *ctx, const int *sets, int n_sets);
+// everything on the device, workspace reserved by the caller (bump-allocates from ctx->ws; joins its own side-stream fork)
+nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_off, const float *ring_xy,
+                          const uint8_t *patches_u8, const uint8_t *image, int64_t H, int64_t W, int ps, int batch_size, float *out_rows,
+                          float *out_centroids);
+
+// A synchronous (host-memory) call runs on the context's own stream and in the context's host arena (its staging buffers and
+// scratch never touch the workspace of the device-memory calls, whose addresses a captured graph may hold).  It first waits
+// for whatever the caller still has in flight on the device-call stream: both kinds of call share the device tables.
+struct StreamScope {
+    nfx_ctx *ctx;
+    hipStream_t saved;
+    StreamScope(nfx_ctx *c, nfx_mem mem) : ctx(c), saved(c->stream)
+    {
+        c->call_mem = mem;
+        c->ws = mem == NFX_MEM_HOST ? &c->host_ws : &c->dev_ws;
+        if (mem == NFX_MEM_HOST && c->own_stream) {
+            (void)hipStreamSynchronize(saved);
+            c->stream = c->own_stream;
+        }
+    }
+    ~StreamScope()
+    {
+        ctx->stream = saved;
+        ctx->ws = &ctx->dev_ws;
+        ctx->call_mem = NFX_MEM_DEVICE;
+    }
+};
+
 // RAII-less helpers ---------------------------------------------------------------------------
 // make capacity >= bytes and rewind the bump pointer (only before ws_alloc calls).  Growing reallocates (synchronise +
 // free + malloc): refused for device-memory calls on a reserved context or during stream capture
@@ -132,6 +183,10 @@ hipError_t launch_pack_masks(nfx_ctx *ctx, int64_t n, const float *masks_f32, in
 hipError_t launch_unpack_masks(nfx_ctx *ctx, int64_t n, const uint64_t *rows, int ps, float *masks_f32);
 hipError_t launch_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids, const uint8_t *image, int64_t H,
                                  int64_t W, int ps, uint8_t *patches);
+// the same out of a WINDOW of the image (rows [wy0, wy0+wh) x columns [wx0, wx0+ww), stored [3][wh][ww]) for the nuclei sel[0..n_sel)
+// of the call (nullptr: nuclei 0..n_sel): patch of nucleus i lands at patches[i]
+hipError_t launch_gather_patches_window(nfx_ctx *ctx, int64_t n_sel, const uint32_t *sel, const float *centroids, const uint8_t *window, int64_t H,
+                                        int64_t W, int64_t wy0, int64_t wx0, int64_t wh, int64_t ww, int ps, uint8_t *patches);
 
 hipError_t launch_color(nfx_ctx *ctx, const Job &job, int col0, void *scratch);
 size_t color_scratch_bytes(const Job &job);

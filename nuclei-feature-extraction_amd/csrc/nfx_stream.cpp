@@ -1,0 +1,326 @@
+// nfx_stream.cpp -- nfx_extract_tile_streamed: the slide streamed BLOCK BY BLOCK, host -> device copies overlapped with compute.
+//
+// Replaces (reference file:line): the per-batch pipeline stage of main.rs:146-151 on a slide that does not have to be resident --
+// load_image_dataset's crop of every nucleus's window out of the image (utils.rs:141-206), move_tensors_to_device (utils.rs:211-224:
+// a synchronous copy of two f32 tensors, 16 ps^2 bytes per nucleus) and the feature sets.  BASELINE.json configs[4]: "WSI-scale 10M
+// nuclei, 64 x 64 patches, full feature set, streamed tile H2D overlapped with compute".
+//
+// What travels over the host link is the TILE, cut into square blocks (2048^2 by default, each with a patch-size halo to the
+// right and below so that every nucleus's window lies inside the block its top-left corner falls in): 3 bytes per slide pixel,
+// i.e. (ps/1.5)^2 x 3 bytes per nucleus at the density of the synthetic slides -- 2.25x fewer than packed patches (3 ps^2), 12x
+// fewer than the reference's f32 patch + mask tensors.  The reference's batch partition is kept (the hue mean couples the
+// nuclei of a batch, color.rs:144-155): nuclei are processed in index order in CHUNKS of whole batches; a chunk runs when every
+// block it touches is resident.  Segmentation tools emit nuclei tile by tile, so a chunk touches one or a few blocks; any
+// order is correct (a block that is needed again after it was evicted is copied again; the device keeps as many blocks as
+// `cache_bytes` allows -- the whole slide, typically).
+//
+//   copy stream    : H2D blocks of chunk k+1 | gather their nuclei's windows into patches[(k+1)&1]
+//   compute stream :              extract(chunk k) from patches[k&1] -> rows[k&1]
+//   rows stream    :                                   D2H rows of chunk k-1
+//
+// Results are bit-identical to nfx_extract_tile on the resident image: the same gather kernel fills the same packed patches, the
+// same extraction runs on the same batches.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "nfx_internal.h"
+
+using namespace nfx;
+
+namespace {
+
+// (c - ps/2) as the two loaders turn it into the window's first row / column (k_util.hip: same f32 arithmetic, same casts)
+int64_t rust_f32_as_i64_host(float v)
+{
+    if (v != v) return 0;
+    const float lim = 1099511627776.0f; // 2^40
+    return v >= lim ? (int64_t)1 << 40 : (v <= -lim ? -((int64_t)1 << 40) : (int64_t)v);
+}
+int64_t window_origin(float c, float half, bool slide)
+{
+    const float v = c - half;
+    if (slide) return v >= 4294967296.0f ? 4294967295ll : (v > 0.0f ? (int64_t)v : 0ll); // `as u32`, utils.rs:104-105
+    const int64_t t = rust_f32_as_i64_host(v);                                            // `as i64`, utils.rs:159-162
+    return t > 0 ? t : 0;
+}
+
+bool is_pinned(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+struct Pinned { // grow-only pinned staging kept by the context
+    static void *get(nfx_ctx *ctx, size_t bytes)
+    {
+        if (bytes <= ctx->pin_cap) return ctx->pin;
+        if (ctx->pin) (void)hipHostFree(ctx->pin);
+        ctx->pin = nullptr; ctx->pin_cap = 0;
+        if (hipHostMalloc(&ctx->pin, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->pin = nullptr; return nullptr; }
+        ctx->pin_cap = bytes;
+        return ctx->pin;
+    }
+};
+
+struct Chunk {
+    int64_t i0, i1;                  // nuclei
+    std::vector<int64_t> blocks;     // distinct blocks its windows start in, ascending
+    std::vector<uint32_t> sel;       // chunk-relative nucleus indices grouped by block (same order as `blocks`)
+    std::vector<uint32_t> sel_off;   // blocks.size() + 1 offsets into sel
+};
+
+} // namespace
+
+extern "C" {
+
+void *nfx_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void nfx_host_free(void *p) { if (p) (void)hipHostFree(p); }
+nfx_status nfx_host_register(void *p, size_t bytes)
+{
+    if (!p) return NFX_ERR_INVALID_ARGUMENT;
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e == hipSuccess || e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return NFX_OK; }
+    (void)hipGetLastError();
+    return NFX_ERR_DEVICE;
+}
+void nfx_host_unregister(void *p) { if (p && hipHostUnregister(p) != hipSuccess) (void)hipGetLastError(); }
+
+nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_offsets,
+                                     const float *ring_xy, const uint8_t *image_u8, int64_t H, int64_t W, int ps, int batch_size, int block,
+                                     int64_t chunk_nuclei, int64_t cache_bytes, float *out_rows, float *out_centroids_xy, nfx_stream_stats *stats)
+{
+    if (stats) memset(stats, 0, sizeof(*stats));
+    nfx_status st = check_common(ctx, n, nv, ps);
+    if (st != NFX_OK) return st;
+    if (!sets || n_sets <= 0) return api_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "no feature set selected");
+    const int F = sets_total_columns(sets, n_sets);
+    if (F < 0) return api_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "unknown feature set");
+    if (batch_size < 1) return api_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "batch_size must be >= 1");
+    if (!ring_offsets || (nv && !ring_xy) || !out_rows) return api_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null input");
+    const bool pix = any_pixel_set(sets, n_sets);
+    if (!pix || n == 0) // nothing to stream: geometry needs no pixels
+        return nfx_extract(ctx, sets, n_sets, n, nv, ring_offsets, ring_xy, nullptr, ps, batch_size, out_rows, out_centroids_xy, NFX_MEM_HOST);
+    if (!image_u8 || H < 1 || W < 1) return api_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null or empty image");
+    if (ps > NFX_ROW_WORD_PS && false) return NFX_ERR_UNSUPPORTED;
+    NFX_HIP(ctx, hipSetDevice(ctx->device));
+    StreamScope scope(ctx, NFX_MEM_HOST); // ctx->stream = the context's own stream (the compute stream below), host arena
+    if ((st = check_offsets(ctx, ring_offsets, n, nv, "ring_offsets")) != NFX_OK) return st;
+    if (!ctx->copy_stream) NFX_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->rows_stream) NFX_HIP(ctx, hipStreamCreateWithFlags(&ctx->rows_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b)
+        for (hipEvent_t *e : {&ctx->ev_ready[b], &ctx->ev_done[b], &ctx->ev_rows[b], &ctx->ev_bounce[b]})
+            if (!*e) NFX_HIP(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    hipStream_t const compute = ctx->stream, copy = ctx->copy_stream, rows_s = ctx->rows_stream;
+    const bool slide = ctx->addressing == NFX_ADDR_SLIDE;
+
+    // ---- geometry of the plan ---------------------------------------------------------------------------------------------
+    const int64_t B = block > 0 ? (block < 64 ? 64 : block) : 2048;
+    const int64_t nbx = (W + B - 1) / B, nby = (H + B - 1) / B, nblocks = nbx * nby;
+    const int64_t sh = std::min<int64_t>(H, B + ps), sw = std::min<int64_t>(W, B + ps); // a block's window: B + halo, clipped to the image
+    const size_t slot_bytes = al(3 * (size_t)sh * sw);
+    const int64_t chunk_max = std::max<int64_t>(batch_size, ((chunk_nuclei > 0 ? chunk_nuclei : 100000) / batch_size) * batch_size);
+    const int64_t chunk_cap = std::min<int64_t>(chunk_max, ((n + batch_size - 1) / batch_size) * batch_size);
+    // a chunk of ONE batch must fit whatever its nuclei's order: one slot per nucleus of a batch at least (or the whole slide)
+    const int64_t want_slots = cache_bytes > 0 ? cache_bytes / (int64_t)slot_bytes : ((int64_t)16 << 30) / (int64_t)slot_bytes;
+    const int64_t n_slots = std::min<int64_t>(nblocks, std::max<int64_t>(std::max<int64_t>(want_slots, 4), std::min<int64_t>(batch_size, nblocks)));
+
+    // ---- stage the rings, centroids of every nucleus (k_preprocess: the arithmetic that addresses the windows) ------------------
+    const size_t P3 = 3 * (size_t)ps * ps;
+    size_t max_chunk_nv = 0; // vertices of the largest possible chunk: any run of chunk_cap nuclei
+    for (int64_t i0 = 0; i0 < n; i0 += batch_size) {
+        const int64_t i1 = std::min<int64_t>(n, i0 + chunk_cap);
+        max_chunk_nv = std::max<size_t>(max_chunk_nv, (size_t)(ring_offsets[i1] - ring_offsets[i0]));
+    }
+    const size_t scratch = extract_ws_bytes(sets, n_sets, chunk_cap, (int64_t)max_chunk_nv, ps, batch_size, false, false);
+    size_t need = al(4 * ((size_t)n + 1)) + al(8 * (size_t)nv + 8) + al(8 * (size_t)n + 8) + (size_t)n_slots * slot_bytes +
+                  2 * al((size_t)chunk_cap * P3) + 2 * al(4 * (size_t)chunk_cap * F + 8) + 2 * al(4 * (size_t)chunk_cap + 8) +
+                  2 * al(4 * ((size_t)chunk_cap + 1)) + al(scratch) + 8192;
+    if ((st = ws_reserve(ctx, need, NFX_MEM_HOST)) != NFX_OK) return st;
+    uint32_t *d_off_all = (uint32_t *)ws_alloc(ctx, 4 * ((size_t)n + 1));
+    float *d_xy = (float *)ws_alloc(ctx, 8 * (size_t)nv + 8);
+    float *d_cen = (float *)ws_alloc(ctx, 8 * (size_t)n + 8);
+    uint8_t *d_slots = (uint8_t *)ws_alloc(ctx, (size_t)n_slots * slot_bytes);
+    uint8_t *d_patches[2]; float *d_rows[2]; uint32_t *d_sel[2], *d_off[2];
+    for (int b = 0; b < 2; ++b) {
+        d_patches[b] = (uint8_t *)ws_alloc(ctx, (size_t)chunk_cap * P3);
+        d_rows[b] = (float *)ws_alloc(ctx, 4 * (size_t)chunk_cap * F + 8);
+        d_sel[b] = (uint32_t *)ws_alloc(ctx, 4 * (size_t)chunk_cap + 8);
+        d_off[b] = (uint32_t *)ws_alloc(ctx, 4 * ((size_t)chunk_cap + 1));
+    }
+    if (!d_off_all || !d_xy || !d_cen || !d_slots || !d_patches[1] || !d_rows[1] || !d_sel[1] || !d_off[1])
+        return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    const size_t ws_mark = ctx->ws->off; // every chunk's extraction bump-allocates its scratch from here
+    if (ctx->ws->cap - ws_mark < scratch) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    if ((st = prepare_sets(ctx, sets, n_sets)) != NFX_OK) return st;
+    NFX_HIP(ctx, hipMemcpyAsync(d_off_all, ring_offsets, 4 * ((size_t)n + 1), hipMemcpyHostToDevice, compute));
+    if (nv) NFX_HIP(ctx, hipMemcpyAsync(d_xy, ring_xy, 8 * (size_t)nv, hipMemcpyHostToDevice, compute));
+    NFX_HIP(ctx, launch_preprocess(ctx, n, d_off_all, d_xy, d_cen, nullptr));
+    std::vector<float> cen(2 * (size_t)n);
+    NFX_HIP(ctx, hipMemcpyAsync(cen.data(), d_cen, 8 * (size_t)n, hipMemcpyDeviceToHost, compute));
+    NFX_HIP(ctx, hipStreamSynchronize(compute));
+    if (out_centroids_xy) memcpy(out_centroids_xy, cen.data(), 8 * (size_t)n);
+    int64_t other_h2d = 4 * (n + 1) + 8 * nv;
+
+    // ---- the plan: every nucleus's block, chunks of whole batches whose blocks fit the cache ----------------------------------
+    const float half = (float)ps / 2.0f;
+    std::vector<int64_t> blk((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t t0 = window_origin(cen[2 * i + 1], half, slide), l0 = window_origin(cen[2 * i], half, slide);
+        t0 = std::min<int64_t>(t0, H - 1); l0 = std::min<int64_t>(l0, W - 1); // a window that starts past the image reads nothing: any block will do
+        blk[i] = (t0 / B) * nbx + l0 / B;
+    }
+    std::vector<Chunk> chunks;
+    {
+        std::vector<int64_t> seen_at((size_t)nblocks, -1); // chunk index a block was last added to
+        int64_t i = 0;
+        while (i < n) {
+            Chunk c; c.i0 = i;
+            const int64_t ck = (int64_t)chunks.size();
+            int64_t distinct = 0;
+            while (i < n && i - c.i0 < chunk_cap) {
+                const int64_t e = std::min<int64_t>(n, i + batch_size);
+                int64_t add = 0;
+                for (int64_t j = i; j < e; ++j) if (seen_at[blk[j]] != ck && seen_at[blk[j]] != -2 - ck) { seen_at[blk[j]] = -2 - ck; ++add; }
+                if (i > c.i0 && distinct + add > n_slots) { // this batch does not fit beside the chunk's blocks: it opens the next chunk
+                    for (int64_t j = i; j < e; ++j) if (seen_at[blk[j]] == -2 - ck) seen_at[blk[j]] = -1;
+                    break;
+                }
+                for (int64_t j = i; j < e; ++j) if (seen_at[blk[j]] == -2 - ck) seen_at[blk[j]] = ck;
+                distinct += add;
+                i = e;
+            }
+            c.i1 = i;
+            std::vector<std::pair<int64_t, uint32_t>> order;
+            order.reserve((size_t)(c.i1 - c.i0));
+            for (int64_t j = c.i0; j < c.i1; ++j) order.emplace_back(blk[j], (uint32_t)(j - c.i0));
+            std::sort(order.begin(), order.end());
+            for (size_t q = 0; q < order.size(); ++q) {
+                if (q == 0 || order[q].first != order[q - 1].first) { c.blocks.push_back(order[q].first); c.sel_off.push_back((uint32_t)q); }
+                c.sel.push_back(order[q].second);
+            }
+            c.sel_off.push_back((uint32_t)order.size());
+            if ((int64_t)c.blocks.size() > n_slots) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "one reference batch touches more blocks than the block cache holds");
+            chunks.push_back(std::move(c));
+        }
+    }
+
+    // ---- pinned staging: selection lists and rebased offsets of two chunks; two bounce blocks if the image is pageable -----------
+    const bool img_pinned = is_pinned(image_u8);
+    const size_t stage_bytes = 2 * (4 * (size_t)chunk_cap + 4 * ((size_t)chunk_cap + 1) + 64) + (img_pinned ? 0 : 2 * slot_bytes);
+    uint8_t *pin = (uint8_t *)Pinned::get(ctx, stage_bytes);
+    if (!pin) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "pinned staging");
+    uint32_t *h_sel[2], *h_off[2]; uint8_t *h_bounce[2] = {nullptr, nullptr};
+    {
+        uint8_t *q = pin;
+        for (int b = 0; b < 2; ++b) { h_sel[b] = (uint32_t *)q; q += 4 * (size_t)chunk_cap + 32; h_off[b] = (uint32_t *)q; q += 4 * ((size_t)chunk_cap + 1) + 32; }
+        if (!img_pinned) { q = pin + ((q - pin + 255) & ~(size_t)255); h_bounce[0] = q; h_bounce[1] = q + slot_bytes; }
+    }
+    int bounce_turn = 0;
+    bool bounce_used[2] = {false, false};
+
+    // ---- block cache ---------------------------------------------------------------------------------------------------------
+    std::vector<int64_t> slot_block((size_t)n_slots, -1), slot_use((size_t)n_slots, -1), block_slot((size_t)nblocks, -1);
+    int64_t img_h2d = 0, blocks_copied = 0, rows_d2h = 0;
+
+    auto fail_sync = [&](nfx_status s) { // an error mid-way: nothing may still be in flight on the private streams when the call returns
+        (void)hipStreamSynchronize(copy); (void)hipStreamSynchronize(compute); (void)hipStreamSynchronize(rows_s);
+        return s;
+    };
+#define NFX_HIP_S(expr)                                                                                                                  \
+    do {                                                                                                                                 \
+        hipError_t e_ = (expr);                                                                                                          \
+        if (e_ != hipSuccess)                                                                                                            \
+            return fail_sync(api_fail(ctx, e_ == hipErrorOutOfMemory ? NFX_ERR_OUT_OF_MEMORY : NFX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_))); \
+    } while (0)
+
+    auto enqueue_copy = [&](int64_t k) -> nfx_status { // H2D of chunk k's missing blocks + the gathers of its windows, on the copy stream
+        const Chunk &c = chunks[(size_t)k];
+        const int b = (int)(k & 1);
+        const int64_t m = c.i1 - c.i0;
+        if (k >= 2) NFX_HIP_S(hipEventSynchronize(ctx->ev_done[b])); // extract(k-2) has finished: patches[b], sel[b], off[b] and their staging are free
+        memcpy(h_sel[b], c.sel.data(), 4 * (size_t)m);
+        const uint32_t v0 = ring_offsets[c.i0];
+        for (int64_t j = 0; j <= m; ++j) h_off[b][j] = ring_offsets[c.i0 + j] - v0;
+        NFX_HIP_S(hipMemcpyAsync(d_sel[b], h_sel[b], 4 * (size_t)m, hipMemcpyHostToDevice, copy));
+        NFX_HIP_S(hipMemcpyAsync(d_off[b], h_off[b], 4 * ((size_t)m + 1), hipMemcpyHostToDevice, copy));
+        other_h2d += 8 * m + 4;
+        for (size_t q = 0; q < c.blocks.size(); ++q) if (block_slot[c.blocks[q]] >= 0) slot_use[block_slot[c.blocks[q]]] = k;
+        for (size_t q = 0; q < c.blocks.size(); ++q) {
+            const int64_t bid = c.blocks[q];
+            const int64_t by = bid / nbx, bx = bid % nbx;
+            const int64_t wy0 = by * B, wx0 = bx * B, wh = std::min<int64_t>(H - wy0, B + ps), ww = std::min<int64_t>(W - wx0, B + ps);
+            int64_t s = block_slot[bid];
+            if (s < 0) { // not resident: take the slot that has gone unused longest (never one this chunk needs)
+                s = 0;
+                for (int64_t t = 1; t < n_slots; ++t) if (slot_use[t] < slot_use[s]) s = t;
+                if (slot_use[s] == k) return fail_sync(api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "block cache too small for one chunk"));
+                if (slot_block[s] >= 0) block_slot[slot_block[s]] = -1;
+                slot_block[s] = bid; block_slot[bid] = s; slot_use[s] = k;
+                uint8_t *dst = d_slots + (size_t)s * slot_bytes;
+                if (img_pinned) {
+                    for (int ch = 0; ch < 3; ++ch)
+                        NFX_HIP_S(hipMemcpy2DAsync(dst + (size_t)ch * wh * ww, (size_t)ww, image_u8 + ((size_t)ch * H + wy0) * W + wx0, (size_t)W, (size_t)ww, (size_t)wh,
+                                                   hipMemcpyHostToDevice, copy));
+                } else { // pageable image: the block is packed into a pinned bounce buffer by the host, then copied in one piece
+                    const int t = bounce_turn; bounce_turn ^= 1;
+                    if (bounce_used[t]) NFX_HIP_S(hipEventSynchronize(ctx->ev_bounce[t]));
+                    for (int ch = 0; ch < 3; ++ch)
+                        for (int64_t r = 0; r < wh; ++r)
+                            memcpy(h_bounce[t] + ((size_t)ch * wh + r) * ww, image_u8 + ((size_t)ch * H + wy0 + r) * W + wx0, (size_t)ww);
+                    NFX_HIP_S(hipMemcpyAsync(dst, h_bounce[t], 3 * (size_t)wh * ww, hipMemcpyHostToDevice, copy));
+                    NFX_HIP_S(hipEventRecord(ctx->ev_bounce[t], copy));
+                    bounce_used[t] = true;
+                }
+                img_h2d += 3 * wh * ww;
+                ++blocks_copied;
+            }
+            ctx->stream = copy;
+            const hipError_t ge = launch_gather_patches_window(ctx, c.sel_off[q + 1] - c.sel_off[q], d_sel[b] + c.sel_off[q], d_cen + 2 * c.i0,
+                                                               d_slots + (size_t)s * slot_bytes, H, W, wy0, wx0, wh, ww, ps, d_patches[b]);
+            ctx->stream = compute;
+            NFX_HIP_S(ge);
+        }
+        NFX_HIP_S(hipEventRecord(ctx->ev_ready[b], copy));
+        return NFX_OK;
+    };
+
+    const int64_t nchunks = (int64_t)chunks.size();
+    if (nchunks && (st = enqueue_copy(0)) != NFX_OK) return st;
+    for (int64_t k = 0; k < nchunks; ++k) {
+        const Chunk &c = chunks[(size_t)k];
+        const int b = (int)(k & 1);
+        const int64_t m = c.i1 - c.i0;
+        if (k + 1 < nchunks && (st = enqueue_copy(k + 1)) != NFX_OK) return st; // the next chunk's blocks travel while this one computes
+        NFX_HIP_S(hipStreamWaitEvent(compute, ctx->ev_ready[b], 0));
+        if (k >= 2) NFX_HIP_S(hipStreamWaitEvent(compute, ctx->ev_rows[b], 0)); // rows[b] of chunk k-2 have left for the host
+        ctx->ws->off = ws_mark;
+        const uint32_t v0 = ring_offsets[c.i0], v1 = ring_offsets[c.i1];
+        st = extract_device(ctx, sets, n_sets, m, (int64_t)(v1 - v0), d_off[b], d_xy + 2 * (size_t)v0, d_patches[b], nullptr, 0, 0, ps, batch_size, d_rows[b], nullptr);
+        if (st != NFX_OK) return fail_sync(st);
+        NFX_HIP_S(hipEventRecord(ctx->ev_done[b], compute));
+        NFX_HIP_S(hipStreamWaitEvent(rows_s, ctx->ev_done[b], 0));
+        NFX_HIP_S(hipMemcpyAsync(out_rows + (size_t)c.i0 * F, d_rows[b], 4 * (size_t)m * F, hipMemcpyDeviceToHost, rows_s));
+        NFX_HIP_S(hipEventRecord(ctx->ev_rows[b], rows_s));
+        rows_d2h += 4 * m * F;
+    }
+#undef NFX_HIP_S
+    NFX_HIP(ctx, hipStreamSynchronize(copy));
+    NFX_HIP(ctx, hipStreamSynchronize(compute));
+    NFX_HIP(ctx, hipStreamSynchronize(rows_s));
+    if (stats) {
+        stats->image_bytes_h2d = img_h2d; stats->other_bytes_h2d = other_h2d; stats->rows_bytes_d2h = rows_d2h + 8 * n;
+        stats->blocks_copied = blocks_copied; stats->blocks_total = nblocks; stats->chunks = nchunks; stats->block_slots = n_slots;
+        stats->image_pinned = img_pinned ? 1 : 0;
+    }
+    return NFX_OK;
+}
+
+} // extern "C"

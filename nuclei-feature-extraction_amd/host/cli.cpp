@@ -8,7 +8,9 @@
 // Differences, all stated at run time: there is no CPU compute path (without -g the engine uses GPU 0);
 // rows come out in input order (the reference's order is batch-completion order); csv, json, parquet/pqt and
 // ipc/feather writers (columnar.hpp); only .png slides decode here (no JPEG / OpenSlide in this image).
-// The whole slide's nuclei are extracted by ONE nfx_extract_tile call per GPU -- 288 GB of HBM holds them.
+// Every GPU extracts its index shard through nfx_extract_tile_streamed: the slide travels block by block (only the blocks the
+// shard's nuclei touch), chunks of whole reference batches are extracted while the next chunk's blocks are on their way --
+// no `n x 3 ps^2` patch workspace and no per-GPU copy of the whole slide, whatever the number of nuclei.
 #include <algorithm>
 #include <charconv>
 #include <chrono>
@@ -239,10 +241,14 @@ int main(int argc, char **argv)
                 std::vector<uint32_t> off((size_t)(i1 - i0 + 1));
                 const uint32_t base = poly.ring_offsets[(size_t)i0];
                 for (int64_t i = i0; i <= i1; ++i) off[(size_t)(i - i0)] = poly.ring_offsets[(size_t)i] - base;
-                const nfx_status st = nfx_extract_tile(ctxs[(size_t)r], sets.data(), n_sets, i1 - i0, off.back(), off.data(),
-                                                       poly.ring_xy.data() + 2 * (size_t)base, img.data.data(), img.H, img.W, args.patch_size,
-                                                       args.batch_size, rows.data() + (size_t)i0 * F, cen.data() + 2 * (size_t)i0, NFX_MEM_HOST);
+                nfx_stream_stats ss;
+                const nfx_status st = nfx_extract_tile_streamed(ctxs[(size_t)r], sets.data(), n_sets, i1 - i0, off.back(), off.data(),
+                                                                poly.ring_xy.data() + 2 * (size_t)base, img.data.data(), img.H, img.W, args.patch_size,
+                                                                args.batch_size, 0, 0, 0, rows.data() + (size_t)i0 * F, cen.data() + 2 * (size_t)i0, &ss);
                 if (st != NFX_OK) { errs[(size_t)r] = nfx_last_error(ctxs[(size_t)r]); return; }
+                log_debug("GPU " + std::to_string(r) + ": " + std::to_string(i1 - i0) + " nuclei in " + std::to_string(ss.chunks) + " chunks, " +
+                          std::to_string(ss.blocks_copied) + " of " + std::to_string(ss.blocks_total) + " blocks (" +
+                          std::to_string(ss.image_bytes_h2d >> 20) + " MiB) to the device");
                 if (any_wide) { // the polygon columns once more, unrounded (preprocess_polygon + geometric_features::*, utils.rs:54-74, shape.rs:89-97)
                     std::vector<float> centred(2 * (size_t)off.back());
                     nfx_status s2 = nfx_preprocess_polygons(ctxs[(size_t)r], i1 - i0, off.back(), off.data(), poly.ring_xy.data() + 2 * (size_t)base,

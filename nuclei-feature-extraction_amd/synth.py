@@ -206,3 +206,56 @@ def tile(seed, H, W, ring_offsets, ring_xy, ps):
             sub = img[ch, y0:y1, x0:x1]
             sub[blob] = (lo[ch] + 30.0 * ((i * 37 + ch * 11) % 17) / 17.0 + 40.0 * (tex - 0.5))[blob] + (sub[blob] - bg[ch])
     return np.clip(img, 0, 255).astype(np.uint8)
+
+
+# ---- slide-scale tiles for the streamed workloads (BASELINE configs[4]; bench only) ---------------------------------------
+def tile_side(n, ps):
+    """logical tile T x T with T = ceil(sqrt(n (ps/1.5)^2)) -- (ps/1.5)^2 slide pixels per nucleus."""
+    return int(np.ceil(np.sqrt(n * (ps / 1.5) ** 2)))
+
+
+def centres_slide_order(seed, i0, n, n_total, ps, tile_w, tile_h, block=2048, slide_i0=0):
+    """Centres of nuclei [i0, i0+n) of a slide that holds nuclei [slide_i0, slide_i0 + n_total) listed TILE BY TILE, as
+    segmentation tools emit them: the slide's k-th nucleus lies in block floor(k * n_blocks / n_total) of a raster of
+    `block`-pixel squares, uniformly inside it (always at least ps/2 + 1 pixels from the slide's border: the border rules are the
+    tests' business, not the bench's)."""
+    idx = _arange(i0, n, np)
+    nbx, nby = -(-tile_w // block), -(-tile_h // block)
+    b = ((idx - slide_i0) * (nbx * nby)) // max(1, n_total)
+    by, bx = b // nbx, b % nbx
+    with np.errstate(over="ignore"):
+        ux = _u01(_ctr(seed, idx, 8, np), np)
+        uy = _u01(_ctr(seed, idx, 9, np), np)
+    m = ps / 2.0 + 1.0
+    x0, x1 = np.maximum(bx * block, m), np.minimum((bx + 1) * block, tile_w - m)
+    y0, y1 = np.maximum(by * block, m), np.minimum((by + 1) * block, tile_h - m)
+    return x0 + ux * np.maximum(x1 - x0, 0.0), y0 + uy * np.maximum(y1 - y0, 0.0)
+
+
+def tile_from_patches(torch, d_patches, ring_cx, ring_cy, H, W, ps, seed, device, chunk=16384):
+    """RGB u8 tile [3,H,W] on `device`: background noise, every nucleus's packed patch pasted where load_image_dataset will
+    look for it (top-left = trunc(c - ps/2), utils.rs:159-162).  Windows overlap at slide density; later writes win (which
+    one is unspecified -- the tile is made once and every path under test reads the same bytes).  ring_cx / ring_cy: the
+    rings' vertex-mean centroids as the engine computes them (f32)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed) & 0x7FFFFFFF)
+    tile = torch.empty((3, H, W), dtype=torch.uint8, device=device)
+    bg = (235, 220, 235)
+    for ch in range(3):
+        for r0 in range(0, H, 4096):   # in bands: randint's int64 temporaries stay small
+            r1 = min(H, r0 + 4096)
+            tile[ch, r0:r1] = (torch.randint(0, 17, (r1 - r0, W), generator=g, device=device, dtype=torch.int16) + (bg[ch] - 8)).to(torch.uint8)
+    n = int(d_patches.shape[0])
+    top = torch.from_numpy(np.trunc(np.asarray(ring_cy, np.float32) - np.float32(ps / 2.0)).astype(np.int64)).to(device)
+    left = torch.from_numpy(np.trunc(np.asarray(ring_cx, np.float32) - np.float32(ps / 2.0)).astype(np.int64)).to(device)
+    rr = torch.arange(ps, device=device, dtype=torch.int64)
+    flat = tile.view(3, H * W)
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        y = top[c0:c1].view(-1, 1, 1) + rr.view(1, ps, 1)
+        x = left[c0:c1].view(-1, 1, 1) + rr.view(1, 1, ps)
+        ok = (y >= 0) & (y < H) & (x >= 0) & (x < W)
+        pos = (y.clamp(0, H - 1) * W + x.clamp(0, W - 1))[ok]
+        for ch in range(3):
+            flat[ch].index_put_((pos,), d_patches[c0:c1, ch][ok])
+    return tile

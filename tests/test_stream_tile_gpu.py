@@ -1,0 +1,110 @@
+"""BASELINE configs[4]: the slide streamed block by block (nfx_extract_tile_streamed) must give the rows of the resident-image call
+bit for bit -- same windows (utils.rs:159-191 / 97-122), same reference batches (the hue mean couples them, color.rs:144-155) --
+whatever the order of the nuclei, the block size, the chunk size and the number of block slots the device cache has."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _parity as par
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(synth, ps, n, H, W, seed, slide_order):
+    s = synth.SEED_BASE + seed
+    cx, cy = synth.centres(s, 0, n, ps, W, H)
+    k = min(8, n)
+    cx[:k] = [0.2, W - 0.3, 3.7, W - 4.1, ps / 2.0, W - ps / 2.0, 10.5, W / 2.0][:k]     # corners, edges: zero padding / shifted windows
+    cy[:k] = [0.4, H - 0.2, H - 2.5, 2.2, ps / 2.0 - 0.5, H - ps / 2.0 + 0.5, H / 2.0, 0.0][:k]
+    if slide_order:   # what a segmentation tool emits: tile by tile (128-pixel tiles, raster order)
+        order = np.lexsort((cx, (cx // 128).astype(np.int64), (cy // 128).astype(np.int64)))
+        cx, cy = cx[order], cy[order]
+    off, xy = synth.polygons(s, 0, n, ps, cx, cy)
+    img = synth.tile(s, H, W, off, xy, ps)
+    return off, xy, img
+
+
+@pytest.mark.parametrize("ps,slide_order,block,chunk,cache_slots,pinned", [
+    (48, True, 128, 64, 0, True),       # slide order, default cache: every needed block travels once
+    (48, False, 64, 32, 5, False),      # random order, five block slots, pageable image: evictions and re-copies through the bounce buffer
+    (32, False, 256, 1000, 0, True),    # one chunk
+    (33, True, 64, 96, 40, False),      # odd patch size (byte path of the gather)
+    (64, False, 96, 48, 12, True),
+])
+def test_streamed_rows_equal_resident_rows(nfx, synth, ps, slide_order, block, chunk, cache_slots, pinned):
+    n, H, W, B = 310, 520, 700, 16
+    off, xy, img = _scene(synth, ps, n, H, W, 23, slide_order)
+    e_off, e_xy = par.edge_case_rings(ps)                     # an empty ring among them: NaN centroid, window at the origin
+    off, xy = par.concat_rings((off, xy), (e_off, e_xy))
+    sets = [0, 1, 2, 3, 4]
+    ctx = nfx.Context(0)
+    want, wcen = ctx.extract_tile(sets, off, xy, img, ps, batch_size=B)
+    image = img
+    if pinned:
+        image = nfx.pinned_empty(img.shape, np.uint8)
+        image[...] = img
+    slot_bytes = 3 * min(H, block + ps) * min(W, block + ps)
+    slot_bytes = (slot_bytes + 255) & ~255
+    got, cen, st = ctx.extract_tile_streamed(sets, off, xy, image, ps, batch_size=B, block=block, chunk_nuclei=chunk,
+                                             cache_bytes=cache_slots * slot_bytes)
+    assert np.array_equal(cen, wcen, equal_nan=True)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.argwhere(got.view(np.uint32) != want.view(np.uint32))[:5]
+    assert st["image_pinned"] == int(pinned) and st["chunks"] >= (len(off) - 1 + max(B, chunk // B * B) - 1) // max(B, chunk // B * B)
+    assert st["blocks_total"] == -(-H // block) * -(-W // block)
+    if cache_slots == 0:
+        assert st["blocks_copied"] <= st["blocks_total"], "with room for the whole slide no block travels twice"
+    else:
+        assert st["block_slots"] == min(st["blocks_total"], max(cache_slots, B, 4))
+    assert st["image_bytes_h2d"] >= st["blocks_copied"] * 3 * 64 * 64
+    # the slide loader's addressing (utils.rs:97-122)
+    ctx.set_patch_addressing("slide")
+    want_s, _ = ctx.extract_tile(sets, off, xy, img, ps, batch_size=B)
+    got_s, _, _ = ctx.extract_tile_streamed(sets, off, xy, image, ps, batch_size=B, block=block, chunk_nuclei=chunk, cache_bytes=cache_slots * slot_bytes)
+    ctx.set_patch_addressing("image")
+    assert np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32))
+    assert not np.array_equal(got_s.view(np.uint32), got.view(np.uint32)), "border nuclei see the two loaders differently"
+    ctx.close()
+
+
+def test_slide_order_needs_few_copies_random_order_many(nfx, synth):
+    """The same nuclei in slide order and shuffled, through a cache of eight blocks: rows agree nucleus for nucleus with the
+    resident call either way; only the number of block copies differs."""
+    ps, n, H, W, B = 32, 600, 768, 768, 20
+    off, xy, img = _scene(synth, ps, n, H, W, 29, True)
+    sets = [1, 2]
+    ctx = nfx.Context(0)
+    slot = (3 * (128 + ps) * (128 + ps) + 255) & ~255
+    rows, _, st = ctx.extract_tile_streamed(sets, off, xy, img, ps, batch_size=B, block=128, chunk_nuclei=60, cache_bytes=20 * slot)
+    want, _ = ctx.extract_tile(sets, off, xy, img, ps, batch_size=B)
+    assert np.array_equal(rows.view(np.uint32), want.view(np.uint32))
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(n)
+    rings = [xy[off[i]:off[i + 1]] for i in perm]
+    off2 = np.zeros(n + 1, np.uint32)
+    np.cumsum([len(r) for r in rings], out=off2[1:])
+    xy2 = np.concatenate(rings)
+    rows2, _, st2 = ctx.extract_tile_streamed(sets, off2, xy2, img, ps, batch_size=B, block=128, chunk_nuclei=60, cache_bytes=20 * slot)
+    want2, _ = ctx.extract_tile(sets, off2, xy2, img, ps, batch_size=B)
+    assert np.array_equal(rows2.view(np.uint32), want2.view(np.uint32))
+    assert st["blocks_copied"] <= st["blocks_total"] + 4 and st2["blocks_copied"] > 2 * st["blocks_copied"], (st, st2)
+    ctx.close()
+
+
+def test_geometry_alone_and_empty_calls_need_no_image(nfx, synth):
+    ps = 32
+    off, xy, _ = par.make_inputs(3, 50, ps)
+    ctx = nfx.Context(0)
+    rows, cen, st = ctx.extract_tile_streamed([0], off, xy, np.zeros((3, 8, 8), np.uint8), ps)
+    want, wcen = ctx.extract([0], off, xy, None, ps)
+    assert np.array_equal(rows, want, equal_nan=True) and np.array_equal(cen, wcen) and st["blocks_copied"] == 0
+    rows, cen, _ = ctx.extract_tile_streamed([0, 1], np.zeros(1, np.uint32), np.zeros((0, 2), np.float32), np.zeros((3, 8, 8), np.uint8), ps)
+    assert rows.shape == (0, 30)
+    # errors: reported, nothing left in flight
+    L = nfx.lib()
+    s = (C.c_int * 1)(1)
+    o = off.astype(np.uint32)
+    st_ = L.nfx_extract_tile_streamed(ctx._h, s, 1, 50, int(o[-1]), o.ctypes.data_as(C.c_void_p), xy.ctypes.data_as(C.c_void_p), None, 8, 8, ps, 100, 0, 0, 0,
+                                      rows.ctypes.data_as(C.c_void_p), None, None)
+    assert st_ == 1 and b"image" in L.nfx_last_error(ctx._h)
+    ctx.close()
