@@ -273,7 +273,7 @@ def streamed_tile_leg(nfx, synth, torch, dist, ctx, dev, workload, n, i0, B, ste
     packed = 3 * ps * ps + 8.0 * len(xy) / n + 4 + 4 * F + 8          # what the packed-patch stream moves per nucleus
     return {"value": round(n * steps / el, 1), "unit": "nuclei/s", "ms_per_step": round(el / steps * 1e3, 3),
             "what": f"{desc}: the nuclei's slide ({T} x {T} pixels, {3 * T * T / 1e9:.2f} GB, nuclei in slide order) starts in pinned host memory and is "
-                    "streamed every step in 2048-pixel blocks (copies overlapped with compute, nfx_extract_tile_streamed), rows copied back; timed from the "
+                    "streamed every step in bands of 2048 rows (contiguous copies overlapped with compute, nfx_extract_tile_streamed), rows copied back; timed from the "
                     "first H2D byte to the last row on the host (SURVEY.md §8d); never the headline value",
             "rows_equal_resident_tile_rows": same, "pcie_bytes_per_nucleus": round(wire / n, 1),
             "pcie_bytes_per_nucleus_packed_patch_stream": round(packed, 1), "link_GBps": round(wire * steps / el / 1e9, 2),

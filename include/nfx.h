@@ -26,7 +26,7 @@
  *                                                 u8 image by load_image_dataset's addressing rules
  *                                                 (utils.rs:141-206)
  *   nfx_extract_tile_streamed                     the same pipeline stage on a slide that is NOT resident: the image
- *                                                 travels block by block over the host link while earlier blocks'
+ *                                                 travels band by band over the host link while earlier bands'
  *                                                 nuclei are extracted (BASELINE configs[4]); replaces the crop
  *                                                 utils.rs:141-206 + move_tensors_to_device utils.rs:211-224 per batch
  *   nfx_centroid_key                              centroid_to_key_string, utils.rs:226-228
@@ -202,25 +202,27 @@ nfx_status nfx_extract_tile(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n
                             const uint32_t *ring_offsets, const float *ring_xy, const uint8_t *image_u8, int64_t H,
                             int64_t W, int ps, int batch_size, float *out_rows, float *out_centroids_xy, nfx_mem mem);
 
-/* ---- the slide streamed block by block, host -> device copies overlapped with compute (BASELINE configs[4]) ------------------
+/* ---- the slide streamed band by band, host -> device copies overlapped with compute (BASELINE configs[4]) -------------------
    All pointers are HOST memory; the call is synchronous (rows and centroids are on the host when it returns) and runs on streams
-   of the context's own.  image_u8 [3][H][W] is cut into square blocks of `block` pixels (0 = 2048; at least 64), each with a
-   patch-size halo to the right and below; nuclei are processed in index order in chunks of whole reference batches
-   (`chunk_nuclei`, 0 = 100 000, rounded down to a multiple of batch_size): while chunk k is extracted, the blocks chunk k+1 touches
-   travel to the device (only those not resident: the device keeps `cache_bytes` of blocks, 0 = 16 GiB, least recently used out first)
-   and its nuclei's windows are gathered from them by load_image_dataset's rules (utils.rs:159-191; NFX_ADDR_SLIDE: utils.rs:97-122),
-   and the rows of chunk k-1 travel back.  Rows are bit-identical to nfx_extract_tile on the resident image, whatever the order of the
-   nuclei (slide order -- what segmentation tools emit -- makes a chunk touch few blocks; any other order only costs copies).
-   For the link's full rate image_u8 and out_rows should be pinned for THIS library's HIP runtime (nfx_host_alloc, or
-   nfx_host_register on memory of the caller's own; memory pinned by another runtime in the process, e.g. PyTorch's, counts as
-   pageable); a pageable image is packed block by block into a pinned bounce buffer by the calling thread.
-   stats (may be NULL): what travelled. */
+   of the context's own.  image_u8 [3][H][W] is cut into horizontal bands of `block` rows (0 = 2048; at least 64) over the full
+   width, each with a patch-size halo below -- a band's rows are contiguous in the planar image, so it travels as three large
+   contiguous copies; nuclei are processed in index order in chunks of whole reference batches (`chunk_nuclei`, 0 = 100 000,
+   rounded down to a multiple of batch_size): while chunk k is extracted, the bands chunk k+1 touches travel to the device (only
+   those not resident: the device keeps `cache_bytes` of bands, 0 = the whole slide if 60 % of the free device memory holds it,
+   least recently used out first) and its nuclei's windows are gathered from them by load_image_dataset's rules (utils.rs:159-191;
+   NFX_ADDR_SLIDE: utils.rs:97-122), and the rows of chunk k-1 travel back.  Rows are bit-identical to nfx_extract_tile on the
+   resident image, whatever the order of the nuclei (slide order -- what segmentation tools emit -- makes a chunk touch one or
+   two bands; any other order only costs copies; a single batch that touches more bands than the cache holds fails with
+   NFX_ERR_OUT_OF_MEMORY).  For the link's full rate and for copies that overlap compute, image_u8 and out_rows should be pinned
+   for THIS library's HIP runtime (nfx_host_alloc, or nfx_host_register on memory of the caller's own; memory pinned by another
+   runtime in the process, e.g. PyTorch's, counts as pageable and is staged by the runtime).
+   stats (may be NULL): what travelled ("blocks" = bands). */
 typedef struct {
     int64_t image_bytes_h2d;  /* block windows copied to the device (3 bytes per pixel, halos and re-copies included) */
     int64_t other_bytes_h2d;  /* ring offsets and vertices, per-chunk selection lists and rebased offsets */
     int64_t rows_bytes_d2h;   /* feature rows + centroids */
     int64_t blocks_copied, blocks_total, block_slots, chunks;
-    int64_t image_pinned;     /* 1: the image was copied straight out of pinned memory; 0: through the bounce buffer */
+    int64_t image_pinned;     /* 1: the image is pinned for this runtime (asynchronous copies); 0: pageable */
 } nfx_stream_stats;
 nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t n_vertices,
                                      const uint32_t *ring_offsets, const float *ring_xy, const uint8_t *image_u8, int64_t H, int64_t W,

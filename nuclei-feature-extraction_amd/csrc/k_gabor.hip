@@ -513,11 +513,12 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
         for (int w = 0; w < GB_WAVES; ++w) gtot += s_gsum[w];
         const float mu_gray = gtot / (float)area;
         // The masked sums are f32 about a per-filter SHIFT (the accumulators start at minus the shift), so that sum d^2 carries no
-        // cancellation: var = s2/K - (s1/K)^2 loses (s1/K)^2 / var in relative accuracy.  First attempt: shift = DC gain x mean
-        // masked gray -- within a few standard deviations of the mean response whenever the 30-tap kernel sees mostly the patch
-        // (measured on the synthetic nuclei: (s1/K)^2 <= 57 var at 32 x 32, <= 10 var at 48 and 64).  On patches smaller than
-        // the kernel the zero padding moves every response off that guess ((s1/K)^2 up to 2700 var at 17 x 17: relative error
-        // 4e-4 on the frequency-0.5 variances): such a nucleus is done a SECOND time with the mean just measured as the shift.
+        // cancellation: var = s2/K - (s1/K)^2 carries the f32 sums' relative error (3..6e-7: <= 16 terms per lane, a six-level
+        // butterfly) times 1 + (s1/K)^2 / var.  First attempt: shift = DC gain x mean masked gray -- within a few standard
+        // deviations of the mean response whenever the 30-tap kernel sees mostly the patch (on the synthetic nuclei (s1/K)^2 exceeds
+        // 8 var for < 1 % of the nuclei at 64 x 64, 1-2 % at 48 x 48, a fifth at 32 x 32).  Where it does -- patches smaller than the
+        // kernel, whose zero padding moves every response off that guess ((s1/K)^2 up to 2700 var at 17 x 17: 4e-4 relative on the
+        // frequency-0.5 variances), flat patches -- the nucleus is done a SECOND time with the mean just measured as the shift.
         if (t < n_filters) s_shift[t] = tab->filters[t].dc * mu_gray;
 #pragma unroll 1
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
                 var = var > 0.0 ? var : 0.0;
                 const double mean = shift + m1;
                 mean_f = (float)mean;
-                off_centre = m1 * m1 > 64.0 * var;
+                off_centre = m1 * m1 > 8.0 * var;
                 if (Fl.ch0 >= 0) { o[2 * Fl.ch0] = (float)mean; o[2 * Fl.ch0 + 1] = (float)var; }
                 if (Fl.ch1 >= 0) { o[2 * Fl.ch1] = (float)mean; o[2 * Fl.ch1 + 1] = (float)var; }
             }

@@ -142,7 +142,9 @@ nfx_status nfx_gather_rows(nfx_ctx *ctx, nfx_comm *comm, const float *rows, int 
         if (counts[r] < 0) return comm_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "nfx_gather_rows: negative count");
     const int64_t mine = counts[comm->rank];
     if (mine > 0 && !rows) return comm_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "nfx_gather_rows: null rows");
-    if (comm->rank == root && !dst) return comm_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "nfx_gather_rows: null dst on the root");
+    int64_t total = 0;
+    for (int r = 0; r < comm->world; ++r) total += counts[r];
+    if (comm->rank == root && !dst && total > 0) return comm_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "nfx_gather_rows: null dst on the root");
     if (comm->device != ctx->device) return comm_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "nfx_gather_rows: communicator and context live on different devices");
     const Rccl *R = rccl();
     if (!R) return comm_fail(ctx, NFX_ERR_UNSUPPORTED, g_rccl.why);

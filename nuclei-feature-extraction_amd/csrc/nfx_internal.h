@@ -52,8 +52,8 @@ struct nfx_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr; // here, beside the rasteriser and the pixel kernels of the same call
     // nfx_extract_tile_streamed (nfx_stream.cpp): block copies + window gathers | rows back to the host, created on first use
     hipStream_t copy_stream = nullptr, rows_stream = nullptr;
-    hipEvent_t ev_ready[2] = {}, ev_done[2] = {}, ev_rows[2] = {}, ev_bounce[2] = {};
-    void *pin = nullptr;      // grow-only pinned host staging (selection lists, rebased offsets, bounce blocks of a pageable image)
+    hipEvent_t ev_ready[2] = {}, ev_done[2] = {}, ev_rows[2] = {};
+    void *pin = nullptr;      // grow-only pinned host staging (selection lists, rebased offsets of two chunks)
     size_t pin_cap = 0;
     nfx_addressing addressing = NFX_ADDR_IMAGE;
     std::string err;
@@ -108,9 +108,11 @@ nfx_status api_fail(nfx_ctx *ctx, nfx_status st, const std::string &msg);
 #define NFX_HIP(ctx, expr)                                                                                 \
     do {                                                                                                   \
         hipError_t e_ = (expr);                                                                            \
-        if (e_ != hipSuccess)                                                                              \
+        if (e_ != hipSuccess) {                                                                            \
+            (void)hipGetLastError(); /* reported here: the next call must not find it again */             \
             return nfx::api_fail(ctx, e_ == hipErrorOutOfMemory ? NFX_ERR_OUT_OF_MEMORY : NFX_ERR_DEVICE,  \
                                  std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+        }                                                                                                  \
     } while (0)
 static inline size_t al(size_t b) { return (b + 255) & ~size_t(255); } // workspace allocations are 256-byte aligned
 nfx_status check_common(nfx_ctx *ctx, int64_t n, int64_t nv, int ps);

@@ -1,20 +1,22 @@
-// nfx_stream.cpp -- nfx_extract_tile_streamed: the slide streamed BLOCK BY BLOCK, host -> device copies overlapped with compute.
+// nfx_stream.cpp -- nfx_extract_tile_streamed: the slide streamed band by band, host -> device copies overlapped with compute.
 //
 // Replaces (reference file:line): the per-batch pipeline stage of main.rs:146-151 on a slide that does not have to be resident --
 // load_image_dataset's crop of every nucleus's window out of the image (utils.rs:141-206), move_tensors_to_device (utils.rs:211-224:
 // a synchronous copy of two f32 tensors, 16 ps^2 bytes per nucleus) and the feature sets.  BASELINE.json configs[4]: "WSI-scale 10M
 // nuclei, 64 x 64 patches, full feature set, streamed tile H2D overlapped with compute".
 //
-// What travels over the host link is the TILE, cut into square blocks (2048^2 by default, each with a patch-size halo to the
-// right and below so that every nucleus's window lies inside the block its top-left corner falls in): 3 bytes per slide pixel,
+// What travels over the host link is the TILE, cut into horizontal BANDS of 2048 rows by default (full width, each with a
+// patch-size halo below, so that every nucleus's window lies inside the band its first row falls in): 3 bytes per slide pixel,
 // i.e. (ps/1.5)^2 x 3 bytes per nucleus at the density of the synthetic slides -- 2.25x fewer than packed patches (3 ps^2), 12x
-// fewer than the reference's f32 patch + mask tensors.  The reference's batch partition is kept (the hue mean couples the
-// nuclei of a batch, color.rs:144-155): nuclei are processed in index order in CHUNKS of whole batches; a chunk runs when every
-// block it touches is resident.  Segmentation tools emit nuclei tile by tile, so a chunk touches one or a few blocks; any
-// order is correct (a block that is needed again after it was evicted is copied again; the device keeps as many blocks as
-// `cache_bytes` allows -- the whole slide, typically).
+// fewer than the reference's f32 patch + mask tensors.  Bands, not squares: the rows of a band are contiguous in the planar
+// [3][H][W] image, so a band is three large contiguous copies at the link's full rate (square 2048^2 blocks are 2112-byte rows at
+// // the image's pitch: measured 35 GB/s with an aligned pitch and 0.3 GB/s with an odd one through hipMemcpy2DAsync, against 45-50 GB/s).
+// The reference's batch partition is kept (the hue mean couples the nuclei of a batch, color.rs:144-155): nuclei are processed
+// in index order in CHUNKS of whole batches; a chunk runs when every band it touches is resident.  Segmentation tools emit
+// nuclei tile by tile, so a chunk touches one or two bands; any order is correct (a band that is needed again after it was
+// evicted is copied again; the device keeps as many bands as `cache_bytes` allows -- the whole slide, typically).
 //
-//   copy stream    : H2D blocks of chunk k+1 | gather their nuclei's windows into patches[(k+1)&1]
+//   copy stream    : H2D bands of chunk k+1 | gather their nuclei's windows into patches[(k+1)&1]
 //   compute stream :              extract(chunk k) from patches[k&1] -> rows[k&1]
 //   rows stream    :                                   D2H rows of chunk k-1
 //
@@ -67,7 +69,7 @@ struct Pinned { // grow-only pinned staging kept by the context
 
 struct Chunk {
     int64_t i0, i1;                  // nuclei
-    std::vector<int64_t> blocks;     // distinct blocks its windows start in, ascending
+    std::vector<int64_t> blocks;     // distinct bands its windows start in, ascending
     std::vector<uint32_t> sel;       // chunk-relative nucleus indices grouped by block (same order as `blocks`)
     std::vector<uint32_t> sel_off;   // blocks.size() + 1 offsets into sel
 };
@@ -109,28 +111,34 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     if (!pix || n == 0) // nothing to stream: geometry needs no pixels
         return nfx_extract(ctx, sets, n_sets, n, nv, ring_offsets, ring_xy, nullptr, ps, batch_size, out_rows, out_centroids_xy, NFX_MEM_HOST);
     if (!image_u8 || H < 1 || W < 1) return api_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null or empty image");
-    if (ps > NFX_ROW_WORD_PS && false) return NFX_ERR_UNSUPPORTED;
     NFX_HIP(ctx, hipSetDevice(ctx->device));
     StreamScope scope(ctx, NFX_MEM_HOST); // ctx->stream = the context's own stream (the compute stream below), host arena
     if ((st = check_offsets(ctx, ring_offsets, n, nv, "ring_offsets")) != NFX_OK) return st;
     if (!ctx->copy_stream) NFX_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     if (!ctx->rows_stream) NFX_HIP(ctx, hipStreamCreateWithFlags(&ctx->rows_stream, hipStreamNonBlocking));
     for (int b = 0; b < 2; ++b)
-        for (hipEvent_t *e : {&ctx->ev_ready[b], &ctx->ev_done[b], &ctx->ev_rows[b], &ctx->ev_bounce[b]})
+        for (hipEvent_t *e : {&ctx->ev_ready[b], &ctx->ev_done[b], &ctx->ev_rows[b]})
             if (!*e) NFX_HIP(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
     hipStream_t const compute = ctx->stream, copy = ctx->copy_stream, rows_s = ctx->rows_stream;
     const bool slide = ctx->addressing == NFX_ADDR_SLIDE;
 
-    // ---- geometry of the plan ---------------------------------------------------------------------------------------------
+    // ---- geometry of the plan: "block" b is the band of rows [b B, b B + B + ps) (clipped to the image), all W columns -----------
     const int64_t B = block > 0 ? (block < 64 ? 64 : block) : 2048;
-    const int64_t nbx = (W + B - 1) / B, nby = (H + B - 1) / B, nblocks = nbx * nby;
-    const int64_t sh = std::min<int64_t>(H, B + ps), sw = std::min<int64_t>(W, B + ps); // a block's window: B + halo, clipped to the image
-    const size_t slot_bytes = al(3 * (size_t)sh * sw);
+    const int64_t nblocks = (H + B - 1) / B;
+    const int64_t sh = std::min<int64_t>(H, B + ps); // rows of a band incl. its halo
+    const size_t slot_bytes = al(3 * (size_t)sh * W);
     const int64_t chunk_max = std::max<int64_t>(batch_size, ((chunk_nuclei > 0 ? chunk_nuclei : 100000) / batch_size) * batch_size);
     const int64_t chunk_cap = std::min<int64_t>(chunk_max, ((n + batch_size - 1) / batch_size) * batch_size);
-    // a chunk of ONE batch must fit whatever its nuclei's order: one slot per nucleus of a batch at least (or the whole slide)
-    const int64_t want_slots = cache_bytes > 0 ? cache_bytes / (int64_t)slot_bytes : ((int64_t)16 << 30) / (int64_t)slot_bytes;
-    const int64_t n_slots = std::min<int64_t>(nblocks, std::max<int64_t>(std::max<int64_t>(want_slots, 4), std::min<int64_t>(batch_size, nblocks)));
+    int64_t want_slots;
+    if (cache_bytes > 0) want_slots = cache_bytes / (int64_t)slot_bytes;
+    else { // default: the whole slide if it fits beside everything else (60 % of what is free now), else what fits
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)16 << 30; }
+        want_slots = (int64_t)((free_b / 10 * 6) / slot_bytes);
+    }
+    // slide-ordered nuclei touch one or two bands per batch; whatever the order, a batch can always run with as many bands as it
+    // has nuclei (or the whole slide)
+    const int64_t n_slots = std::min<int64_t>(nblocks, std::max<int64_t>(std::max<int64_t>(want_slots, 2), std::min<int64_t>(batch_size, nblocks)));
 
     // ---- stage the rings, centroids of every nucleus (k_preprocess: the arithmetic that addresses the windows) ------------------
     const size_t P3 = 3 * (size_t)ps * ps;
@@ -173,9 +181,9 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     const float half = (float)ps / 2.0f;
     std::vector<int64_t> blk((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
-        int64_t t0 = window_origin(cen[2 * i + 1], half, slide), l0 = window_origin(cen[2 * i], half, slide);
-        t0 = std::min<int64_t>(t0, H - 1); l0 = std::min<int64_t>(l0, W - 1); // a window that starts past the image reads nothing: any block will do
-        blk[i] = (t0 / B) * nbx + l0 / B;
+        int64_t t0 = window_origin(cen[2 * i + 1], half, slide);
+        t0 = std::min<int64_t>(t0, H - 1); // a window that starts past the image reads nothing: any band will do
+        blk[i] = t0 / B;
     }
     std::vector<Chunk> chunks;
     {
@@ -207,24 +215,21 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
                 c.sel.push_back(order[q].second);
             }
             c.sel_off.push_back((uint32_t)order.size());
-            if ((int64_t)c.blocks.size() > n_slots) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "one reference batch touches more blocks than the block cache holds");
+            if ((int64_t)c.blocks.size() > n_slots) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "one reference batch touches more bands than the band cache holds: raise cache_bytes");
             chunks.push_back(std::move(c));
         }
     }
 
-    // ---- pinned staging: selection lists and rebased offsets of two chunks; two bounce blocks if the image is pageable -----------
-    const bool img_pinned = is_pinned(image_u8);
-    const size_t stage_bytes = 2 * (4 * (size_t)chunk_cap + 4 * ((size_t)chunk_cap + 1) + 64) + (img_pinned ? 0 : 2 * slot_bytes);
+    // ---- pinned staging: selection lists and rebased offsets of two chunks -------------------------------------------------------
+    const bool img_pinned = is_pinned(image_u8); // (a pageable image is copied by the runtime through its own staging: correct, not overlapped)
+    const size_t stage_bytes = 2 * (4 * (size_t)chunk_cap + 4 * ((size_t)chunk_cap + 1) + 128) + 512;
     uint8_t *pin = (uint8_t *)Pinned::get(ctx, stage_bytes);
     if (!pin) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "pinned staging");
-    uint32_t *h_sel[2], *h_off[2]; uint8_t *h_bounce[2] = {nullptr, nullptr};
+    uint32_t *h_sel[2], *h_off[2];
     {
         uint8_t *q = pin;
         for (int b = 0; b < 2; ++b) { h_sel[b] = (uint32_t *)q; q += 4 * (size_t)chunk_cap + 32; h_off[b] = (uint32_t *)q; q += 4 * ((size_t)chunk_cap + 1) + 32; }
-        if (!img_pinned) { q = pin + ((q - pin + 255) & ~(size_t)255); h_bounce[0] = q; h_bounce[1] = q + slot_bytes; }
     }
-    int bounce_turn = 0;
-    bool bounce_used[2] = {false, false};
 
     // ---- block cache ---------------------------------------------------------------------------------------------------------
     std::vector<int64_t> slot_block((size_t)n_slots, -1), slot_use((size_t)n_slots, -1), block_slot((size_t)nblocks, -1);
@@ -255,30 +260,17 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         for (size_t q = 0; q < c.blocks.size(); ++q) if (block_slot[c.blocks[q]] >= 0) slot_use[block_slot[c.blocks[q]]] = k;
         for (size_t q = 0; q < c.blocks.size(); ++q) {
             const int64_t bid = c.blocks[q];
-            const int64_t by = bid / nbx, bx = bid % nbx;
-            const int64_t wy0 = by * B, wx0 = bx * B, wh = std::min<int64_t>(H - wy0, B + ps), ww = std::min<int64_t>(W - wx0, B + ps);
+            const int64_t wy0 = bid * B, wx0 = 0, wh = std::min<int64_t>(H - wy0, B + ps), ww = W;
             int64_t s = block_slot[bid];
             if (s < 0) { // not resident: take the slot that has gone unused longest (never one this chunk needs)
                 s = 0;
                 for (int64_t t = 1; t < n_slots; ++t) if (slot_use[t] < slot_use[s]) s = t;
-                if (slot_use[s] == k) return fail_sync(api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "block cache too small for one chunk"));
+                if (slot_use[s] == k) return fail_sync(api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "band cache too small for one chunk"));
                 if (slot_block[s] >= 0) block_slot[slot_block[s]] = -1;
                 slot_block[s] = bid; block_slot[bid] = s; slot_use[s] = k;
                 uint8_t *dst = d_slots + (size_t)s * slot_bytes;
-                if (img_pinned) {
-                    for (int ch = 0; ch < 3; ++ch)
-                        NFX_HIP_S(hipMemcpy2DAsync(dst + (size_t)ch * wh * ww, (size_t)ww, image_u8 + ((size_t)ch * H + wy0) * W + wx0, (size_t)W, (size_t)ww, (size_t)wh,
-                                                   hipMemcpyHostToDevice, copy));
-                } else { // pageable image: the block is packed into a pinned bounce buffer by the host, then copied in one piece
-                    const int t = bounce_turn; bounce_turn ^= 1;
-                    if (bounce_used[t]) NFX_HIP_S(hipEventSynchronize(ctx->ev_bounce[t]));
-                    for (int ch = 0; ch < 3; ++ch)
-                        for (int64_t r = 0; r < wh; ++r)
-                            memcpy(h_bounce[t] + ((size_t)ch * wh + r) * ww, image_u8 + ((size_t)ch * H + wy0 + r) * W + wx0, (size_t)ww);
-                    NFX_HIP_S(hipMemcpyAsync(dst, h_bounce[t], 3 * (size_t)wh * ww, hipMemcpyHostToDevice, copy));
-                    NFX_HIP_S(hipEventRecord(ctx->ev_bounce[t], copy));
-                    bounce_used[t] = true;
-                }
+                for (int ch = 0; ch < 3; ++ch) // rows [wy0, wy0 + wh) of a channel are contiguous in the planar image
+                    NFX_HIP_S(hipMemcpyAsync(dst + (size_t)ch * wh * ww, image_u8 + ((size_t)ch * H + wy0) * W, (size_t)wh * ww, hipMemcpyHostToDevice, copy));
                 img_h2d += 3 * wh * ww;
                 ++blocks_copied;
             }

@@ -1,6 +1,6 @@
-"""BASELINE configs[4]: the slide streamed block by block (nfx_extract_tile_streamed) must give the rows of the resident-image call
+"""BASELINE configs[4]: the slide streamed band by band (nfx_extract_tile_streamed) must give the rows of the resident-image call
 bit for bit -- same windows (utils.rs:159-191 / 97-122), same reference batches (the hue mean couples them, color.rs:144-155) --
-whatever the order of the nuclei, the block size, the chunk size and the number of block slots the device cache has."""
+whatever the order of the nuclei, the band height, the chunk size and the number of bands the device cache holds."""
 import ctypes as C
 
 import numpy as np
@@ -25,15 +25,15 @@ def _scene(synth, ps, n, H, W, seed, slide_order):
     return off, xy, img
 
 
-@pytest.mark.parametrize("ps,slide_order,block,chunk,cache_slots,pinned", [
-    (48, True, 128, 64, 0, True),       # slide order, default cache: every needed block travels once
-    (48, False, 64, 32, 5, False),      # random order, five block slots, pageable image: evictions and re-copies through the bounce buffer
-    (32, False, 256, 1000, 0, True),    # one chunk
-    (33, True, 64, 96, 40, False),      # odd patch size (byte path of the gather)
-    (64, False, 96, 48, 12, True),
+@pytest.mark.parametrize("ps,slide_order,block,chunk,cache_slots,pinned,B", [
+    (48, True, 128, 64, 0, True, 16),     # slide order, default cache: every needed band travels once
+    (48, False, 64, 8, 3, False, 4),      # random order, four band slots of nine, pageable image: evictions and re-copies
+    (32, False, 256, 1000, 0, True, 16),  # one chunk
+    (33, True, 64, 96, 40, False, 16),    # odd patch size (byte path of the gather)
+    (64, False, 96, 48, 2, True, 3),
 ])
-def test_streamed_rows_equal_resident_rows(nfx, synth, ps, slide_order, block, chunk, cache_slots, pinned):
-    n, H, W, B = 310, 520, 700, 16
+def test_streamed_rows_equal_resident_rows(nfx, synth, ps, slide_order, block, chunk, cache_slots, pinned, B):
+    n, H, W = 310, 520, 700
     off, xy, img = _scene(synth, ps, n, H, W, 23, slide_order)
     e_off, e_xy = par.edge_case_rings(ps)                     # an empty ring among them: NaN centroid, window at the origin
     off, xy = par.concat_rings((off, xy), (e_off, e_xy))
@@ -44,18 +44,17 @@ def test_streamed_rows_equal_resident_rows(nfx, synth, ps, slide_order, block, c
     if pinned:
         image = nfx.pinned_empty(img.shape, np.uint8)
         image[...] = img
-    slot_bytes = 3 * min(H, block + ps) * min(W, block + ps)
-    slot_bytes = (slot_bytes + 255) & ~255
+    slot_bytes = (3 * min(H, block + ps) * W + 255) & ~255      # a band: `block` rows + a patch-size halo, full width
     got, cen, st = ctx.extract_tile_streamed(sets, off, xy, image, ps, batch_size=B, block=block, chunk_nuclei=chunk,
                                              cache_bytes=cache_slots * slot_bytes)
     assert np.array_equal(cen, wcen, equal_nan=True)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.argwhere(got.view(np.uint32) != want.view(np.uint32))[:5]
     assert st["image_pinned"] == int(pinned) and st["chunks"] >= (len(off) - 1 + max(B, chunk // B * B) - 1) // max(B, chunk // B * B)
-    assert st["blocks_total"] == -(-H // block) * -(-W // block)
+    assert st["blocks_total"] == -(-H // block)
     if cache_slots == 0:
-        assert st["blocks_copied"] <= st["blocks_total"], "with room for the whole slide no block travels twice"
+        assert st["blocks_copied"] <= st["blocks_total"], "with room for the whole slide no band travels twice"
     else:
-        assert st["block_slots"] == min(st["blocks_total"], max(cache_slots, B, 4))
+        assert st["block_slots"] == min(st["blocks_total"], max(cache_slots, B, 2))
     assert st["image_bytes_h2d"] >= st["blocks_copied"] * 3 * 64 * 64
     # the slide loader's addressing (utils.rs:97-122)
     ctx.set_patch_addressing("slide")
@@ -68,14 +67,14 @@ def test_streamed_rows_equal_resident_rows(nfx, synth, ps, slide_order, block, c
 
 
 def test_slide_order_needs_few_copies_random_order_many(nfx, synth):
-    """The same nuclei in slide order and shuffled, through a cache of eight blocks: rows agree nucleus for nucleus with the
-    resident call either way; only the number of block copies differs."""
-    ps, n, H, W, B = 32, 600, 768, 768, 20
+    """The same nuclei in slide order and shuffled, through a cache of four bands out of twelve: rows agree nucleus for nucleus
+    with the resident call either way; only the number of band copies differs."""
+    ps, n, H, W, B = 32, 600, 768, 768, 4
     off, xy, img = _scene(synth, ps, n, H, W, 29, True)
     sets = [1, 2]
     ctx = nfx.Context(0)
-    slot = (3 * (128 + ps) * (128 + ps) + 255) & ~255
-    rows, _, st = ctx.extract_tile_streamed(sets, off, xy, img, ps, batch_size=B, block=128, chunk_nuclei=60, cache_bytes=20 * slot)
+    slot = (3 * (64 + ps) * W + 255) & ~255
+    rows, _, st = ctx.extract_tile_streamed(sets, off, xy, img, ps, batch_size=B, block=64, chunk_nuclei=40, cache_bytes=4 * slot)
     want, _ = ctx.extract_tile(sets, off, xy, img, ps, batch_size=B)
     assert np.array_equal(rows.view(np.uint32), want.view(np.uint32))
     rng = np.random.default_rng(3)
@@ -84,10 +83,11 @@ def test_slide_order_needs_few_copies_random_order_many(nfx, synth):
     off2 = np.zeros(n + 1, np.uint32)
     np.cumsum([len(r) for r in rings], out=off2[1:])
     xy2 = np.concatenate(rings)
-    rows2, _, st2 = ctx.extract_tile_streamed(sets, off2, xy2, img, ps, batch_size=B, block=128, chunk_nuclei=60, cache_bytes=20 * slot)
+    rows2, _, st2 = ctx.extract_tile_streamed(sets, off2, xy2, img, ps, batch_size=B, block=64, chunk_nuclei=40, cache_bytes=4 * slot)
     want2, _ = ctx.extract_tile(sets, off2, xy2, img, ps, batch_size=B)
     assert np.array_equal(rows2.view(np.uint32), want2.view(np.uint32))
-    assert st["blocks_copied"] <= st["blocks_total"] + 4 and st2["blocks_copied"] > 2 * st["blocks_copied"], (st, st2)
+    assert st["block_slots"] == 4 and st["blocks_total"] == 12
+    assert st["blocks_copied"] <= 2 * st["blocks_total"] and st2["blocks_copied"] > 4 * st["blocks_copied"], (st, st2)
     ctx.close()
 
 

@@ -44,7 +44,7 @@ def _trait(nfx, ctx, set_id, off, xy, patchs, masks, B):
     for b0 in range(0, n, B):
         b1 = min(n, b0 + B)
         o = (off[b0:b1 + 1] - off[b0]).astype(np.uint32)
-        out.append(ctx.compute_features_batched(set_id, o, xy[off[b0]:off[b1]], patchs[b0:b1], masks[b0:b1]))
+        out.append(ctx.compute_features_batched(set_id, o, xy[off[b0]:off[b1]], None if patchs is None else patchs[b0:b1], masks[b0:b1]))
     return np.concatenate(out)
 
 
