@@ -22,7 +22,9 @@
 //     telescope over the ranks (difference tables for every possible rank live in global memory, L1/L2
 //     resident; the look-up for a pair is issued one loop iteration after its rank is known), so the
 //     multiplicities are never read back and no cell needs an owner;
-//   * L=32 and L=64 use dense triangular tables of packed 16-bit counters (5 KB); L=128 and L=254 use
+//   * gray levels are counted RELATIVE to the nucleus's lowest level (GlGeom): outside the top class the dense tables and the
+//     histograms cover 3/4 of the scale, and a nucleus whose levels span more is handed to the top class before any counting;
+//   * L=32 and L=64 use dense triangular tables of packed 16-bit counters (5 KB; 3 KB for the 3/4 span); L=128 and L=254 use
 //     open-addressing HASH tables -- 3/4 slot per mask pixel of the class's capacity for the typical texture, with a
 //     hand-over to the next class for the nucleus that fills it (template parameter FULL) -- instead
 //     of 16.5 / 64.8 KB dense ones, keyed by hi << 8 | lo and filled insert-first (a new cell costs one LDS
@@ -53,10 +55,30 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 static constexpr int GL_NACC = 10;
 static constexpr int GL_RANKS = 4096;      // rank range of the global difference tables (a cell holds at most 4032 pairs)
 static constexpr int GL_COUNTS = 8200;     // count range of the x ln x table (a marginal bin holds at most 2 * 4032)
-static constexpr int GL_HIST_WORDS = 768;
 static constexpr unsigned GL_EMPTY = 0xFFFFFFFFu;
-static constexpr int GL_D64_OFF = 272;     // pass A: d32 at 0 (264 words) | d64 at 272 (1040 words) | h128 at 1320
-static constexpr int GL_H128_OFF = 1320;   // pass B: h254 at 0
+// Table and histogram geometry of one instantiation.  FULL (the top class of a patch size, a small call's single launch): every
+// level can occur.  Otherwise the structures are sized for the TYPICAL nucleus -- a nucleus's gray levels span 3/4 of the scale at
+// most (R128 = 96 of 128 levels, R254 = 192 of 254; on the synthetic H&E nuclei the spans are 76 / 150 at the median, 90 / 182 at
+// the maximum): levels are taken relative to the nucleus's lowest one, the dense tables of levels 32 / 64 and the histograms cover
+// the span only -- 3 KB of LDS per wave less, i.e. one or two more waves per CU in every class -- and a nucleus whose span
+// does not fit is handed to the top class's list before any counting is done.
+template <bool FULL>
+struct GlGeom {
+    static constexpr int R128 = FULL ? 128 : 96, R64 = R128 / 2, R32 = R128 / 4;     // level spans the dense tables hold
+    static constexpr int R254 = FULL ? 254 : 192;
+    static constexpr int D32_WORDS = ((R32 * (R32 + 1) / 2 + 1) / 2 + 7) & ~7;       // packed 16-bit triangular cells, 32-byte pieces
+    static constexpr int D64_WORDS = ((R64 * (R64 + 1) / 2 + 1) / 2 + 7) & ~7;
+    static constexpr int D64_OFF = D32_WORDS;                                         // pass A: d32 | d64 | h128 (hash)
+    static constexpr int H128_OFF = D32_WORDS + D64_WORDS;                             // pass B: h254 over the whole table memory
+    // histogram words, every segment a whole number of 64-word slices (lane + 64 m addressing in the folds):
+    //   pass A: hx128 at 0 (128) | hs32 at 128 (64) | hs64 at 192 (128) | hs128 at 320 (64 HS128_SLICES)
+    //   pass B: hx254 at 0 (64 HXB) | hs254 at 64 HXB (64 HSB)
+    static constexpr int HS128_SLICES = FULL ? 4 : 3;
+    static constexpr int HXB = FULL ? 4 : 3, HSB = 2 * HXB;
+    static constexpr int HIST_A = 320 + 64 * HS128_SLICES, HIST_B = 64 * (HXB + HSB);
+    static constexpr int HIST_WORDS = HIST_A > HIST_B ? HIST_A : HIST_B;
+    static_assert(2 * R32 <= 64 && 2 * R64 <= 128 && 2 * R128 <= 64 * HS128_SLICES && R254 <= 64 * HXB && 2 * R254 <= 64 * HSB, "histogram segments");
+};
 
 __constant__ int kGlcmOffsets[4][2] = {{0, 1}, {1, 1}, {1, 0}, {1, -1}}; // texture.rs:20 (dy,dx)
 
@@ -334,10 +356,13 @@ __global__ __launch_bounds__(256) void k_glcm_classify(int64_t n, int ps, const 
 // The 14 Haralick features of one (level, offset) combination from its ten sums; one lane per combination.
 // dbg (test hook, nfx_debug_texture_counts): the six exact integers among the sums.
 // WIDE: patches above 64 x 64 hold more pairs than the x ln x table covers; that (register-rich) kernel takes plain logarithms.
+// base: the level the nucleus's levels were counted relative to (0 for the full-range structures): only the sums over s = a + b see it.
 template <bool WIDE>
-static __device__ void glcm_features(const double (&a)[GL_NACC], const GlcmLuts *__restrict__ lut, float *__restrict__ o, int64_t *__restrict__ dbg)
+static __device__ void glcm_features(const double (&a)[GL_NACC], double base, const GlcmLuts *__restrict__ lut, float *__restrict__ o, int64_t *__restrict__ dbg)
 {
-    const double N = a[0], S1 = a[1], S2 = a[2], D1 = a[3], D2 = a[4], IDM = a[5], ASMN = a[6], ENTS = a[7], HXS = a[8], HSS = a[9];
+    const double N = a[0], D1 = a[3], D2 = a[4], IDM = a[5], ASMN = a[6], ENTS = a[7], HXS = a[8], HSS = a[9];
+    // s_abs = s_rel + 2 base for each of the N pairs: exact in doubles (integers far below 2^53)
+    const double S1 = a[1] + 2.0 * base * N, S2 = a[2] + 4.0 * base * a[1] + 4.0 * base * base * N;
     if (dbg) {
         dbg[0] = (int64_t)N; dbg[1] = (int64_t)S1; dbg[2] = (int64_t)S2; dbg[3] = (int64_t)D1; dbg[4] = (int64_t)D2; dbg[5] = (int64_t)ASMN;
     }
@@ -399,26 +424,32 @@ static __device__ void glcm_features(const double (&a)[GL_NACC], const GlcmLuts 
 //       whose table holds a cell for every pair it can have (3/4 of a capacity at least 4/3 as large).
 template <typename T, int QCAP, int NPRE, bool FULL>
 __global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3 : (QCAP <= 2048 ? 2 : 1))) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int *__restrict__ cursor,
-                                             int *__restrict__ next_list, int *__restrict__ next_count, int ps,
+                                             int *__restrict__ next_list, int *__restrict__ next_count, int *__restrict__ top_list, int *__restrict__ top_count, int ps,
                                              const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
                                              const GlcmLuts *__restrict__ lut, double *__restrict__ slots, float *__restrict__ out, int F,
                                              int col0, int64_t *__restrict__ dbg)
 {
-    // never less than what lets the table memory double as the staging area of the NPRE KiB patch
-    constexpr int SLOTS_MIN = NPRE * 256 - GL_HIST_WORDS - GL_H128_OFF;
+    using G = GlGeom<FULL>;
+    constexpr int GL_HIST_WORDS = G::HIST_WORDS, GL_D64_OFF = G::D64_OFF, GL_H128_OFF = G::H128_OFF;
+    // never less than what lets the table memory (with the pass-A memo behind it: nothing of a nucleus lives there yet) double as
+    // the staging area of the NPRE KiB patch
+    constexpr int MEMO_WORDS = (QCAP + 64) / 4;
+    constexpr int SLOTS_MIN = NPRE * 256 - GL_HIST_WORDS - GL_H128_OFF - MEMO_WORDS;
     constexpr int SLOTS_WANT = FULL ? 11 * QCAP / 8 : 3 * QCAP / 4;
-    constexpr int SLOTS = SLOTS_WANT > SLOTS_MIN ? SLOTS_WANT : SLOTS_MIN;
+    constexpr int SLOTS_B = ((QCAP - GL_H128_OFF + 3) / 4) * 4; // the level-254 pass needs a slot per pair in the whole table memory
+    constexpr int SLOTS_AB = SLOTS_WANT > SLOTS_MIN ? SLOTS_WANT : SLOTS_MIN;
+    constexpr int SLOTS = SLOTS_AB > SLOTS_B ? SLOTS_AB : SLOTS_B;
     static_assert(FULL || GL_H128_OFF + SLOTS >= QCAP, "the level-254 pass hashes into the whole table memory: a cell per pair fits");
     constexpr int TAB_WORDS = GL_H128_OFF + SLOTS;
-    __shared__ __attribute__((aligned(16))) unsigned s_mem[TAB_WORDS + GL_HIST_WORDS]; // tables | histograms
+    __shared__ __attribute__((aligned(16))) unsigned s_mem[TAB_WORDS + GL_HIST_WORDS + MEMO_WORDS]; // tables | histograms | memo
     __shared__ unsigned s_q[QCAP + 1];         // list entry: r << 24 | c << 16 | level128 << 8 | level254 (levels 64 and 32
                                              // are level128 >> 1 and >> 2: floor(128 g) >> 1 == floor(64 g))
     __shared__ uint64_t s_rows1[66];         // mask row r at [r + 1]; zero rows either side
     __shared__ unsigned short s_rowstart[66];
     __shared__ unsigned s_dummy[8];    // parking words for the searches of lanes without a pair (lane & 7)
     __shared__ __attribute__((aligned(16))) double s_sums[4 * GL_NACC]; // one offset's sums (four levels), stored as one 320-byte piece
-    __shared__ unsigned char s_memo[QCAP + 64];
     unsigned *const s_tab = s_mem, *const s_hist = s_mem + TAB_WORDS;
+    unsigned char *const s_memo = reinterpret_cast<unsigned char *>(s_mem + TAB_WORDS + GL_HIST_WORDS); // [QCAP + 64]
 
     int lane = threadIdx.x;
     const int P = ps * ps;
@@ -437,6 +468,7 @@ __global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3
     // u8 patches travel through registers: the next nucleus's patch and mask row are requested as soon as the
     // current ones have been put down in LDS, so their HBM latency hides behind a whole nucleus of work
     const int n16 = (3 * P) / 16;
+    static_assert(sizeof(T) != 1 || (int)sizeof(s_mem) >= NPRE * 1024, "the staging area holds all NPRE KiB the prefetch registers put down");
     const bool stage = sizeof(T) == 1 && ((3 * P) & 15) == 0 && 3 * P <= (int)sizeof(s_mem) && 3 * P <= NPRE * 1024 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0;
     u32x4 pre[NPRE]; // a native vector type: HIP's uint4 struct is copied with memcpy, which keeps the array in scratch memory
     uint64_t row_next;
@@ -459,6 +491,7 @@ __global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3
 
     double *const slot = slots + (size_t)blockIdx.x * 16 * GL_NACC; // this wave's parking slot: [offset][level][GL_NACC]
     int64_t i_done = -1; // the nucleus whose sums sit in the slot, features not yet evaluated
+    int done_b128 = 0, done_b254 = 0; // ... and the levels its counts were taken relative to (wave-uniform)
 #pragma unroll 1
     for (;;) {
         const bool more = j < cnt; // wave-uniform
@@ -467,7 +500,7 @@ __global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3
         if (more && stage) {
             u32x4 *dst = reinterpret_cast<u32x4 *>(s_mem);
 #pragma unroll
-            for (int k = 0; k < NPRE; ++k) dst[lane + 64 * k] = pre[k]; // s_mem holds NPRE KiB: pieces past the patch land in table memory that is swept below
+            for (int k = 0; k < NPRE; ++k) dst[lane + 64 * k] = pre[k]; // s_mem holds NPRE KiB: pieces past the patch land in table / memo memory that is swept or rewritten below
         }
         // ---- the 14 features of the PREVIOUS nucleus's 16 combinations (texture.rs:81-157 order: level-major, then offset) ----
         // evaluated here, between putting down this nucleus's patch and requesting the next one's: the only point of the loop
@@ -489,7 +522,8 @@ __global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3
 #pragma unroll
                 for (int k = 0; k < GL_NACC; ++k)
                     a[k] = __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long *>(src) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                glcm_features<false>(a, lut, out + i_done * (int64_t)F + col0 + lane * 14, dbg ? dbg + (i_done * 16 + lane) * 6 : nullptr);
+                const double base = (double)(lvl == 3 ? done_b254 : (done_b128 >> (2 - lvl))); // levels 32, 64, 128 nest: floor(128 g) >> k
+                glcm_features<false>(a, base, lut, out + i_done * (int64_t)F + col0 + lane * 14, dbg ? dbg + (i_done * 16 + lane) * 6 : nullptr);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -521,6 +555,7 @@ __global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3
         wave_lds_fence();
         // ---- every masked pixel is read and quantised once, all lanes busy --------------------------------------
         const T *pp = patches + (size_t)i * 3 * P;
+        int mx128 = 0, mn128n = 0, mx254 = 0, mn254n = 0; // maxima of q and of (top - q): minima through the same non-negative maximum
         for (int e = lane; e < K; e += 128) { // two entries per lane: both read chains in flight
             const int e2 = e + 64 < K ? e + 64 : e;
             const unsigned pos = s_q[e], pos2 = s_q[e2];
@@ -538,15 +573,28 @@ __global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3
                 g = gray_at<T>(pp, P, p);
                 g2 = gray_at<T>(pp, P, p2);
             }
-            s_q[e] = pos | (quant(g, 128) << 8) | quant(g, 254); // texture.rs:19
-            if (e + 64 < K) s_q[e + 64] = pos2 | (quant(g2, 128) << 8) | quant(g2, 254);
+            const unsigned qa128 = quant(g, 128), qa254 = quant(g, 254), qb128 = quant(g2, 128), qb254 = quant(g2, 254); // texture.rs:19
+            s_q[e] = pos | (qa128 << 8) | qa254;
+            if (e + 64 < K) s_q[e + 64] = pos2 | (qb128 << 8) | qb254;
+            // (entry e2 repeats entry e when e + 64 is past the list: harmless for a minimum / maximum)
+            mx128 = max(mx128, (int)max(qa128, qb128)); mn128n = max(mn128n, 127 - (int)min(qa128, qb128));
+            mx254 = max(mx254, (int)max(qa254, qb254)); mn254n = max(mn254n, 253 - (int)min(qa254, qb254));
         }
+        // ---- the nucleus's level span: counts are taken relative to its lowest level (GlGeom), in EVERY instantiation -- a
+        // nucleus's bins meet the same lanes and its sums the same order whichever class it runs in: identical bits -----------
+        const int hi128 = wave_max_nonneg_i32(mx128), lo128 = 127 - wave_max_nonneg_i32(mn128n);
+        const int hi254 = wave_max_nonneg_i32(mx254), lo254 = 253 - wave_max_nonneg_i32(mn254n);
+        const int b128 = K > 0 ? (lo128 & ~3) : 0; // a multiple of 4: levels 64 and 32 stay shifts of the relative level 128
+        const int b254 = K > 0 ? lo254 : 0;
+        const bool span_fits = FULL || K == 0 || (hi128 - b128 < G::R128 && hi254 - b254 < G::R254); // wave-uniform
+        const u16x2 base2 = {(unsigned short)b128, (unsigned short)b128}, base3 = {(unsigned short)b254, (unsigned short)b254};
+        if (lane == 0) s_q[K] = ((unsigned)b128 << 8) | (unsigned)b254; // what an entry without a partner may read as its partner: a word of the list's own kind
         wave_lds_fence();
         sweep(s_hist, GL_HIST_WORDS, 0u, lane);
         if (lane < 8) s_dummy[lane] = GL_DUMMY;
         bool abandoned = false;
 #pragma unroll 1
-        for (int oi = 0; oi < 4; ++oi) {
+        for (int oi = 0; oi < (span_fits ? 4 : 0); ++oi) {
             const int dy = kGlcmOffsets[oi][0], dx = kGlcmOffsets[oi][1];
             sweep(s_tab, GL_H128_OFF, 0u, lane);               // pass A's dense tables start from zero
             sweep(s_tab + GL_H128_OFF, SLOTS, GL_EMPTY, lane); // and its hash table from empty
@@ -569,7 +617,7 @@ __global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3
                 const Located X = locate(e, true, ps, dy, dx, s_q, s_rows1, s_rowstart);
                 const Located Y = locate(e + 64, e + 64 < K, ps, dy, dx, s_q, s_rows1, s_rowstart);
                 // levels of both entries packed: .x = entry e, .y = entry e + 64 (level128 is byte 1 of a list word; 64 and 32 by shift)
-                const u16x2 a2 = bytes2<1>(X.qa, Y.qa), b2 = bytes2<1>(X.qb, Y.qb);
+                const u16x2 a2 = bytes2<1>(X.qa, Y.qa) - base2, b2 = bytes2<1>(X.qb, Y.qb) - base2; // (an entry without a partner reads a list word all the same)
                 const u16x2 a1 = a2 >> (u16x2){1, 1}, b1 = b2 >> (u16x2){1, 1};
                 const u16x2 a0 = a2 >> (u16x2){2, 2}, b0 = b2 >> (u16x2){2, 2};
                 const Ordered2 P0 = order2(a0, b0), P1 = order2(a1, b1), P2 = order2(a2, b2);
@@ -609,9 +657,10 @@ __global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3
                 // fold: read and clear the histogram words, request every x ln x together, and only then do the
                 // table sweep and the power-sum reductions, so the look-ups' round trip hides behind them
                 const uint2 h2 = reinterpret_cast<const uint2 *>(s_hist)[lane]; // hx128[2 lane], hx128[2 lane + 1]
+                constexpr int NS = G::HS128_SLICES;                               // slices of the level-128 sum histogram: 4, or 3 (zeros beyond)
                 unsigned hv[7];
 #pragma unroll
-                for (int m = 0; m < 7; ++m) hv[m] = s_hist[128 + lane + 64 * m];
+                for (int m = 0; m < 7; ++m) hv[m] = m < 3 + NS ? s_hist[128 + lane + 64 * m] : 0u;
                 const unsigned n64 = h2.x + h2.y;                       // hx64[lane]
                 const unsigned n32 = n64 + (unsigned)__shfl_down((int)n64, 1, 64); // hx32[lane / 2] on even lanes
                 const unsigned n32e = (lane & 1) ? 0u : n32;
@@ -619,17 +668,17 @@ __global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3
                 const double f64_ = lut->xlnx[n64], f32_ = lut->xlnx[n32e];
                 double fs[7];
 #pragma unroll
-                for (int m = 0; m < 7; ++m) fs[m] = lut->xlnx[hv[m]];
-                sweep(s_hist, 576, 0u, lane);
+                for (int m = 0; m < 7; ++m) fs[m] = m < 3 + NS ? lut->xlnx[hv[m]] : 0.0;
+                sweep(s_hist, G::HIST_A, 0u, lane);
                 sweep(s_tab, TAB_WORDS, GL_EMPTY, lane); // pass B's hash table is the WHOLE table memory (d32, d64 and h128 are
-                                                          // done): 2.3-2.7 slots per entry, so fewer searches need a second probe
+                                                          // done): more slots per entry, so fewer searches need a second probe
                                                           // and the wave's iteration -- as slow as its unluckiest key -- ends sooner
                 const double hx128 = f0 + f1;
                 const double hx64 = f64_, hx32 = f32_;
                 double e[7];
 #pragma unroll
                 for (int m = 0; m < 7; ++m) e[m] = fs[m];
-                const double hs32 = e[0], hs64 = e[1] + e[2], hs128 = (e[3] + e[4]) + (e[5] + e[6]);
+                const double hs32 = e[0], hs64 = e[1] + e[2], hs128 = (e[3] + e[4]) + (e[5] + e[6]); // (e[6] is an exact zero in the 3-slice layout)
                 {   // sum s n_s and sum s^2 n_s: word 128 + lane + 64 m holds n_s of s = lane (level 32), lane + 64 (m - 1), lane + 64 (m - 3)
                     const unsigned s0 = (unsigned)lane, s1 = s0 + 64u, s2 = s0 + 128u, s3 = s0 + 192u;
                     A0.S1 = s0 * hv[0];                A0.S2 = s0 * s0 * hv[0];
@@ -664,7 +713,7 @@ __global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3
             }
             wave_lds_fence();
             // ================= pass B: level 254 ===================================================================
-            // histogram words: hx 0..253 | hs 256..762
+            // histogram words: hx254 at 0 (HXB slices of 64) | hs254 behind it (2 HXB slices); levels relative to the nucleus's lowest
             unsigned pend3[2] = {0u, 0u};
             bool table_full_b = false; // (cannot happen: TAB_WORDS >= QCAP, asserted above)
 #pragma unroll 1
@@ -672,14 +721,14 @@ __global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3
                 const double ev30 = rank_tab[pend3[0]], ev31 = rank_tab[pend3[1]];
                 const Located X = relocate(e, true, s_q, s_memo);
                 const Located Y = relocate(e + 64, e + 64 < K, s_q, s_memo);
-                const u16x2 a3 = bytes2<0>(X.qa, Y.qa), b3 = bytes2<0>(X.qb, Y.qb); // level254 is byte 0 of a list word
+                const u16x2 a3 = bytes2<0>(X.qa, Y.qa) - base3, b3 = bytes2<0>(X.qb, Y.qb) - base3; // level254 is byte 0 of a list word
                 const Ordered2 P3 = order2(a3, b3);
                 const unsigned fmask = (X.fwd ? 0xFFFFu : 0u) | (Y.fwd ? 0xFFFF0000u : 0u);
                 atomicAdd(&s_hist[a3.x], X.deg);
                 atomicAdd(&s_hist[a3.y], Y.deg);
                 const u16x2 s3 = a3 + b3;
-                atomicAdd(&s_hist[256 + s3.x], X.fwd ? 1u : 0u);
-                atomicAdd(&s_hist[256 + s3.y], Y.fwd ? 1u : 0u);
+                atomicAdd(&s_hist[64 * G::HXB + s3.x], X.fwd ? 1u : 0u);
+                atomicAdd(&s_hist[64 * G::HXB + s3.y], Y.fwd ? 1u : 0u);
                 unsigned rx, ry;
                 const u16x2 k3 = cell_key2(P3);
                 hash_rank2<TAB_WORDS>(s_tab, s_dummy + (lane & 7), k3.x, X.fwd, k3.y, Y.fwd, rx, ry, table_full_b);
@@ -689,21 +738,25 @@ __global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3
             A3.ents += rank_tab[pend3[0]] + rank_tab[pend3[1]];
             wave_lds_fence();
             {
-                unsigned hv[12];
+                constexpr int HXB = G::HXB, HSB = G::HSB; // slices of hx254 and of hs254 that exist in this layout (4 + 8, or 3 + 6)
+                // the sums below are written for the full layout; a slice the 3-slice layout lacks is an exact zero in it (and holds
+                // only zeros for such a nucleus in the full one), so both layouts add the same numbers in the same order
+                unsigned hx_[4], hs_[8];
 #pragma unroll
-                for (int m = 0; m < 12; ++m) hv[m] = s_hist[lane + 64 * m];
-                double fs[12];
+                for (int m = 0; m < 4; ++m) hx_[m] = m < HXB ? s_hist[lane + 64 * m] : 0u;
 #pragma unroll
-                for (int m = 0; m < 12; ++m) fs[m] = lut->xlnx[hv[m]];
-                sweep(s_hist, GL_HIST_WORDS, 0u, lane);
-                double e[12];
+                for (int m = 0; m < 8; ++m) hs_[m] = m < HSB ? s_hist[64 * HXB + lane + 64 * m] : 0u;
+                double ex[4], es[8];
 #pragma unroll
-                for (int m = 0; m < 12; ++m) e[m] = fs[m];
+                for (int m = 0; m < 4; ++m) ex[m] = m < HXB ? lut->xlnx[hx_[m]] : 0.0;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) es[m] = m < HSB ? lut->xlnx[hs_[m]] : 0.0;
+                sweep(s_hist, G::HIST_B, 0u, lane);
                 A3.S1 = 0u; A3.S2 = 0u;
 #pragma unroll
-                for (int m = 4; m < 12; ++m) { const unsigned sv = (unsigned)lane + 64u * (unsigned)(m - 4); A3.S1 += sv * hv[m]; A3.S2 += sv * sv * hv[m]; }
-                const double hx = (e[0] + e[1]) + (e[2] + e[3]);
-                const double hs = ((e[4] + e[5]) + (e[6] + e[7])) + ((e[8] + e[9]) + (e[10] + e[11]));
+                for (int m = 0; m < 8; ++m) { const unsigned sv = (unsigned)lane + 64u * (unsigned)m; A3.S1 += sv * hs_[m]; A3.S2 += sv * sv * hs_[m]; }
+                const double hx = (ex[0] + ex[1]) + (ex[2] + ex[3]);
+                const double hs = ((es[0] + es[1]) + (es[2] + es[3])) + ((es[4] + es[5]) + (es[6] + es[7]));
                 unsigned U[8] = {A3.S1, A3.S2, A3.D1, A3.D2, A3.asmn, 0u, 0u, 0u};
                 double Dv[4] = {A3.ents, hx, hs, 0.0};
                 const unsigned ut = wave_reduce_scatter(U, lane);
@@ -724,7 +777,11 @@ __global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3
         if (abandoned) { // more distinct level-128 cells than the typical-size table holds: the next class takes the nucleus
             if (lane == 0) next_list[atomicAdd(next_count, 1)] = (int)i;
             i_done = -1; // nothing of it is evaluated here
+        } else if (!span_fits) { // gray levels spread over more of the scale than the typical-size tables cover: the top class (full range) takes it
+            if (lane == 0) top_list[atomicAdd(top_count, 1)] = (int)i;
+            i_done = -1;
         }
+        done_b128 = b128; done_b254 = b254;
         j = jn;
     }
 }
@@ -835,7 +892,7 @@ __global__ __launch_bounds__(256) void k_glcm_wide(int64_t n, int ps, const T *_
             double a[GL_NACC];
 #pragma unroll
             for (int k = 0; k < GL_NACC; ++k) a[k] = s_sums[t][k];
-            glcm_features<true>(a, lut, out + i * (int64_t)F + col0 + t * 14, dbg ? dbg + (i * 16 + t) * 6 : nullptr);
+            glcm_features<true>(a, 0.0, lut, out + i * (int64_t)F + col0 + t * 14, dbg ? dbg + (i * 16 + t) * 6 : nullptr);
         }
         __syncthreads();
     }
@@ -879,7 +936,7 @@ hipError_t prepare_glcm(nfx_ctx *ctx)
 // holds (asked of the runtime once per instantiation: LDS allocation granularity and register budget included); blocks
 // beyond a list's length exit at once.
 template <typename T, int QCAP, int NPRE, bool FULL>
-static void launch_class(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *slots, const int *lists, const int *counts, int cls, int col0)
+static void launch_class(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *slots, const int *lists, const int *counts, int cls, int top, int col0)
 {
     static int wgs_per_cu = 0; // same answer for every context: one device type per process
     if (wgs_per_cu == 0) {
@@ -893,8 +950,11 @@ static void launch_class(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, doub
     // a nucleus that does not fit a typical-size table moves on to the next class's list (that launch has not started yet)
     int *next_list = FULL ? nullptr : const_cast<int *>(lists) + (int64_t)(cls + 1) * job.n;
     int *next_count = FULL ? nullptr : const_cast<int *>(counts) + cls + 1;
+    // ... and one whose gray levels span more of the scale than the typical-size tables to the top class's (full-range structures)
+    int *top_list = FULL ? nullptr : const_cast<int *>(lists) + (int64_t)top * job.n;
+    int *top_count = FULL ? nullptr : const_cast<int *>(counts) + top;
     hipLaunchKernelGGL((k_glcm<T, QCAP, NPRE, FULL>), dim3(grid), dim3(64), 0, ctx->stream, lists + (int64_t)cls * job.n, counts + cls, const_cast<int *>(counts) + GL_CLASSES + cls,
-                       next_list, next_count, job.ps,
+                       next_list, next_count, top_list, top_count, job.ps,
                        reinterpret_cast<const T *>(job.patches), job.mask_rows, lut, slots, job.out, job.F, col0, job.dbg_glcm);
 }
 
@@ -905,8 +965,8 @@ static void launch_classes(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, do
     auto run = [&](int cls) { return cls <= top && (only < 0 || only == cls); };
 #define NFX_GL_CLASS(CLS, QCAP)                                                                                         \
     if (run(CLS)) {                                                                                                     \
-        if (CLS == top) launch_class<T, QCAP, NPRE, true>(ctx, job, lut, slots, lists, counts, CLS, col0);              \
-        else launch_class<T, QCAP, NPRE, false>(ctx, job, lut, slots, lists, counts, CLS, col0);                        \
+        if (CLS == top) launch_class<T, QCAP, NPRE, true>(ctx, job, lut, slots, lists, counts, CLS, top, col0);         \
+        else launch_class<T, QCAP, NPRE, false>(ctx, job, lut, slots, lists, counts, CLS, top, col0);                   \
     }
     NFX_GL_CLASS(0, 512)
     NFX_GL_CLASS(1, 768)

@@ -108,7 +108,8 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     if (batch_size < 1) return api_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "batch_size must be >= 1");
     if (!ring_offsets || (nv && !ring_xy) || !out_rows) return api_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null input");
     const bool pix = any_pixel_set(sets, n_sets);
-    if (!pix || n == 0) // nothing to stream: geometry needs no pixels
+    if (n == 0) return NFX_OK;
+    if (!pix) // nothing to stream: geometry needs no pixels
         return nfx_extract(ctx, sets, n_sets, n, nv, ring_offsets, ring_xy, nullptr, ps, batch_size, out_rows, out_centroids_xy, NFX_MEM_HOST);
     if (!image_u8 || H < 1 || W < 1) return api_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "null or empty image");
     NFX_HIP(ctx, hipSetDevice(ctx->device));

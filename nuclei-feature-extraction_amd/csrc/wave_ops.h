@@ -24,6 +24,18 @@ static __device__ __forceinline__ int wave_total_i32(int v)
 }
 static __device__ __forceinline__ unsigned wave_total_u32(unsigned v) { return (unsigned)wave_total_i32((int)v); }
 
+// maximum of NON-NEGATIVE values over the wave (0, the fill value of the masked DPP steps, is their neutral element)
+static __device__ __forceinline__ int wave_max_nonneg_i32(int v)
+{
+    v = max(v, dpp_i32<0xB1, 0xF>(v));
+    v = max(v, dpp_i32<0x4E, 0xF>(v));
+    v = max(v, dpp_i32<0x141, 0xF>(v));
+    v = max(v, dpp_i32<0x140, 0xF>(v));
+    v = max(v, dpp_i32<0x142, 0xA>(v));
+    v = max(v, dpp_i32<0x143, 0xC>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // inclusive prefix sum over the 64 lanes, DPP only: Hillis-Steele inside each row of 16 (row_shr 1, 2, 4, 8 with zero
 // fill), then the row totals carried across rows (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3)
 static __device__ __forceinline__ int wave_inclusive_scan_i32(int v)

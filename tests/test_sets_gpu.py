@@ -133,3 +133,51 @@ def test_glcm_noise_textures_move_on_to_the_next_size_class(nfx, ctx, ps, n):
     par.assert_rows_close(got, want, par.column_scales(nfx, [2], ps), what=f"glcm noise ps={ps}")
     again, _ = ctx.extract([2], off, xy, pu8, ps, batch_size=100)
     assert np.array_equal(got, again, equal_nan=True)
+
+
+@pytest.mark.parametrize("ps,n", [(48, 2400), (64, 1300)])
+def test_glcm_wide_level_spans_go_to_the_full_range_class(nfx, ctx, ps, n):
+    """Outside the top class of a patch size the dense tables and histograms cover 3/4 of the gray scale, counted from the
+    nucleus's lowest level (k_glcm.hip, GlGeom).  Tissue-like nuclei span 0.6 of it; here every fourth nucleus gets a black and a
+    white pixel at its centre (full span, smooth texture: the hash table does NOT fill), every fifth a span just below / above the
+    limit: the kernel hands what does not fit to the top class's list before counting anything.  The integers behind the columns
+    == the oracle's for every nucleus, rows against the oracle, same bits run after run."""
+    off, xy, pu8 = par.make_inputs(700 + ps, n, ps)
+    pu8 = pu8.copy()
+    c = ps // 2
+    wide = np.arange(n) % 4 == 0
+    pu8[wide, :, c, c] = 0
+    pu8[wide, :, c, c + 1] = 255
+    edge = np.arange(n) % 5 == 1                     # spans of 0.745 .. 0.76 of the scale around the 3/4 limit
+    lo = 20
+    for k, i in enumerate(np.nonzero(edge)[0]):
+        pu8[i] = np.clip(pu8[i], lo, 255)
+        pu8[i, :, c, c] = lo
+        pu8[i, :, c, c + 1] = lo + 188 + (k % 6)
+    want, _ = orc.extract([2], off, xy, pu8, ps, batch_size=100, threads=16)
+    got, _ = ctx.extract([2], off, xy, pu8, ps, batch_size=100)
+    par.assert_rows_close(got, want, par.column_scales(nfx, [2], ps), what=f"glcm wide spans ps={ps}")
+    again, _ = ctx.extract([2], off, xy, pu8, ps, batch_size=100)
+    assert np.array_equal(got, again, equal_nan=True)
+    m = 160
+    gs, _ = ctx.debug_texture_counts(off[:m + 1], xy[:off[m]], pu8[:m], ps, glrlm=False)     # a small call: ONE launch of the full-range class
+    ws, _ = orc.texture_counts(off[:m + 1], xy[:off[m]], pu8[:m], ps)
+    assert np.array_equal(gs, ws)
+    big, _ = ctx.debug_texture_counts(off, xy, pu8, ps, glrlm=False)                         # the size classes, hand-overs included
+    assert np.array_equal(big[:m], ws)
+
+
+@pytest.mark.parametrize("ps", [32, 48, 64])
+def test_glcm_rows_do_not_depend_on_the_class_a_nucleus_ran_in(nfx, ctx, ps):
+    """A call of up to 768 nuclei runs as one launch of the full-range class, a larger one through the typical-size classes: the
+    same nucleus must come out with the same BITS either way (levels are taken relative to its lowest level in every
+    instantiation, so its bins meet the same lanes and its sums the same order) -- an index-sharded run on several GPUs hands
+    the last rank a short shard."""
+    n = 3000
+    off, xy, pu8 = par.make_inputs(800 + ps, n, ps)
+    big, _ = ctx.extract([2], off, xy, pu8, ps, batch_size=100)
+    for i0 in (0, 1100, 2400):
+        m = 600
+        o = (off[i0:i0 + m + 1] - off[i0]).astype(np.uint32)
+        small, _ = ctx.extract([2], o, xy[off[i0]:off[i0 + m]], pu8[i0:i0 + m], ps, batch_size=100)
+        assert np.array_equal(small.view(np.uint32), big[i0:i0 + m].view(np.uint32)), np.argwhere(small.view(np.uint32) != big[i0:i0 + m].view(np.uint32))[:5]
