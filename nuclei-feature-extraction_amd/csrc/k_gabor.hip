@@ -164,10 +164,16 @@ template <int N> using gb_int = std::integral_constant<int, N>;
 // strip sizes a workgroup of GB_WAVES waves can meet: TSR = ceil(ncol / GB_WAVES) <= GB_MAX_TSR, CT = ceil(nrow / (64 / TSR)) <= GB_MAX_CT
 static constexpr int GB_MAX_TSR = (NFX_ROW_WORD_PS + GB_WAVES - 1) / GB_WAVES;
 static constexpr int GB_MAX_CT = (NFX_ROW_WORD_PS + (64 / GB_MAX_TSR) - 1) / (64 / GB_MAX_TSR);
+// the shared column passes of the envelope groups keep three accumulator sets at once (6 CT registers beside the 2 (CT + 29) of the
+// window): taller strips (boxes beyond ~50 rows) take the pass-by-pass form
+#ifndef NFX_GB_EVEN3_MAX_CT
+#define NFX_GB_EVEN3_MAX_CT 10
+#endif
+static constexpr int GB_EVEN3_MAX_CT = NFX_GB_EVEN3_MAX_CT;
 #define NFX_GB_CASE(N, MAXN, F) case N: if constexpr (N <= MAXN) F(gb_int<N>{}); break;
 
 static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const GaborTables *__restrict__ tab, int n_groups, int n_plain, int ps,
-                                                     const GaborView *s_view, const float *s_shift, int t,
+                                                     const GaborView *s_view, float mu_gray, const float *s_shift, bool refined, int t,
                                                      double (*s_part)[GB_MAX_FILTERS][2], int dbg)
 {
     const int lane = t & 63, wv = t >> 6;
@@ -326,9 +332,14 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
                 const int meta = __float_as_int(wp[GB_META + 2]); // combine | slot0 << 8 | slot1 << 16 (255: none)
                 f2 a = {0.0f, 0.0f}, b = {0.0f, 0.0f};
                 f2 acc[CT];
-                // per-filter shift of this attempt (k_gabor: DC gain x mean masked gray first; the measured mean if that was far off)
-                const int fs0 = (meta >> 8) & 255, fs1 = (meta >> 16) & 255;
-                const float sh0 = s_shift[fs0 != 255 ? fs0 : 0], sh1 = fs1 != 255 ? s_shift[fs1] : 0.0f;
+                // per-filter shift of this attempt (k_gabor): DC gain x mean masked gray -- two scalar operands -- on the first; on the
+                // rare second one the mean the first attempt measured (LDS; wave-uniform branch)
+                float sh0 = wp[GB_META] * mu_gray, sh1 = wp[GB_META + 1] * mu_gray;
+                if (refined) {
+                    const int fs0 = (meta >> 8) & 255, fs1 = (meta >> 16) & 255;
+                    sh0 = s_shift[fs0 != 255 ? fs0 : 0];
+                    sh1 = fs1 != 255 ? s_shift[fs1] : 0.0f;
+                }
                 // the accumulators start at minus the shift (for the mixed pair: A - B starts at -sh0, A + B at -sh1), so
                 // the responses come out already shifted; masked partial sums of the strip's responses follow (f32
                 // inside the strip and the wave, f64 across waves)
@@ -365,7 +376,101 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
                 }
             }
         };
+        // ENVELOPE groups (90 degrees; 0 degrees on the transposed view): the plane pair holds the same envelope-filtered image
+        // twice and all three column passes have EVEN kernels (G(y) cos B y on a grid that is symmetric about 0: tap j equals tap
+        // 29 - j), so the two taps share one multiplication:
+        //     acc[o] = sum_{j < 15} w_j (x[o + j] + x[o + 29 - j])
+        // and the sums x[o + j] + x[o + 29 - j] serve all three passes: 15 adds + 45 packed FMAs per output instead of 90 packed FMAs.
+        // (Tap 29 - j takes tap j's weight: the two are the same real number and differ by at most one f32 rounding in the table.)
+        auto column_passes_even3 = [&](auto ct_tag) {
+            constexpr int CT = decltype(ct_tag)::value, CWIN = CT + GB_SIZE - 1, HALF = GB_SIZE / 2;
+            float x[CWIN]; // both halves of the plane pair hold the same number here: one register per window element
+#pragma unroll
+            for (int j = 0; j < CWIN; ++j) x[j] = su[j * GB_UW].x;
+            const float *__restrict__ w0 = img + 1 * GB_WSLOT, *__restrict__ w1 = img + 2 * GB_WSLOT, *__restrict__ w2 = img + 3 * GB_WSLOT;
+            f2 acc[3][CT];
+            float sh[3][2];
+            int metas[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const float *__restrict__ wp = img + (1 + p) * GB_WSLOT;
+                metas[p] = __float_as_int(wp[GB_META + 2]);
+                sh[p][0] = wp[GB_META] * mu_gray;
+                sh[p][1] = wp[GB_META + 1] * mu_gray;
+                if (refined) {
+                    const int fs0 = (metas[p] >> 8) & 255, fs1 = (metas[p] >> 16) & 255;
+                    sh[p][0] = s_shift[fs0 != 255 ? fs0 : 0];
+                    sh[p][1] = fs1 != 255 ? s_shift[fs1] : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < CT; ++q) acc[p][q] = (f2){-sh[p][0], -sh[p][1]};
+            }
+            // the 45 tap pairs do not fit the scalar registers at once (102, of which the kernel's own state takes a third): two
+            // halves of 8 and 7 taps, the second half's loads issued when the first half's FMAs are under way
+            auto half_taps = [&](auto j0_tag, auto nj_tag) {
+                constexpr int J0 = decltype(j0_tag)::value, NJ = decltype(nj_tag)::value;
+                f2 t0[NJ], t1[NJ], t2[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    t0[j] = (f2){w0[2 * (J0 + j)], w0[2 * (J0 + j) + 1]};
+                    t1[j] = (f2){w1[2 * (J0 + j)], w1[2 * (J0 + j) + 1]};
+                    t2[j] = (f2){w2[2 * (J0 + j)], w2[2 * (J0 + j) + 1]};
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                    for (int q = 0; q < CT; ++q) {
+                        const float s1 = x[q + J0 + j] + x[q + GB_SIZE - 1 - (J0 + j)];
+                        const f2 sj = {s1, s1};
+                        acc[0][q] = __builtin_elementwise_fma(t0[j], sj, acc[0][q]);
+                        acc[1][q] = __builtin_elementwise_fma(t1[j], sj, acc[1][q]);
+                        acc[2][q] = __builtin_elementwise_fma(t2[j], sj, acc[2][q]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            half_taps(gb_int<0>{}, gb_int<8>{});
+            half_taps(gb_int<8>{}, gb_int<HALF - 8>{});
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                f2 a = {0.0f, 0.0f}, b = {0.0f, 0.0f};
+#pragma unroll
+                for (int q = 0; q < CT; ++q) {
+                    const float mq = ((mbits >> q) & 1u) ? 1.0f : 0.0f;
+                    const f2 d = acc[p][q] * (f2){mq, mq};
+                    a += d;
+                    b = __builtin_elementwise_fma(d, d, b);
+                }
+                float tot[4] = {a.x, b.x, a.y, b.y};
+                const float mine = wave_reduce_scatter(tot, lane);
+                if (lane < 4) {
+                    const int which = scatter_index<4>(lane);
+                    const int f = (metas[p] >> (8 + 8 * (which >> 1))) & 255;
+                    if (f != 255) s_part[wv][f][which & 1] = (double)mine;
+                }
+            }
+        };
         if (!(dbg & 2)) {
+            if (envelope && n_pass == 3 && ct <= GB_EVEN3_MAX_CT && !(dbg & 8)) {
+                switch (ct) {
+                NFX_GB_CASE(2, GB_EVEN3_MAX_CT, column_passes_even3)
+                NFX_GB_CASE(3, GB_EVEN3_MAX_CT, column_passes_even3)
+                NFX_GB_CASE(4, GB_EVEN3_MAX_CT, column_passes_even3)
+                NFX_GB_CASE(5, GB_EVEN3_MAX_CT, column_passes_even3)
+                NFX_GB_CASE(6, GB_EVEN3_MAX_CT, column_passes_even3)
+                NFX_GB_CASE(7, GB_EVEN3_MAX_CT, column_passes_even3)
+                NFX_GB_CASE(8, GB_EVEN3_MAX_CT, column_passes_even3)
+                NFX_GB_CASE(9, GB_EVEN3_MAX_CT, column_passes_even3)
+                NFX_GB_CASE(10, GB_EVEN3_MAX_CT, column_passes_even3)
+                NFX_GB_CASE(11, GB_EVEN3_MAX_CT, column_passes_even3)
+                NFX_GB_CASE(12, GB_EVEN3_MAX_CT, column_passes_even3)
+                NFX_GB_CASE(13, GB_EVEN3_MAX_CT, column_passes_even3)
+                NFX_GB_CASE(14, GB_EVEN3_MAX_CT, column_passes_even3)
+                NFX_GB_CASE(15, GB_EVEN3_MAX_CT, column_passes_even3)
+                NFX_GB_CASE(16, GB_EVEN3_MAX_CT, column_passes_even3)
+                default: break;
+                }
+            } else {
             switch (ct) {
             NFX_GB_CASE(2, GB_MAX_CT, column_passes)
             NFX_GB_CASE(3, GB_MAX_CT, column_passes)
@@ -383,6 +488,7 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
             NFX_GB_CASE(15, GB_MAX_CT, column_passes)
             NFX_GB_CASE(16, GB_MAX_CT, column_passes)
             default: break;
+            }
             }
         }
         wave_lds_fence(); // the next group's row pass overwrites the columns read above
@@ -524,7 +630,7 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
         for (int attempt = 0; attempt < 2; ++attempt) {
             if (lane < GB_MAX_FILTERS) { s_part[wv][lane][0] = 0.0; s_part[wv][lane][1] = 0.0; } // a wave whose strip lies outside the box adds nothing
             __syncthreads();
-            gabor_nucleus(S, tab, n_groups, n_plain, ps, s_view, s_shift, t, s_part, dbg);
+            gabor_nucleus(S, tab, n_groups, n_plain, ps, s_view, mu_gray, s_shift, attempt != 0, t, s_part, dbg);
             __syncthreads();
             // ---- mean / variance (texture.rs:339-344) from the shifted sums: mean = c + s1/K, var = s2/K - (s1/K)^2 -----
             bool off_centre = false;
@@ -532,7 +638,7 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
             if (t < n_filters) {
                 const GaborFilter &Fl = tab->filters[t];
                 const double K = (double)area;
-                const double shift = (double)s_shift[t];
+                const double shift = (double)s_shift[t]; // attempt 0: Fl.dc * mu_gray, the very product the passes formed from their scalar operands
                 double a = 0.0, b = 0.0;
 #pragma unroll
                 for (int w = 0; w < GB_WAVES; ++w) { a += s_part[w][t][0]; b += s_part[w][t][1]; }
