@@ -46,6 +46,9 @@ namespace nfx {
 
 static constexpr int GB_SIZE = 30, GB_PAD = 15, GB_THREADS = 256, GB_WAVES = GB_THREADS / 64;
 static_assert(GB_WAVES == 4, "four strips of TSR <= 16 columns tile the plane's 64 columns; the transposed-mask step hands 16 rows to a wave");
+#ifndef NFX_GB_REDO_RATIO
+#define NFX_GB_REDO_RATIO 8.0 // (s1/K)^2 / var beyond which a nucleus is done again with the measured mean as shift (k_gabor)
+#endif
 static constexpr int GB_GW = NFX_ROW_WORD_PS + GB_SIZE - 1; // gray row with apron: 93 floats
 static constexpr int GB_UW = NFX_ROW_WORD_PS + 1;           // U/W row stride (odd: conflict-free both ways)
 static constexpr int GB_UH = NFX_ROW_WORD_PS + GB_SIZE - 1; // U/W rows incl. zero aprons: 93
@@ -164,12 +167,6 @@ template <int N> using gb_int = std::integral_constant<int, N>;
 // strip sizes a workgroup of GB_WAVES waves can meet: TSR = ceil(ncol / GB_WAVES) <= GB_MAX_TSR, CT = ceil(nrow / (64 / TSR)) <= GB_MAX_CT
 static constexpr int GB_MAX_TSR = (NFX_ROW_WORD_PS + GB_WAVES - 1) / GB_WAVES;
 static constexpr int GB_MAX_CT = (NFX_ROW_WORD_PS + (64 / GB_MAX_TSR) - 1) / (64 / GB_MAX_TSR);
-// the shared column passes of the envelope groups keep three accumulator sets at once (6 CT registers beside the 2 (CT + 29) of the
-// window): taller strips (boxes beyond ~50 rows) take the pass-by-pass form
-#ifndef NFX_GB_EVEN3_MAX_CT
-#define NFX_GB_EVEN3_MAX_CT 10
-#endif
-static constexpr int GB_EVEN3_MAX_CT = NFX_GB_EVEN3_MAX_CT;
 #define NFX_GB_CASE(N, MAXN, F) case N: if constexpr (N <= MAXN) F(gb_int<N>{}); break;
 
 static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const GaborTables *__restrict__ tab, int n_groups, int n_plain, int ps,
@@ -376,101 +373,7 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
                 }
             }
         };
-        // ENVELOPE groups (90 degrees; 0 degrees on the transposed view): the plane pair holds the same envelope-filtered image
-        // twice and all three column passes have EVEN kernels (G(y) cos B y on a grid that is symmetric about 0: tap j equals tap
-        // 29 - j), so the two taps share one multiplication:
-        //     acc[o] = sum_{j < 15} w_j (x[o + j] + x[o + 29 - j])
-        // and the sums x[o + j] + x[o + 29 - j] serve all three passes: 15 adds + 45 packed FMAs per output instead of 90 packed FMAs.
-        // (Tap 29 - j takes tap j's weight: the two are the same real number and differ by at most one f32 rounding in the table.)
-        auto column_passes_even3 = [&](auto ct_tag) {
-            constexpr int CT = decltype(ct_tag)::value, CWIN = CT + GB_SIZE - 1, HALF = GB_SIZE / 2;
-            float x[CWIN]; // both halves of the plane pair hold the same number here: one register per window element
-#pragma unroll
-            for (int j = 0; j < CWIN; ++j) x[j] = su[j * GB_UW].x;
-            const float *__restrict__ w0 = img + 1 * GB_WSLOT, *__restrict__ w1 = img + 2 * GB_WSLOT, *__restrict__ w2 = img + 3 * GB_WSLOT;
-            f2 acc[3][CT];
-            float sh[3][2];
-            int metas[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const float *__restrict__ wp = img + (1 + p) * GB_WSLOT;
-                metas[p] = __float_as_int(wp[GB_META + 2]);
-                sh[p][0] = wp[GB_META] * mu_gray;
-                sh[p][1] = wp[GB_META + 1] * mu_gray;
-                if (refined) {
-                    const int fs0 = (metas[p] >> 8) & 255, fs1 = (metas[p] >> 16) & 255;
-                    sh[p][0] = s_shift[fs0 != 255 ? fs0 : 0];
-                    sh[p][1] = fs1 != 255 ? s_shift[fs1] : 0.0f;
-                }
-#pragma unroll
-                for (int q = 0; q < CT; ++q) acc[p][q] = (f2){-sh[p][0], -sh[p][1]};
-            }
-            // the 45 tap pairs do not fit the scalar registers at once (102, of which the kernel's own state takes a third): two
-            // halves of 8 and 7 taps, the second half's loads issued when the first half's FMAs are under way
-            auto half_taps = [&](auto j0_tag, auto nj_tag) {
-                constexpr int J0 = decltype(j0_tag)::value, NJ = decltype(nj_tag)::value;
-                f2 t0[NJ], t1[NJ], t2[NJ];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    t0[j] = (f2){w0[2 * (J0 + j)], w0[2 * (J0 + j) + 1]};
-                    t1[j] = (f2){w1[2 * (J0 + j)], w1[2 * (J0 + j) + 1]};
-                    t2[j] = (f2){w2[2 * (J0 + j)], w2[2 * (J0 + j) + 1]};
-                }
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-                    for (int q = 0; q < CT; ++q) {
-                        const float s1 = x[q + J0 + j] + x[q + GB_SIZE - 1 - (J0 + j)];
-                        const f2 sj = {s1, s1};
-                        acc[0][q] = __builtin_elementwise_fma(t0[j], sj, acc[0][q]);
-                        acc[1][q] = __builtin_elementwise_fma(t1[j], sj, acc[1][q]);
-                        acc[2][q] = __builtin_elementwise_fma(t2[j], sj, acc[2][q]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            };
-            half_taps(gb_int<0>{}, gb_int<8>{});
-            half_taps(gb_int<8>{}, gb_int<HALF - 8>{});
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                f2 a = {0.0f, 0.0f}, b = {0.0f, 0.0f};
-#pragma unroll
-                for (int q = 0; q < CT; ++q) {
-                    const float mq = ((mbits >> q) & 1u) ? 1.0f : 0.0f;
-                    const f2 d = acc[p][q] * (f2){mq, mq};
-                    a += d;
-                    b = __builtin_elementwise_fma(d, d, b);
-                }
-                float tot[4] = {a.x, b.x, a.y, b.y};
-                const float mine = wave_reduce_scatter(tot, lane);
-                if (lane < 4) {
-                    const int which = scatter_index<4>(lane);
-                    const int f = (metas[p] >> (8 + 8 * (which >> 1))) & 255;
-                    if (f != 255) s_part[wv][f][which & 1] = (double)mine;
-                }
-            }
-        };
         if (!(dbg & 2)) {
-            if (envelope && n_pass == 3 && ct <= GB_EVEN3_MAX_CT && !(dbg & 8)) {
-                switch (ct) {
-                NFX_GB_CASE(2, GB_EVEN3_MAX_CT, column_passes_even3)
-                NFX_GB_CASE(3, GB_EVEN3_MAX_CT, column_passes_even3)
-                NFX_GB_CASE(4, GB_EVEN3_MAX_CT, column_passes_even3)
-                NFX_GB_CASE(5, GB_EVEN3_MAX_CT, column_passes_even3)
-                NFX_GB_CASE(6, GB_EVEN3_MAX_CT, column_passes_even3)
-                NFX_GB_CASE(7, GB_EVEN3_MAX_CT, column_passes_even3)
-                NFX_GB_CASE(8, GB_EVEN3_MAX_CT, column_passes_even3)
-                NFX_GB_CASE(9, GB_EVEN3_MAX_CT, column_passes_even3)
-                NFX_GB_CASE(10, GB_EVEN3_MAX_CT, column_passes_even3)
-                NFX_GB_CASE(11, GB_EVEN3_MAX_CT, column_passes_even3)
-                NFX_GB_CASE(12, GB_EVEN3_MAX_CT, column_passes_even3)
-                NFX_GB_CASE(13, GB_EVEN3_MAX_CT, column_passes_even3)
-                NFX_GB_CASE(14, GB_EVEN3_MAX_CT, column_passes_even3)
-                NFX_GB_CASE(15, GB_EVEN3_MAX_CT, column_passes_even3)
-                NFX_GB_CASE(16, GB_EVEN3_MAX_CT, column_passes_even3)
-                default: break;
-                }
-            } else {
             switch (ct) {
             NFX_GB_CASE(2, GB_MAX_CT, column_passes)
             NFX_GB_CASE(3, GB_MAX_CT, column_passes)
@@ -488,7 +391,6 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
             NFX_GB_CASE(15, GB_MAX_CT, column_passes)
             NFX_GB_CASE(16, GB_MAX_CT, column_passes)
             default: break;
-            }
             }
         }
         wave_lds_fence(); // the next group's row pass overwrites the columns read above
@@ -647,7 +549,7 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
                 var = var > 0.0 ? var : 0.0;
                 const double mean = shift + m1;
                 mean_f = (float)mean;
-                off_centre = m1 * m1 > 8.0 * var;
+                off_centre = m1 * m1 > NFX_GB_REDO_RATIO * var;
                 if (Fl.ch0 >= 0) { o[2 * Fl.ch0] = (float)mean; o[2 * Fl.ch0 + 1] = (float)var; }
                 if (Fl.ch1 >= 0) { o[2 * Fl.ch1] = (float)mean; o[2 * Fl.ch1 + 1] = (float)var; }
             }

@@ -178,48 +178,56 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     if (out_centroids_xy) memcpy(out_centroids_xy, cen.data(), 8 * (size_t)n);
     int64_t other_h2d = 4 * (n + 1) + 8 * nv;
 
-    // ---- the plan: every nucleus's block, chunks of whole batches whose blocks fit the cache ----------------------------------
+    // ---- the plan, made chunk by chunk while the device works on the chunks before: the band of every nucleus's window, chunks of
+    // whole batches whose bands fit the cache, the chunk's nuclei grouped by band (a counting sort: bands are few) -----------------
     const float half = (float)ps / 2.0f;
-    std::vector<int64_t> blk((size_t)n);
-    for (int64_t i = 0; i < n; ++i) {
+    auto band_of = [&](int64_t i) {
         int64_t t0 = window_origin(cen[2 * i + 1], half, slide);
         t0 = std::min<int64_t>(t0, H - 1); // a window that starts past the image reads nothing: any band will do
-        blk[i] = t0 / B;
-    }
-    std::vector<Chunk> chunks;
-    {
-        std::vector<int64_t> seen_at((size_t)nblocks, -1); // chunk index a block was last added to
-        int64_t i = 0;
-        while (i < n) {
-            Chunk c; c.i0 = i;
-            const int64_t ck = (int64_t)chunks.size();
-            int64_t distinct = 0;
-            while (i < n && i - c.i0 < chunk_cap) {
-                const int64_t e = std::min<int64_t>(n, i + batch_size);
-                int64_t add = 0;
-                for (int64_t j = i; j < e; ++j) if (seen_at[blk[j]] != ck && seen_at[blk[j]] != -2 - ck) { seen_at[blk[j]] = -2 - ck; ++add; }
-                if (i > c.i0 && distinct + add > n_slots) { // this batch does not fit beside the chunk's blocks: it opens the next chunk
-                    for (int64_t j = i; j < e; ++j) if (seen_at[blk[j]] == -2 - ck) seen_at[blk[j]] = -1;
-                    break;
-                }
-                for (int64_t j = i; j < e; ++j) if (seen_at[blk[j]] == -2 - ck) seen_at[blk[j]] = ck;
-                distinct += add;
-                i = e;
+        return t0 / B;
+    };
+    std::vector<int64_t> stamp((size_t)nblocks, -1);   // chunk a band was last counted for
+    std::vector<uint32_t> band_count((size_t)nblocks, 0);
+    std::vector<int64_t> blk_buf((size_t)chunk_cap);
+    int64_t plan_next = 0, plan_index = 0;             // first nucleus / index of the chunk the next plan() call makes
+    auto plan = [&](Chunk &c) -> bool {                // false: a single batch needs more bands than the cache holds
+        c.i0 = plan_next; c.blocks.clear(); c.sel.clear(); c.sel_off.clear();
+        const int64_t ck = plan_index++;
+        int64_t i = c.i0, distinct = 0;
+        while (i < n && i - c.i0 < chunk_cap) {
+            const int64_t e = std::min<int64_t>(n, i + batch_size);
+            int64_t add = 0;
+            for (int64_t j = i; j < e; ++j) {
+                const int64_t bnd = band_of(j);
+                blk_buf[(size_t)(j - c.i0)] = bnd;
+                if (stamp[bnd] != ck && stamp[bnd] != -2 - ck) { stamp[bnd] = -2 - ck; ++add; }
             }
-            c.i1 = i;
-            std::vector<std::pair<int64_t, uint32_t>> order;
-            order.reserve((size_t)(c.i1 - c.i0));
-            for (int64_t j = c.i0; j < c.i1; ++j) order.emplace_back(blk[j], (uint32_t)(j - c.i0));
-            std::sort(order.begin(), order.end());
-            for (size_t q = 0; q < order.size(); ++q) {
-                if (q == 0 || order[q].first != order[q - 1].first) { c.blocks.push_back(order[q].first); c.sel_off.push_back((uint32_t)q); }
-                c.sel.push_back(order[q].second);
+            const bool fits = distinct + add <= n_slots;
+            for (int64_t j = i; j < e; ++j) { // settle the tentative marks: counted (the batch joins the chunk) or forgotten
+                int64_t &m = stamp[blk_buf[(size_t)(j - c.i0)]];
+                if (m == -2 - ck) m = (fits || i == c.i0) ? ck : -1;
             }
-            c.sel_off.push_back((uint32_t)order.size());
-            if ((int64_t)c.blocks.size() > n_slots) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "one reference batch touches more bands than the band cache holds: raise cache_bytes");
-            chunks.push_back(std::move(c));
+            if (!fits && i > c.i0) break;      // this batch opens the next chunk
+            if (!fits) return false;           // ... a chunk of one batch that does not fit: nothing to be done
+            distinct += add;
+            i = e;
         }
-    }
+        c.i1 = i;
+        plan_next = i;
+        const int64_t m = c.i1 - c.i0;
+        for (int64_t j = 0; j < m; ++j) ++band_count[blk_buf[(size_t)j]];
+        for (int64_t bnd = 0; bnd < nblocks; ++bnd)  // (a few dozen bands: a scan is cheaper than collecting and sorting the touched ones)
+            if (band_count[bnd]) { c.blocks.push_back(bnd); c.sel_off.push_back((uint32_t)c.sel.size()); c.sel.resize(c.sel.size() + band_count[bnd]); }
+        c.sel_off.push_back((uint32_t)c.sel.size());
+        {   // scatter: nucleus j goes to the next free place of its band's run (runs in ascending band order, nuclei in index order)
+            std::vector<uint32_t> &at = band_count; // reuse as write cursors: at[band] = start of the band's run
+            for (size_t q = 0; q < c.blocks.size(); ++q) at[c.blocks[q]] = c.sel_off[q];
+            for (int64_t j = 0; j < m; ++j) c.sel[at[blk_buf[(size_t)j]]++] = (uint32_t)j;
+            for (size_t q = 0; q < c.blocks.size(); ++q) at[c.blocks[q]] = 0;
+        }
+        return true;
+    };
+    Chunk plans[2]; // chunk k lives in plans[k & 1] from its planning to the enqueue of its extraction
 
     // ---- pinned staging: selection lists and rebased offsets of two chunks -------------------------------------------------------
     const bool img_pinned = is_pinned(image_u8); // (a pageable image is copied by the runtime through its own staging: correct, not overlapped)
@@ -247,8 +255,8 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
             return fail_sync(api_fail(ctx, e_ == hipErrorOutOfMemory ? NFX_ERR_OUT_OF_MEMORY : NFX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_))); \
     } while (0)
 
-    auto enqueue_copy = [&](int64_t k) -> nfx_status { // H2D of chunk k's missing blocks + the gathers of its windows, on the copy stream
-        const Chunk &c = chunks[(size_t)k];
+    auto enqueue_copy = [&](int64_t k) -> nfx_status { // H2D of chunk k's missing bands + the gathers of its windows, on the copy stream
+        const Chunk &c = plans[k & 1];
         const int b = (int)(k & 1);
         const int64_t m = c.i1 - c.i0;
         if (k >= 2) NFX_HIP_S(hipEventSynchronize(ctx->ev_done[b])); // extract(k-2) has finished: patches[b], sel[b], off[b] and their staging are free
@@ -285,13 +293,18 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         return NFX_OK;
     };
 
-    const int64_t nchunks = (int64_t)chunks.size();
-    if (nchunks && (st = enqueue_copy(0)) != NFX_OK) return st;
-    for (int64_t k = 0; k < nchunks; ++k) {
-        const Chunk &c = chunks[(size_t)k];
+    int64_t nchunks = 0;
+    bool have = plan_next < n;
+    if (have) {
+        if (!plan(plans[0])) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "one reference batch touches more bands than the band cache holds: raise cache_bytes");
+        if ((st = enqueue_copy(0)) != NFX_OK) return st;
+    }
+    for (int64_t k = 0; have; ++k) {
+        const Chunk &c = plans[k & 1];
         const int b = (int)(k & 1);
-        const int64_t m = c.i1 - c.i0;
-        if (k + 1 < nchunks && (st = enqueue_copy(k + 1)) != NFX_OK) return st; // the next chunk's blocks travel while this one computes
+        const int64_t m = c.i1 - c.i0, i0 = c.i0;
+        ++nchunks;
+        // extraction of chunk k and the trip home of its rows: enqueued first (they wait for their events on the device) ...
         NFX_HIP_S(hipStreamWaitEvent(compute, ctx->ev_ready[b], 0));
         if (k >= 2) NFX_HIP_S(hipStreamWaitEvent(compute, ctx->ev_rows[b], 0)); // rows[b] of chunk k-2 have left for the host
         ctx->ws->off = ws_mark;
@@ -300,9 +313,16 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         if (st != NFX_OK) return fail_sync(st);
         NFX_HIP_S(hipEventRecord(ctx->ev_done[b], compute));
         NFX_HIP_S(hipStreamWaitEvent(rows_s, ctx->ev_done[b], 0));
-        NFX_HIP_S(hipMemcpyAsync(out_rows + (size_t)c.i0 * F, d_rows[b], 4 * (size_t)m * F, hipMemcpyDeviceToHost, rows_s));
+        NFX_HIP_S(hipMemcpyAsync(out_rows + (size_t)i0 * F, d_rows[b], 4 * (size_t)m * F, hipMemcpyDeviceToHost, rows_s));
         NFX_HIP_S(hipEventRecord(ctx->ev_rows[b], rows_s));
         rows_d2h += 4 * m * F;
+        // ... then the next chunk is planned (host work, beside the device's) and its bands are sent on their way: they travel
+        // while chunk k computes
+        have = plan_next < n;
+        if (have) {
+            if (!plan(plans[(k + 1) & 1])) return fail_sync(api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "one reference batch touches more bands than the band cache holds: raise cache_bytes"));
+            if ((st = enqueue_copy(k + 1)) != NFX_OK) return st;
+        }
     }
 #undef NFX_HIP_S
     NFX_HIP(ctx, hipStreamSynchronize(copy));
