@@ -169,8 +169,9 @@ static constexpr int GB_MAX_TSR = (NFX_ROW_WORD_PS + GB_WAVES - 1) / GB_WAVES;
 static constexpr int GB_MAX_CT = (NFX_ROW_WORD_PS + (64 / GB_MAX_TSR) - 1) / (64 / GB_MAX_TSR);
 #define NFX_GB_CASE(N, MAXN, F) case N: if constexpr (N <= MAXN) F(gb_int<N>{}); break;
 
+template <bool REFINED>
 static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const GaborTables *__restrict__ tab, int n_groups, int n_plain, int ps,
-                                                     const GaborView *s_view, float mu_gray, const float *s_shift, bool refined, int t,
+                                                     const GaborView *s_view, float mu_gray, const float *s_shift, int t,
                                                      double (*s_part)[GB_MAX_FILTERS][2], int dbg)
 {
     const int lane = t & 63, wv = t >> 6;
@@ -329,13 +330,16 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
                 const int meta = __float_as_int(wp[GB_META + 2]); // combine | slot0 << 8 | slot1 << 16 (255: none)
                 f2 a = {0.0f, 0.0f}, b = {0.0f, 0.0f};
                 f2 acc[CT];
-                // per-filter shift of this attempt (k_gabor): DC gain x mean masked gray -- two scalar operands -- on the first; on the
-                // rare second one the mean the first attempt measured (LDS; wave-uniform branch)
-                float sh0 = wp[GB_META] * mu_gray, sh1 = wp[GB_META + 1] * mu_gray;
-                if (refined) {
+                // per-filter shift (k_gabor): DC gain x mean masked gray -- two scalar operands; in the second launch, over the few nuclei
+                // whose first result was far off that guess, the mean the first launch measured (LDS)
+                float sh0, sh1;
+                if constexpr (REFINED) {
                     const int fs0 = (meta >> 8) & 255, fs1 = (meta >> 16) & 255;
                     sh0 = s_shift[fs0 != 255 ? fs0 : 0];
                     sh1 = fs1 != 255 ? s_shift[fs1] : 0.0f;
+                } else {
+                    sh0 = wp[GB_META] * mu_gray;
+                    sh1 = wp[GB_META + 1] * mu_gray;
                 }
                 // the accumulators start at minus the shift (for the mixed pair: A - B starts at -sh0, A + B at -sh1), so
                 // the responses come out already shifted; masked partial sums of the strip's responses follow (f32
@@ -398,17 +402,20 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
   }
 }
 
-template <typename T>
+// REFINED = false: the launch over all n nuclei; a nucleus one of whose variances came out of a badly centred sum is appended to
+// redo_list.  REFINED = true: the launch over redo_list (count read on the device), shifts = the means already in the rows.
+template <typename T, bool REFINED>
 __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t n, int ps, const T *__restrict__ patches,
                                                          const uint64_t *__restrict__ mask_rows,
                                                          const GaborTables *__restrict__ tab, float *__restrict__ out,
-                                                         int F, int col0, int dbg)
+                                                         int F, int col0, int dbg, int *__restrict__ redo_list, int *__restrict__ redo_count)
 {
     __shared__ float s_g[NFX_ROW_WORD_PS * GB_GW + 16];
     __shared__ f2 s_UW[GB_UH * GB_UW]; // plane pair; row r lives at index r + GB_PAD; aprons stay zero
     __shared__ uint64_t s_rows[64 + 16];
     __shared__ double s_part[GB_WAVES][GB_MAX_FILTERS][2];
     __shared__ float s_shift[GB_MAX_FILTERS];
+    __shared__ int s_redo;
     __shared__ float s_gsum[GB_WAVES];
     __shared__ GaborView s_view[2];
 
@@ -435,8 +442,12 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
             r4n = src[0]; g4n = src[P / 16]; b4n = src[2 * (P / 16)];
         }
     };
-    if ((int64_t)blockIdx.x < n) request(blockIdx.x);
-    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    if (REFINED) n = *redo_count;            // the list's length (this launch follows the one that filled it, on the same stream)
+    auto nucleus_at = [&](int64_t j) -> int64_t { return REFINED ? (int64_t)redo_list[j] : j; };
+    if (t == 0) s_redo = 0;
+    if ((int64_t)blockIdx.x < n) request(nucleus_at(blockIdx.x));
+    for (int64_t j = blockIdx.x; j < n; j += gridDim.x) {
+        const int64_t i = nucleus_at(j);
         if (t < 64) s_rows[t] = row_next;
         __syncthreads();
         const T *pp = patches + (size_t)i * 3 * P;
@@ -471,7 +482,7 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
                 if (c >= ps) { c -= ps; r += 1; }
             }
         }
-        if (i + (int64_t)gridDim.x < n) request(i + gridDim.x);
+        if (j + (int64_t)gridDim.x < n) request(nucleus_at(j + gridDim.x));
         gsum = wave_total_f32(gsum);
         // mask bounding box and area: lane r looks at row r, the wave votes
         const uint64_t wrow = s_rows[lane];
@@ -515,48 +526,44 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
             put_view(s_view[1], false, 0ull, cmin, cmax, rmin, rmax);
         }
         if (lane == 0) s_gsum[wv] = gsum;
+        if (lane < GB_MAX_FILTERS) { s_part[wv][lane][0] = 0.0; s_part[wv][lane][1] = 0.0; } // a wave whose strip lies outside the box adds nothing
+        // The masked sums are f32 about a per-filter SHIFT (the accumulators start at minus the shift), so that sum d^2 carries no
+        // cancellation: var = s2/K - (s1/K)^2 carries the f32 sums' relative error (3..6e-7: <= 16 terms per lane, a six-level
+        // butterfly) times 1 + (s1/K)^2 / var.  First launch: shift = DC gain x mean masked gray -- within a few standard
+        // deviations of the mean response whenever the 30-tap kernel sees mostly the patch.  Where (s1/K)^2 > 8 var all the same --
+        // patches smaller than the kernel, whose zero padding moves every response off that guess ((s1/K)^2 up to 2700 var at
+        // 17 x 17: 4e-4 relative on the frequency-0.5 variances), flat patches -- the nucleus goes on a list, and a SECOND launch
+        // does the listed nuclei again with the means just measured as shifts (this launch's own code stays what it was: the
+        // same loop with the second attempt inside it cost 2.3 % on every nucleus).
+        if (REFINED && t < n_filters) { const GaborFilter &Fl = tab->filters[t]; s_shift[t] = o[2 * (Fl.ch0 >= 0 ? Fl.ch0 : Fl.ch1)]; }
         __syncthreads();
         float gtot = 0.0f;
 #pragma unroll
         for (int w = 0; w < GB_WAVES; ++w) gtot += s_gsum[w];
         const float mu_gray = gtot / (float)area;
-        // The masked sums are f32 about a per-filter SHIFT (the accumulators start at minus the shift), so that sum d^2 carries no
-        // cancellation: var = s2/K - (s1/K)^2 carries the f32 sums' relative error (3..6e-7: <= 16 terms per lane, a six-level
-        // butterfly) times 1 + (s1/K)^2 / var.  First attempt: shift = DC gain x mean masked gray -- within a few standard
-        // deviations of the mean response whenever the 30-tap kernel sees mostly the patch (on the synthetic nuclei (s1/K)^2 exceeds
-        // 8 var for < 1 % of the nuclei at 64 x 64, 1-2 % at 48 x 48, a fifth at 32 x 32).  Where it does -- patches smaller than the
-        // kernel, whose zero padding moves every response off that guess ((s1/K)^2 up to 2700 var at 17 x 17: 4e-4 relative on the
-        // frequency-0.5 variances), flat patches -- the nucleus is done a SECOND time with the mean just measured as the shift.
-        if (t < n_filters) s_shift[t] = tab->filters[t].dc * mu_gray;
-#pragma unroll 1
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            if (lane < GB_MAX_FILTERS) { s_part[wv][lane][0] = 0.0; s_part[wv][lane][1] = 0.0; } // a wave whose strip lies outside the box adds nothing
-            __syncthreads();
-            gabor_nucleus(S, tab, n_groups, n_plain, ps, s_view, mu_gray, s_shift, attempt != 0, t, s_part, dbg);
-            __syncthreads();
-            // ---- mean / variance (texture.rs:339-344) from the shifted sums: mean = c + s1/K, var = s2/K - (s1/K)^2 -----
-            bool off_centre = false;
-            float mean_f = 0.0f;
-            if (t < n_filters) {
-                const GaborFilter &Fl = tab->filters[t];
-                const double K = (double)area;
-                const double shift = (double)s_shift[t]; // attempt 0: Fl.dc * mu_gray, the very product the passes formed from their scalar operands
-                double a = 0.0, b = 0.0;
+        gabor_nucleus<REFINED>(S, tab, n_groups, n_plain, ps, s_view, mu_gray, s_shift, t, s_part, dbg);
+        __syncthreads();
+        // ---- mean / variance (texture.rs:339-344) from the shifted sums: mean = c + s1/K, var = s2/K - (s1/K)^2 -----
+        if (t < n_filters) {
+            const GaborFilter &Fl = tab->filters[t];
+            const double K = (double)area;
+            const double shift = REFINED ? (double)s_shift[t] : (double)(Fl.dc * mu_gray);
+            double a = 0.0, b = 0.0;
 #pragma unroll
-                for (int w = 0; w < GB_WAVES; ++w) { a += s_part[w][t][0]; b += s_part[w][t][1]; }
-                const double m1 = a / K;
-                double var = b / K - m1 * m1;
-                var = var > 0.0 ? var : 0.0;
-                const double mean = shift + m1;
-                mean_f = (float)mean;
-                off_centre = m1 * m1 > NFX_GB_REDO_RATIO * var;
-                if (Fl.ch0 >= 0) { o[2 * Fl.ch0] = (float)mean; o[2 * Fl.ch0 + 1] = (float)var; }
-                if (Fl.ch1 >= 0) { o[2 * Fl.ch1] = (float)mean; o[2 * Fl.ch1 + 1] = (float)var; }
-            }
-            if (attempt == 1 || !__syncthreads_or(off_centre)) break; // (__syncthreads_or: every thread reaches it, the verdict is uniform)
-            if (t < n_filters) s_shift[t] = mean_f;
+            for (int w = 0; w < GB_WAVES; ++w) { a += s_part[w][t][0]; b += s_part[w][t][1]; }
+            const double m1 = a / K;
+            double var = b / K - m1 * m1;
+            var = var > 0.0 ? var : 0.0;
+            const double mean = shift + m1;
+            if (!REFINED && m1 * m1 > NFX_GB_REDO_RATIO * var) s_redo = 1; // (several threads may store the same 1)
+            if (Fl.ch0 >= 0) { o[2 * Fl.ch0] = (float)mean; o[2 * Fl.ch0 + 1] = (float)var; }
+            if (Fl.ch1 >= 0) { o[2 * Fl.ch1] = (float)mean; o[2 * Fl.ch1 + 1] = (float)var; }
         }
         __syncthreads();
+        if (!REFINED && t == 0 && s_redo) { // after the barrier: every filter's verdict is in
+            redo_list[atomicAdd(redo_count, 1)] = (int)i;
+            s_redo = 0;
+        }
     }
 }
 
@@ -815,9 +822,12 @@ hipError_t prepare_gabor(nfx_ctx *ctx)
     return hipSuccess;
 }
 
-hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0)
+size_t gabor_scratch_bytes(const Job &job) { return job.ps > NFX_ROW_WORD_PS ? 0 : sizeof(int) * ((size_t)(job.n > 0 ? job.n : 1) + 16); } // redo list + its length
+
+hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
 {
     if (job.n == 0) return hipSuccess;
+    if (job.n > 0x7FFFFFFFll) return hipErrorInvalidValue; // the redo list holds 32-bit nucleus indices
     hipError_t e = prepare_gabor(ctx);
     if (e != hipSuccess) return e;
     ScopedTiming t(ctx, KS_GABOR);
@@ -830,6 +840,7 @@ hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0)
         else
             hipLaunchKernelGGL(k_gabor_wide<uint8_t>, dim3(wgrid), dim3(GBW_THREADS), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const uint8_t *>(job.patches),
                                job.mask_rows, dense, job.out, job.F, col0);
+        (void)scratch;
         return hipGetLastError();
     }
     // 64 rounds of the resident workgroups: nuclei differ several-fold in work, and with few large blocks the launch ends when
@@ -843,12 +854,21 @@ hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0)
 #else
     const int dbg = 0;
 #endif
-    if (job.patches_f32)
-        hipLaunchKernelGGL(k_gabor<float>, dim3(grid), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps,
-                           reinterpret_cast<const float *>(job.patches), job.mask_rows, tab, job.out, job.F, col0, dbg);
-    else
-        hipLaunchKernelGGL(k_gabor<uint8_t>, dim3(grid), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps,
-                           reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, tab, job.out, job.F, col0, dbg);
+    int *redo_count = reinterpret_cast<int *>(scratch), *redo_list = redo_count + 16;
+    e = hipMemsetAsync(redo_count, 0, sizeof(int), ctx->stream);
+    if (e != hipSuccess) return e;
+    // the second launch walks the list the first one filled: two workgroups per CU (its length is only known on the device; on
+    // the BASELINE patch sizes it holds a percent of the nuclei or less, on patches smaller than the filter nearly all of them)
+    const unsigned grid2 = (unsigned)(job.n < 256 * 2 * 4 ? job.n : 256 * 2 * 4);
+    if (job.patches_f32) {
+        const float *pf = reinterpret_cast<const float *>(job.patches);
+        hipLaunchKernelGGL((k_gabor<float, false>), dim3(grid), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps, pf, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count);
+        hipLaunchKernelGGL((k_gabor<float, true>), dim3(grid2), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps, pf, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count);
+    } else {
+        const uint8_t *pb = reinterpret_cast<const uint8_t *>(job.patches);
+        hipLaunchKernelGGL((k_gabor<uint8_t, false>), dim3(grid), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps, pb, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count);
+        hipLaunchKernelGGL((k_gabor<uint8_t, true>), dim3(grid2), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps, pb, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count);
+    }
     return hipGetLastError();
 }
 

@@ -444,6 +444,7 @@ size_t extract_ws_bytes(const int *sets, int n_sets, int64_t n, int64_t nv, int 
     Job j; j.n = n; j.ps = ps; j.batch_size = batch_size;
     b += (size_t)count_set(sets, n_sets, NFX_SET_COLOR) * al(color_scratch_bytes(j)); // a repeated "color" gets scratch of its own
     if (count_set(sets, n_sets, NFX_SET_GLCM)) b += al(glcm_scratch_bytes(j));
+    if (count_set(sets, n_sets, NFX_SET_GABOR)) b += al(gabor_scratch_bytes(j));
     return b + 4096;
 }
 
@@ -516,7 +517,7 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
 
     int col = 0;
     bool geo_done = false;
-    void *poly_scr = nullptr, *glcm_scr = nullptr;
+    void *poly_scr = nullptr, *glcm_scr = nullptr, *gabor_scr = nullptr;
     for (int s = 0; s < n_sets; ++s) {
         switch (sets[s]) {
         case NFX_SET_GEOMETRY: {
@@ -546,8 +547,10 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
         }
         case NFX_SET_GLRLM: NFX_HIP(ctx, launch_glrlm(ctx, job, col)); break;
         case NFX_SET_GABOR: {
+            if (!gabor_scr) gabor_scr = ws_alloc(ctx, gabor_scratch_bytes(job)); // (a repeated "gabor" runs after the first on the same stream: shared)
+            if (!gabor_scr && gabor_scratch_bytes(job)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
             if (gabor_side) ctx->stream = ctx->side_stream;
-            const hipError_t ge = launch_gabor(ctx, job, col);
+            const hipError_t ge = launch_gabor(ctx, job, col, gabor_scr);
             ctx->stream = main_stream;
             NFX_HIP(ctx, ge);
             break;
@@ -595,6 +598,7 @@ static size_t trait_ws_bytes(int set, int64_t n, int64_t nv, int ps)
     if (set == NFX_SET_GEOMETRY) need += al(polygon_scratch_bytes(n, nv));
     if (set == NFX_SET_COLOR) need += al(color_scratch_bytes(job));
     if (set == NFX_SET_GLCM) need += al(glcm_scratch_bytes(job));
+    if (set == NFX_SET_GABOR) need += al(gabor_scratch_bytes(job));
     return need;
 }
 
@@ -779,7 +783,12 @@ nfx_status nfx_compute_features_batched(nfx_ctx *ctx, int set, int64_t n, int64_
         break;
     }
     case NFX_SET_GLRLM: NFX_HIP(ctx, launch_glrlm(ctx, job, 0)); break;
-    case NFX_SET_GABOR: NFX_HIP(ctx, launch_gabor(ctx, job, 0)); break;
+    case NFX_SET_GABOR: {
+        void *scr = ws_alloc(ctx, gabor_scratch_bytes(job));
+        if (!scr && gabor_scratch_bytes(job)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+        NFX_HIP(ctx, launch_gabor(ctx, job, 0, scr));
+        break;
+    }
     }
     if (mem == NFX_MEM_HOST) {
         if (n) NFX_HIP(ctx, hipMemcpyAsync(out, d_out, 4 * (size_t)n * F, hipMemcpyDeviceToHost, ctx->stream));

@@ -196,7 +196,8 @@ size_t color_scratch_bytes(const Job &job);
 hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch);
 size_t glcm_scratch_bytes(const Job &job);
 hipError_t launch_glrlm(nfx_ctx *ctx, const Job &job, int col0);
-hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0);
+hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0, void *scratch);
+size_t gabor_scratch_bytes(const Job &job);
 // device tables of a feature set (no-ops once built).  Building allocates and copies synchronously: nfx_ctx_reserve does it
 // up front; a launcher that finds its table missing builds it on the spot unless tables_locked(ctx)
 bool tables_locked(nfx_ctx *ctx); // a device-memory call on a reserved context, or a stream capture in progress: no allocation allowed

@@ -115,7 +115,11 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     NFX_HIP(ctx, hipSetDevice(ctx->device));
     StreamScope scope(ctx, NFX_MEM_HOST); // ctx->stream = the context's own stream (the compute stream below), host arena
     if ((st = check_offsets(ctx, ring_offsets, n, nv, "ring_offsets")) != NFX_OK) return st;
-    if (!ctx->copy_stream) NFX_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->copy_stream) { // the gathers (and whatever kernels the runtime copies with) go ahead of the extraction's when CUs free up
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); hi = 0; }
+        NFX_HIP(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, hi));
+    }
     if (!ctx->rows_stream) NFX_HIP(ctx, hipStreamCreateWithFlags(&ctx->rows_stream, hipStreamNonBlocking));
     for (int b = 0; b < 2; ++b)
         for (hipEvent_t *e : {&ctx->ev_ready[b], &ctx->ev_done[b], &ctx->ev_rows[b]})
@@ -293,22 +297,30 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         return NFX_OK;
     };
 
+    // Order of the host's work per chunk k: plan chunk k+1 (host only: the device is still busy with chunk k-1), send its bands
+    // on their way (waits for extract(k-1): its buffers are then free -- and the device is idle at that moment, so the copies and
+    // gathers start at once), THEN enqueue extract(k), which runs beside them.  (Enqueueing extract(k) first was measured: the
+    // copies then queue up behind the extraction's chip-filling kernels and nothing overlaps: 151 ms instead of 116 for 500 k
+    // nuclei at 64 x 64, all sets.)
     int64_t nchunks = 0;
-    bool have = plan_next < n;
+    bool have = plan_next < n, have_next = false;
     if (have) {
         if (!plan(plans[0])) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "one reference batch touches more bands than the band cache holds: raise cache_bytes");
         if ((st = enqueue_copy(0)) != NFX_OK) return st;
     }
-    for (int64_t k = 0; have; ++k) {
-        const Chunk &c = plans[k & 1];
+    for (int64_t k = 0; have; ++k, have = have_next) {
         const int b = (int)(k & 1);
-        const int64_t m = c.i1 - c.i0, i0 = c.i0;
+        const int64_t i0 = plans[b].i0, i1 = plans[b].i1, m = i1 - i0;
         ++nchunks;
-        // extraction of chunk k and the trip home of its rows: enqueued first (they wait for their events on the device) ...
+        have_next = plan_next < n;
+        if (have_next) {
+            if (!plan(plans[b ^ 1])) return fail_sync(api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "one reference batch touches more bands than the band cache holds: raise cache_bytes"));
+            if ((st = enqueue_copy(k + 1)) != NFX_OK) return st;
+        }
         NFX_HIP_S(hipStreamWaitEvent(compute, ctx->ev_ready[b], 0));
         if (k >= 2) NFX_HIP_S(hipStreamWaitEvent(compute, ctx->ev_rows[b], 0)); // rows[b] of chunk k-2 have left for the host
         ctx->ws->off = ws_mark;
-        const uint32_t v0 = ring_offsets[c.i0], v1 = ring_offsets[c.i1];
+        const uint32_t v0 = ring_offsets[i0], v1 = ring_offsets[i1];
         st = extract_device(ctx, sets, n_sets, m, (int64_t)(v1 - v0), d_off[b], d_xy + 2 * (size_t)v0, d_patches[b], nullptr, 0, 0, ps, batch_size, d_rows[b], nullptr);
         if (st != NFX_OK) return fail_sync(st);
         NFX_HIP_S(hipEventRecord(ctx->ev_done[b], compute));
@@ -316,13 +328,6 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         NFX_HIP_S(hipMemcpyAsync(out_rows + (size_t)i0 * F, d_rows[b], 4 * (size_t)m * F, hipMemcpyDeviceToHost, rows_s));
         NFX_HIP_S(hipEventRecord(ctx->ev_rows[b], rows_s));
         rows_d2h += 4 * m * F;
-        // ... then the next chunk is planned (host work, beside the device's) and its bands are sent on their way: they travel
-        // while chunk k computes
-        have = plan_next < n;
-        if (have) {
-            if (!plan(plans[(k + 1) & 1])) return fail_sync(api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "one reference batch touches more bands than the band cache holds: raise cache_bytes"));
-            if ((st = enqueue_copy(k + 1)) != NFX_OK) return st;
-        }
     }
 #undef NFX_HIP_S
     NFX_HIP(ctx, hipStreamSynchronize(copy));
