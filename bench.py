@@ -118,6 +118,10 @@ def parse_args():
                     help="N>1: rank0 (default) = every rank's rows are gathered to rank 0 inside the timed region (the reference's vstack, "
                          "main.rs:96-108); none = rows stay on the rank that computed them (compute-only scaling).  With rank0 the line also "
                          "carries `also.weak_scaling_compute_only`, measured in the same run")
+    ap.add_argument("--transport", default="torch", choices=["torch", "nfx"],
+                    help="N>1: what carries the rows to rank 0 -- torch.distributed.gather (c10d over RCCL; default) or the engine's own "
+                         "nfx_gather_rows (include/nfx.h: grouped ncclSend / ncclRecv below any framework; torch.distributed only hands out the "
+                         "communicator id)")
     ap.add_argument("--ipc-legacy", default="env", choices=["env", "0", "1"],
                     help="N>1: HSA_ENABLE_IPC_MODE_LEGACY for the ranks (RCCL peer access across processes).  env (default) = whatever the "
                          "environment holds, 0 if it holds nothing (dmabuf IPC: what this pool's host driver supports); recorded in the line")
@@ -398,7 +402,9 @@ def main():
             pipeline.extract_streamed(ctx, sets, res.off, res.xy, h_patches, ps, batch_size=B, chunk_nuclei=args.chunk, out=d_out,
                                       host_rows=h_rows, want_centroids=False)
     elif use_dist and args.gather == "rank0":
-        sx = D.ShardedExtraction(world * n_local, F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if rehearsal else None)
+        transport = "torch" if rehearsal else args.transport      # (the native gather needs one GPU per rank)
+        sx = D.ShardedExtraction(world * n_local, F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if rehearsal else None,
+                                 transport=transport)
         assert (sx.i0, sx.i1) == (rank * n_local, (rank + 1) * n_local)
 
         def step():
@@ -463,7 +469,8 @@ def main():
     if not args.no_also and not stream_mode and world > 1 and use_dist and 0 < n_strong <= n_local:
         # configs[3]: the SAME n_strong nuclei cut into `world` batch-aligned shards (strong scaling); rank 0's weak-scaling
         # inputs start with exactly those nuclei, so it can check the gathered matrix against its own single-GPU result
-        ssx = D.ShardedExtraction(n_strong, F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if rehearsal else None)
+        ssx = D.ShardedExtraction(n_strong, F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if rehearsal else None,
+                                  transport="torch" if rehearsal else args.transport)
         rs = Resident(nfx, synth, torch, dev, args.workload, ssx.n_local, ssx.i0, set_names)
         el_s, _ = timed(torch, dist, True, ctx, args.steps, 1, lambda: ssx.step(lambda b0, b1, out: rs.extract(ctx, b0, b1, out, B)),
                         lambda: fence(ssx))
@@ -512,7 +519,8 @@ def main():
         ctx.reserve(r5.sets, r5.n, len(r5.xy), r5.ps, batch_size=B)
         k5 = max(2, args.steps // 2)
         if use_dist:
-            sx5 = D.ShardedExtraction(world * n5, r5.F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if rehearsal else None)
+            sx5 = D.ShardedExtraction(world * n5, r5.F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if rehearsal else None,
+                                      transport="torch" if rehearsal else args.transport)
             el5, t5 = timed(torch, dist, True, ctx, k5, 1, lambda: sx5.step(lambda b0, b1, out: r5.extract(ctx, b0, b1, out, B)), lambda: fence(sx5))
             ok5 = sx5.verify_transport()
         else:
@@ -553,6 +561,8 @@ def main():
                                  "pinned host memory (PCIe-inclusive; NOT the headline metric)",
                        "gen_seconds": round(gen_s, 1), "csrc_stamp": csrc_stamp(),
                        "gather": ("none" if (stream_mode or args.gather == "none") else "rank0") if world > 1 else None,
+                       "transport": (("torch.distributed.gather" if (rehearsal or args.transport == "torch") else "nfx_gather_rows (grouped ncclSend/ncclRecv)")
+                                     if use_dist and not stream_mode and args.gather == "rank0" else None),
                        "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") if use_dist else None},
             "roofline": roofline, "cpu_baseline": cpu, "also": also or None,
         }

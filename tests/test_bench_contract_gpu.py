@@ -86,6 +86,12 @@ def test_one_rank_over_rccl_and_gather_none():
     assert d["n_gpus"] == 1 and d["also"]["gather_checksums_match"] is True
     assert d["also"]["full_feature_set"]["gather_checksums_match"] is True
     assert d["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # the same rehearsal with the rows carried by the engine's own gather (nfx_gather_rows) instead of torch.distributed's
+    r = subprocess.run(base + ["--transport", "nfx"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert "nfx_gather_rows" in d["config"]["transport"] and d["also"]["gather_checksums_match"] is True
+    assert d["also"]["full_feature_set"]["gather_checksums_match"] is True
     r = subprocess.run(base + ["--gather", "none", "--no-also"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
