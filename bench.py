@@ -85,8 +85,8 @@ def committed_counters(workload, kernel):
         return None, "no profiles/pmc_current.json"
     if doc.get("csrc_stamp") != csrc_stamp():
         return None, f"profiles/pmc_current.json was taken on csrc {doc.get('csrc_stamp')}, this is {csrc_stamp()}"
-    t = doc.get(workload)
-    if not t or t.get("kernel") != kernel:
+    t = (doc.get(workload) or {}).get("slots", {}).get(kernel)
+    if not t:
         return None, f"profiles/pmc_current.json holds no counters for {workload}/{kernel}"
     return t, doc.get("source", "profiles/pmc_current.json")
 
