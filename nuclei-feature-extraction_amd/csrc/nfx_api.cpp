@@ -308,7 +308,7 @@ void nfx_ctx_destroy(nfx_ctx *ctx)
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->rows_stream) { (void)hipStreamSynchronize(ctx->rows_stream); (void)hipStreamDestroy(ctx->rows_stream); }
     for (int b = 0; b < 2; ++b)
-        for (hipEvent_t e : {ctx->ev_ready[b], ctx->ev_done[b], ctx->ev_rows[b]})
+        for (hipEvent_t e : {ctx->ev_ready[b], ctx->ev_done[b], ctx->ev_rows[b], ctx->ev_bands[b]})
             if (e) (void)hipEventDestroy(e);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);

@@ -53,7 +53,7 @@ struct nfx_ctx {
     hipEvent_t ev_mid = nullptr;                     // (experiment knob NFX_EXP_GABOR_SIDE: mask rows ready)
     // nfx_extract_tile_streamed (nfx_stream.cpp): block copies + window gathers | rows back to the host, created on first use
     hipStream_t copy_stream = nullptr, rows_stream = nullptr;
-    hipEvent_t ev_ready[2] = {}, ev_done[2] = {}, ev_rows[2] = {};
+    hipEvent_t ev_ready[2] = {}, ev_done[2] = {}, ev_rows[2] = {}, ev_bands[2] = {};
     void *pin = nullptr;      // grow-only pinned host staging (selection lists, rebased offsets of two chunks)
     size_t pin_cap = 0;
     nfx_addressing addressing = NFX_ADDR_IMAGE;

@@ -16,9 +16,9 @@
 // nuclei tile by tile, so a chunk touches one or two bands; any order is correct (a band that is needed again after it was
 // evicted is copied again; the device keeps as many bands as `cache_bytes` allows -- the whole slide, typically).
 //
-//   copy stream    : H2D bands of chunk k+1 | gather their nuclei's windows into patches[(k+1)&1]
+//   copy stream    : H2D bands of chunk k+1, k+2, ... back to back (nothing but copies: the link never waits for a kernel)
+//   rows stream    : gather the windows of chunk k+1 out of its bands into patches[(k+1)&1] | D2H rows of chunk k-1
 //   compute stream :              extract(chunk k) from patches[k&1] -> rows[k&1]
-//   rows stream    :                                   D2H rows of chunk k-1
 //
 // Results are bit-identical to nfx_extract_tile on the resident image: the same gather kernel fills the same packed patches, the
 // same extraction runs on the same batches.
@@ -120,9 +120,13 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); hi = 0; }
         NFX_HIP(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, hi));
     }
-    if (!ctx->rows_stream) NFX_HIP(ctx, hipStreamCreateWithFlags(&ctx->rows_stream, hipStreamNonBlocking));
+    if (!ctx->rows_stream) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); hi = 0; }
+        NFX_HIP(ctx, hipStreamCreateWithPriority(&ctx->rows_stream, hipStreamNonBlocking, hi));
+    }
     for (int b = 0; b < 2; ++b)
-        for (hipEvent_t *e : {&ctx->ev_ready[b], &ctx->ev_done[b], &ctx->ev_rows[b]})
+        for (hipEvent_t *e : {&ctx->ev_ready[b], &ctx->ev_done[b], &ctx->ev_rows[b], &ctx->ev_bands[b]})
             if (!*e) NFX_HIP(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
     hipStream_t const compute = ctx->stream, copy = ctx->copy_stream, rows_s = ctx->rows_stream;
     const bool slide = ctx->addressing == NFX_ADDR_SLIDE;
@@ -259,7 +263,9 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
             return fail_sync(api_fail(ctx, e_ == hipErrorOutOfMemory ? NFX_ERR_OUT_OF_MEMORY : NFX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_))); \
     } while (0)
 
-    auto enqueue_copy = [&](int64_t k) -> nfx_status { // H2D of chunk k's missing bands + the gathers of its windows, on the copy stream
+    // H2D of chunk k's missing bands on the copy stream -- nothing but copies there, so the link never waits for a kernel -- and the
+    // gathers of its windows behind them on the rows stream (which also carries the rows home)
+    auto enqueue_copy = [&](int64_t k) -> nfx_status {
         const Chunk &c = plans[k & 1];
         const int b = (int)(k & 1);
         const int64_t m = c.i1 - c.i0;
@@ -271,15 +277,22 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         NFX_HIP_S(hipMemcpyAsync(d_off[b], h_off[b], 4 * ((size_t)m + 1), hipMemcpyHostToDevice, copy));
         other_h2d += 8 * m + 4;
         for (size_t q = 0; q < c.blocks.size(); ++q) if (block_slot[c.blocks[q]] >= 0) slot_use[block_slot[c.blocks[q]]] = k;
+        std::vector<int64_t> slot_of_q(c.blocks.size());
+        bool evicted_waited = false;
         for (size_t q = 0; q < c.blocks.size(); ++q) {
             const int64_t bid = c.blocks[q];
-            const int64_t wy0 = bid * B, wx0 = 0, wh = std::min<int64_t>(H - wy0, B + ps), ww = W;
+            const int64_t wy0 = bid * B, wh = std::min<int64_t>(H - wy0, B + ps), ww = W;
             int64_t s = block_slot[bid];
             if (s < 0) { // not resident: take the slot that has gone unused longest (never one this chunk needs)
                 s = 0;
                 for (int64_t t = 1; t < n_slots; ++t) if (slot_use[t] < slot_use[s]) s = t;
                 if (slot_use[s] == k) return fail_sync(api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "band cache too small for one chunk"));
-                if (slot_block[s] >= 0) block_slot[slot_block[s]] = -1;
+                if (slot_block[s] >= 0) {
+                    block_slot[slot_block[s]] = -1;
+                    // an evicted band may still be read by the gathers of an earlier chunk (they run on the other stream, in order):
+                    // the overwriting copy waits for the latest of them
+                    if (!evicted_waited && k >= 1) { NFX_HIP_S(hipStreamWaitEvent(copy, ctx->ev_ready[(k - 1) & 1], 0)); evicted_waited = true; }
+                }
                 slot_block[s] = bid; block_slot[bid] = s; slot_use[s] = k;
                 uint8_t *dst = d_slots + (size_t)s * slot_bytes;
                 for (int ch = 0; ch < 3; ++ch) // rows [wy0, wy0 + wh) of a channel are contiguous in the planar image
@@ -287,13 +300,20 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
                 img_h2d += 3 * wh * ww;
                 ++blocks_copied;
             }
-            ctx->stream = copy;
+            slot_of_q[q] = s;
+        }
+        NFX_HIP_S(hipEventRecord(ctx->ev_bands[b], copy));
+        NFX_HIP_S(hipStreamWaitEvent(rows_s, ctx->ev_bands[b], 0));
+        for (size_t q = 0; q < c.blocks.size(); ++q) {
+            const int64_t bid = c.blocks[q];
+            const int64_t wy0 = bid * B, wh = std::min<int64_t>(H - wy0, B + ps);
+            ctx->stream = rows_s;
             const hipError_t ge = launch_gather_patches_window(ctx, c.sel_off[q + 1] - c.sel_off[q], d_sel[b] + c.sel_off[q], d_cen + 2 * c.i0,
-                                                               d_slots + (size_t)s * slot_bytes, H, W, wy0, wx0, wh, ww, ps, d_patches[b]);
+                                                               d_slots + (size_t)slot_of_q[q] * slot_bytes, H, W, wy0, 0, wh, W, ps, d_patches[b]);
             ctx->stream = compute;
             NFX_HIP_S(ge);
         }
-        NFX_HIP_S(hipEventRecord(ctx->ev_ready[b], copy));
+        NFX_HIP_S(hipEventRecord(ctx->ev_ready[b], rows_s));
         return NFX_OK;
     };
 
