@@ -402,14 +402,43 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
   }
 }
 
-// REFINED = false: the launch over all n nuclei; a nucleus one of whose variances came out of a badly centred sum is appended to
-// redo_list.  REFINED = true: the launch over redo_list (count read on the device), shifts = the means already in the rows.
-template <typename T, bool REFINED>
+// ---- patch sizes 65..128: the same kernel on TILES ------------------------------------------------------------------------------
+// The planes of a 128 x 128 patch do not fit the LDS, but a response only depends on the 30 x 30 pixels around it: a 64 x 64 WINDOW of
+// the patch (zeros outside the patch, as the reference's padding has them) gives the exact responses of its central 35 x 35 pixels
+// (15 taps before, 14 after).  k_gabor_plan cuts a wide nucleus's mask into such central squares -- up to 16 tiles, only those that hold
+// mask pixels -- k_gabor<T, GB_TILES> runs every tile as a nucleus of its own (window as the patch, central mask as the mask, the
+// WHOLE mask's shift) and writes the tile's masked sums, and k_gabor_finish adds a nucleus's tiles in a fixed order and forms the
+// 96 columns.
+static constexpr int GB_MAIN = 0, GB_REFINED = 1, GB_TILES = 2;
+static constexpr int GB_CENTRAL = NFX_ROW_WORD_PS - (GB_SIZE - 1);                 // 35: rows / columns [15, 50) of a window
+static constexpr int GB_TILES_PER_DIM = (NFX_MAX_PATCH_SIZE + GB_CENTRAL - 1) / GB_CENTRAL; // 4
+static constexpr int GB_MAX_TILES = GB_TILES_PER_DIM * GB_TILES_PER_DIM;           // per nucleus
+struct GaborTile { int nucleus, wr, wc, pad; };                                    // window origin in patch coordinates (may be negative)
+struct GaborTileArgs {
+    const GaborTile *tiles; const int *tile_count; const float *mu_gray; double *tile_sums; // [tile][GB_MAX_FILTERS][2]
+};
+
+// bits [off, off + 64) of the 128-bit row (w1 : w0), zeros outside
+static __device__ __forceinline__ uint64_t window_bits(uint64_t w0, uint64_t w1, int off)
+{
+    if (off <= -64 || off >= 128) return 0ull;
+    if (off < 0) return w0 << (-off);
+    if (off == 0) return w0;
+    if (off < 64) return (w0 >> off) | (w1 << (64 - off));
+    return off == 64 ? w1 : (w1 >> (off - 64));
+}
+
+// MODE = GB_MAIN: the launch over all n nuclei; a nucleus one of whose variances came out of a badly centred sum is appended to
+// redo_list.  GB_REFINED: the launch over redo_list (count read on the device), shifts = the means already in the rows.
+// GB_TILES: the launch over the tiles of wide nuclei (above).
+template <typename T, int MODE>
 __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t n, int ps, const T *__restrict__ patches,
                                                          const uint64_t *__restrict__ mask_rows,
                                                          const GaborTables *__restrict__ tab, float *__restrict__ out,
-                                                         int F, int col0, int dbg, int *__restrict__ redo_list, int *__restrict__ redo_count)
+                                                         int F, int col0, int dbg, int *__restrict__ redo_list, int *__restrict__ redo_count,
+                                                         GaborTileArgs ta)
 {
+    constexpr bool REFINED = MODE == GB_REFINED, TILES = MODE == GB_TILES;
     __shared__ float s_g[NFX_ROW_WORD_PS * GB_GW + 16];
     __shared__ f2 s_UW[GB_UH * GB_UW]; // plane pair; row r lives at index r + GB_PAD; aprons stay zero
     __shared__ uint64_t s_rows[64 + 16];
@@ -429,13 +458,15 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
     GaborShared S;
     S.g = s_g; S.UW = s_UW;
     // u8 patches whose rows are whole 16-byte pieces come in with one 16-byte load per channel and thread
-    const bool vec = sizeof(T) == 1 && (ps & 15) == 0 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0;
+    const bool vec = !TILES && sizeof(T) == 1 && (ps & 15) == 0 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0;
+    const int pse = TILES ? NFX_ROW_WORD_PS : ps; // the patch the nucleus code below sees: a tile's window is 64 x 64
 
     // the next nucleus's mask row and (16-byte-piece) patch travel in registers while the current nucleus is processed: their
     // HBM latency hides behind a whole nucleus of work instead of stalling the workgroup at the top of every iteration
     uint64_t row_next = 0ull;
     uint4 r4n = make_uint4(0, 0, 0, 0), g4n = r4n, b4n = r4n;
     auto request = [&](int64_t i2) {
+        if (TILES) return; // (a tile's window rows are read where they are staged)
         if (t < 64) row_next = t < ps ? mask_rows[i2 * ps + t] : 0ull;
         if (vec && t < P / 16) {
             const uint4 *src = reinterpret_cast<const uint4 *>(patches + (size_t)i2 * 3 * P) + t;
@@ -443,16 +474,39 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
         }
     };
     if (REFINED) n = *redo_count;            // the list's length (this launch follows the one that filled it, on the same stream)
-    auto nucleus_at = [&](int64_t j) -> int64_t { return REFINED ? (int64_t)redo_list[j] : j; };
+    if (TILES) n = *ta.tile_count;
+    auto nucleus_at = [&](int64_t j) -> int64_t { return REFINED ? (int64_t)redo_list[j] : (TILES ? (int64_t)ta.tiles[j].nucleus : j); };
     if (t == 0) s_redo = 0;
     if ((int64_t)blockIdx.x < n) request(nucleus_at(blockIdx.x));
     for (int64_t j = blockIdx.x; j < n; j += gridDim.x) {
         const int64_t i = nucleus_at(j);
-        if (t < 64) s_rows[t] = row_next;
+        int wr = 0, wc = 0;
+        if (TILES) { // the window's mask rows: the wide mask's bits [wc, wc + 64) of row wr + t, central square only
+            wr = ta.tiles[j].wr; wc = ta.tiles[j].wc;
+            if (t < 64) {
+                const int r = wr + t;
+                uint64_t bits = 0ull;
+                if (t >= GB_PAD && t < GB_PAD + GB_CENTRAL && r >= 0 && r < ps)
+                    bits = window_bits(mask_rows[((size_t)i * ps + r) * 2], mask_rows[((size_t)i * ps + r) * 2 + 1], wc) & (((1ull << GB_CENTRAL) - 1ull) << GB_PAD);
+                s_rows[t] = bits;
+            }
+        } else if (t < 64) s_rows[t] = row_next;
         __syncthreads();
         const T *pp = patches + (size_t)i * 3 * P;
         float gsum = 0.0f; // masked gray sum -> the shift that keeps the f32 partial sums well conditioned
-        if (vec) {
+        if (TILES) { // the 64 x 64 window of the patch, zeros outside it
+            for (int p = t; p < NFX_ROW_WORD_PS * NFX_ROW_WORD_PS; p += GB_THREADS) {
+                const int rr = p >> 6, cc = p & 63, pr = wr + rr, pc = wc + cc;
+                float gs = 0.0f;
+                if (pr >= 0 && pr < ps && pc >= 0 && pc < ps) {
+                    const int q = pr * ps + pc;
+                    gs = BPx<T>::ld(pp, q) + BPx<T>::ld(pp, P + q);
+                    gs = gs + BPx<T>::ld(pp, 2 * P + q);
+                    gs = sizeof(T) == 1 ? third_of_u8_sum(gs) : gs / 3.0f; // texture.rs:332
+                }
+                s_g[rr * GB_GW + cc + GB_PAD] = gs;
+            }
+        } else if (vec) {
             for (int k = t; k < P / 16; k += GB_THREADS) {
                 const uint4 r4 = r4n, g4 = g4n, b4 = b4n; // P / 16 <= 256: one piece per thread and channel
                 const unsigned rr[4] = {r4.x, r4.y, r4.z, r4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
@@ -492,8 +546,9 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { olo |= __shfl_xor(olo, o, 64); ohi |= __shfl_xor(ohi, o, 64); }
         const uint64_t orr = ((uint64_t)(unsigned)ohi << 32) | (uint64_t)(unsigned)olo;
-        const int rmin = rowsany ? __ffsll((long long)rowsany) - 1 : ps, rmax = rowsany ? 63 - __clzll((long long)rowsany) : -1;
+        const int rmin = rowsany ? __ffsll((long long)rowsany) - 1 : pse, rmax = rowsany ? 63 - __clzll((long long)rowsany) : -1;
         float *o = out + i * (int64_t)F + col0;
+        if (TILES && area == 0) { __syncthreads(); continue; } // (the plan emits no empty tile)
         if (area == 0) { // 0/0 in texture.rs:340-344
             if (t < 96) o[t] = __builtin_nanf("");
             __syncthreads();
@@ -505,7 +560,7 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
             if (lane == 0) {
                 V.rmin = r_lo; V.rmax = r_hi; V.cmin = c_lo; V.cmax = c_hi;
                 V.rlo = r_lo - GB_PAD > 0 ? r_lo - GB_PAD : 0;
-                const int rhi = r_hi + (GB_SIZE - 1 - GB_PAD) < ps - 1 ? r_hi + (GB_SIZE - 1 - GB_PAD) : ps - 1;
+                const int rhi = r_hi + (GB_SIZE - 1 - GB_PAD) < pse - 1 ? r_hi + (GB_SIZE - 1 - GB_PAD) : pse - 1;
                 V.nrow_rp = rhi - V.rlo + 1;
             }
         };
@@ -540,9 +595,20 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
         float gtot = 0.0f;
 #pragma unroll
         for (int w = 0; w < GB_WAVES; ++w) gtot += s_gsum[w];
-        const float mu_gray = gtot / (float)area;
-        gabor_nucleus<REFINED>(S, tab, n_groups, n_plain, ps, s_view, mu_gray, s_shift, t, s_part, dbg);
+        const float mu_gray = TILES ? ta.mu_gray[i] : gtot / (float)area; // a tile's shift is its NUCLEUS's: the tiles' sums then simply add up
+        gabor_nucleus<REFINED>(S, tab, n_groups, n_plain, pse, s_view, mu_gray, s_shift, t, s_part, dbg);
         __syncthreads();
+        if (TILES) { // the tile's masked sums; k_gabor_finish adds a nucleus's tiles and forms the columns
+            if (t < n_filters) {
+                double a = 0.0, b = 0.0;
+#pragma unroll
+                for (int w = 0; w < GB_WAVES; ++w) { a += s_part[w][t][0]; b += s_part[w][t][1]; }
+                ta.tile_sums[((size_t)j * GB_MAX_FILTERS + t) * 2] = a;
+                ta.tile_sums[((size_t)j * GB_MAX_FILTERS + t) * 2 + 1] = b;
+            }
+            __syncthreads();
+            continue;
+        }
         // ---- mean / variance (texture.rs:339-344) from the shifted sums: mean = c + s1/K, var = s2/K - (s1/K)^2 -----
         if (t < n_filters) {
             const GaborFilter &Fl = tab->filters[t];
@@ -555,16 +621,119 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
             double var = b / K - m1 * m1;
             var = var > 0.0 ? var : 0.0;
             const double mean = shift + m1;
-            if (!REFINED && m1 * m1 > NFX_GB_REDO_RATIO * var) s_redo = 1; // (several threads may store the same 1)
+            if (MODE == GB_MAIN && m1 * m1 > NFX_GB_REDO_RATIO * var) s_redo = 1; // (several threads may store the same 1)
             if (Fl.ch0 >= 0) { o[2 * Fl.ch0] = (float)mean; o[2 * Fl.ch0 + 1] = (float)var; }
             if (Fl.ch1 >= 0) { o[2 * Fl.ch1] = (float)mean; o[2 * Fl.ch1 + 1] = (float)var; }
         }
         __syncthreads();
-        if (!REFINED && t == 0 && s_redo) { // after the barrier: every filter's verdict is in
+        if (MODE == GB_MAIN && t == 0 && s_redo) { // after the barrier: every filter's verdict is in
             redo_list[atomicAdd(redo_count, 1)] = (int)i;
             s_redo = 0;
         }
     }
+}
+
+// One workgroup per wide nucleus: mask area and masked gray sum (the shift), bounding box, and the tiles -- central squares of
+// GB_CENTRAL pixels laid over the bounding box from its top-left corner, those without a mask pixel left out -- written as ONE run
+// of the tile list (tile_begin / tile_n per nucleus), in row-major order: the order k_gabor_finish adds them in.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gabor_plan(int64_t n, int ps, const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
+                                                    GaborTile *__restrict__ tiles, int *__restrict__ tile_count, int *__restrict__ tile_begin,
+                                                    int *__restrict__ tile_n, float *__restrict__ mu_gray, int *__restrict__ area_out)
+{
+    __shared__ uint64_t s_rows[NFX_MAX_PATCH_SIZE][2];
+    __shared__ float s_g[4];
+    __shared__ int s_box[4], s_k[4], s_base;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int P = ps * ps;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        for (int k = t; k < 2 * ps; k += 256) s_rows[k >> 1][k & 1] = mask_rows[(size_t)i * ps * 2 + k];
+        __syncthreads();
+        const T *pp = patches + (size_t)i * 3 * P;
+        float gsum = 0.0f;
+        int cnt = 0;
+        for (int p = t; p < P; p += 256) {
+            const int r = p / ps, c = p - r * ps;
+            if ((s_rows[r][c >> 6] >> (c & 63)) & 1ull) {
+                float gs = BPx<T>::ld(pp, p) + BPx<T>::ld(pp, P + p);
+                gs = gs + BPx<T>::ld(pp, 2 * P + p);
+                gsum += sizeof(T) == 1 ? third_of_u8_sum(gs) : gs / 3.0f;
+                ++cnt;
+            }
+        }
+        gsum = wave_total_f32(gsum);
+        cnt = wave_total_i32(cnt);
+        if (lane == 0) { s_g[wv] = gsum; s_k[wv] = cnt; }
+        if (t == 0) { // bounding box (a serial look at <= 128 rows: nothing beside the 16 k pixels above)
+            int rmin = ps, rmax = -1;
+            uint64_t o0 = 0ull, o1 = 0ull;
+            for (int r = 0; r < ps; ++r) {
+                const uint64_t a = s_rows[r][0], b = s_rows[r][1];
+                if (a | b) { rmin = r < rmin ? r : rmin; rmax = r; }
+                o0 |= a; o1 |= b;
+            }
+            s_box[0] = rmin; s_box[1] = rmax;
+            s_box[2] = o0 ? __ffsll((long long)o0) - 1 : (o1 ? 64 + __ffsll((long long)o1) - 1 : ps);
+            s_box[3] = o1 ? 127 - __clzll((long long)o1) : (o0 ? 63 - __clzll((long long)o0) : -1);
+        }
+        __syncthreads();
+        const int area = (s_k[0] + s_k[1]) + (s_k[2] + s_k[3]);
+        const int rmin = s_box[0], rmax = s_box[1], cmin = s_box[2], cmax = s_box[3];
+        const int tr = area ? (rmax - rmin) / GB_CENTRAL + 1 : 0, tc = area ? (cmax - cmin) / GB_CENTRAL + 1 : 0;
+        // thread a * tc + b looks at tile (a, b): does its central square hold a mask pixel?
+        bool has = false;
+        if (t < tr * tc) {
+            const int a = t / tc, b = t - a * tc, r0 = rmin + a * GB_CENTRAL, c0 = cmin + b * GB_CENTRAL;
+            for (int r = r0; r < r0 + GB_CENTRAL && r < ps && !has; ++r)
+                has = (window_bits(s_rows[r][0], s_rows[r][1], c0) & ((1ull << GB_CENTRAL) - 1ull)) != 0ull;
+        }
+        const uint64_t votes = __ballot(has); // tr * tc <= 16: all in wave 0
+        if (t == 0) {
+            const int m = __popcll(votes);
+            s_base = m ? atomicAdd(tile_count, m) : 0;
+            tile_begin[i] = s_base; tile_n[i] = m;
+            mu_gray[i] = ((s_g[0] + s_g[1]) + (s_g[2] + s_g[3])) / (float)area;
+            area_out[i] = area;
+        }
+        __syncthreads();
+        if (has) {
+            const int a = t / tc, b = t - a * tc;
+            const int slot = s_base + __popcll(votes & ((1ull << t) - 1ull));
+            tiles[slot] = GaborTile{(int)i, rmin + a * GB_CENTRAL - GB_PAD, cmin + b * GB_CENTRAL - GB_PAD, 0};
+        }
+        __syncthreads();
+    }
+}
+
+// One thread per (nucleus, filter): the tiles' sums in list order, then mean / variance exactly as k_gabor forms them.
+__global__ __launch_bounds__(256) void k_gabor_finish(int64_t n, const GaborTables *__restrict__ tab, const int *__restrict__ tile_begin,
+                                                      const int *__restrict__ tile_n, const float *__restrict__ mu_gray, const int *__restrict__ area,
+                                                      const double *__restrict__ tile_sums, float *__restrict__ out, int F, int col0)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = g / GB_MAX_FILTERS;
+    const int f = (int)(g - i * GB_MAX_FILTERS);
+    if (i >= n || f >= tab->n_filters) return;
+    const GaborFilter &Fl = tab->filters[f];
+    float *o = out + i * (int64_t)F + col0;
+    const int K = area[i];
+    float mean_f = __builtin_nanf(""), var_f = __builtin_nanf(""); // empty mask: 0/0 in texture.rs:340-344
+    if (K > 0) {
+        double a = 0.0, b = 0.0;
+        const int t0 = tile_begin[i], m = tile_n[i];
+        for (int k = 0; k < m; ++k) {
+            a += tile_sums[((size_t)(t0 + k) * GB_MAX_FILTERS + f) * 2];
+            b += tile_sums[((size_t)(t0 + k) * GB_MAX_FILTERS + f) * 2 + 1];
+        }
+        const double shift = (double)(Fl.dc * mu_gray[i]);
+        const double m1 = a / (double)K;
+        double var = b / (double)K - m1 * m1;
+        var = var > 0.0 ? var : 0.0;
+        mean_f = (float)(shift + m1);
+        var_f = (float)var;
+    }
+    if (Fl.ch0 >= 0) { o[2 * Fl.ch0] = mean_f; o[2 * Fl.ch0 + 1] = var_f; }
+    if (Fl.ch1 >= 0) { o[2 * Fl.ch1] = mean_f; o[2 * Fl.ch1 + 1] = var_f; }
 }
 
 // ---- host: factorised, paired filter bank (DESIGN.md "Gabor bank") --------------------------------------
@@ -673,121 +842,6 @@ static void build_tables(GaborTables &T)
     T.n_groups = ok ? ng : GB_MAX_GROUPS + 1;
 }
 
-// ---- patch sizes 65..128: one 512-thread workgroup per nucleus (see k_geometry.hip, "patch sizes 65..128") -----------------
-// The paired separable passes above keep a 93 x 93 window of planes in LDS; a 128 x 128 patch does not fit.  This plainer form
-// is the reference's own shape: the DENSE 30 x 30 kernel of every channel (texture.rs:333-334; same bank as the separable
-// one, angle index * 6 + frequency index, theta = a pi / 4) correlated with the zero-padded gray patch (15 before, 14 after)
-// at the masked pixels only.  The masked pixels are compacted (row by row, in order: the sums are reproducible) so that
-// every lane owns one; a lane reads one 30-value row of its window from LDS and uses it for all 48 channels -- the weights are
-// wave-uniform and come through the scalar cache -- before it moves to the next of the 30 rows: 1440 FMAs per 30 LDS reads.
-// A tap row is accumulated in f32 (30 terms), rows in f64; masked mean and variance (texture.rs:339-344) from f64 sums.
-static constexpr int GBW_CH = 48;
-static constexpr int GBW_THREADS = 512; // two waves per SIMD: one wave's scalar weight loads hide behind the other's FMAs
-static constexpr int GBW_GS = NFX_MAX_PATCH_SIZE + GB_SIZE - 1; // gray row with apron: 157 floats (odd: conflict-free)
-struct GaborDense { float w[GBW_CH][GB_SIZE * GB_SIZE]; };
-
-template <typename T>
-__global__ __launch_bounds__(GBW_THREADS, 2) void k_gabor_wide(int64_t n, int ps, const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
-                                                       const GaborDense *__restrict__ bank, float *__restrict__ out, int F, int col0)
-{
-    __shared__ float s_ga[GBW_GS * GBW_GS];                                      // gray patch at [r + 15][c + 15], zero apron
-    __shared__ unsigned short s_list[NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE];   // masked pixels, r * ps + c, in raster order
-    __shared__ double s_sum[GBW_THREADS / 64][GBW_CH][2];
-    __shared__ int s_rowstart[NFX_MAX_PATCH_SIZE + 1];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int P = ps * ps;
-    for (int k = t; k < GBW_GS * GBW_GS; k += GBW_THREADS) s_ga[k] = 0.0f;
-    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
-        __syncthreads();
-        const T *pp = patches + (size_t)i * 3 * P;
-        const uint64_t *rows = mask_rows + (size_t)i * ps * 2;
-        for (int p = t; p < P; p += GBW_THREADS) {
-            float gs = BPx<T>::ld(pp, p) + BPx<T>::ld(pp, P + p);
-            gs = gs + BPx<T>::ld(pp, 2 * P + p);
-            const int r = p / ps, c = p - r * ps;
-            s_ga[(r + GB_PAD) * GBW_GS + c + GB_PAD] = sizeof(T) == 1 ? third_of_u8_sum(gs) : gs / 3.0f; // texture.rs:332
-        }
-        if (t == 0) { // row starts of the compacted list (128 additions: nothing next to the 43 200 FMAs per pixel below)
-            int at = 0;
-            for (int r = 0; r < ps; ++r) { s_rowstart[r] = at; at += __popcll(rows[2 * r]) + __popcll(rows[2 * r + 1]); }
-            s_rowstart[ps] = at;
-        }
-        for (int k = t; k < (GBW_THREADS / 64) * GBW_CH * 2; k += GBW_THREADS) (&s_sum[0][0][0])[k] = 0.0;
-        __syncthreads();
-        if (t < ps) {
-            int at = s_rowstart[t];
-            for (int w = 0; w < 2; ++w) {
-                uint64_t bits = rows[2 * t + w];
-                while (bits) {
-                    const int c = 64 * w + __ffsll((long long)bits) - 1;
-                    bits &= bits - 1ull;
-                    s_list[at++] = (unsigned short)(t * ps + c);
-                }
-            }
-        }
-        __syncthreads();
-        const int K = s_rowstart[ps];
-        for (int base = 0; base < K; base += GBW_THREADS) {
-            const int e = base + t;
-            const bool valid = e < K;
-            const int p = s_list[valid ? e : 0];
-            const int r = p / ps, c = p - r * ps;
-            double acc[GBW_CH];
-#pragma unroll
-            for (int f = 0; f < GBW_CH; ++f) acc[f] = 0.0;
-#pragma unroll 1
-            for (int ii = 0; ii < GB_SIZE; ++ii) {
-                float g[GB_SIZE];
-                const float *grow = &s_ga[(r + ii) * GBW_GS + c]; // gray row r + ii - 15, columns c - 15 .. c + 14
-#pragma unroll
-                for (int jj = 0; jj < GB_SIZE; ++jj) g[jj] = grow[jj];
-#pragma unroll
-                for (int f = 0; f < GBW_CH; ++f) {
-                    const float *w = &bank->w[f][ii * GB_SIZE]; // wave-uniform: scalar loads
-                    float row = 0.0f;
-#pragma unroll
-                    for (int jj = 0; jj < GB_SIZE; ++jj) row = fmaf(w[jj], g[jj], row);
-                    acc[f] += (double)row;
-                }
-            }
-#pragma unroll
-            for (int f = 0; f < GBW_CH; ++f) {
-                const double a = valid ? acc[f] : 0.0;
-                const double s1 = wave_total_f64(a), s2 = wave_total_f64(a * a);
-                if (lane == 0) { s_sum[wv][f][0] += s1; s_sum[wv][f][1] += s2; }
-            }
-        }
-        __syncthreads();
-        if (t < GBW_CH) {
-            const double area = (double)K;
-            double a = 0.0, b = 0.0;
-#pragma unroll
-            for (int w = 0; w < GBW_THREADS / 64; ++w) { a += s_sum[w][t][0]; b += s_sum[w][t][1]; }
-            const double mean = a / area; // 0/0 for an empty mask, as texture.rs:340-344
-            double var = b / area - mean * mean;
-            var = var > 0.0 ? var : (var == var ? 0.0 : var);
-            float *o = out + i * (int64_t)F + col0;
-            o[2 * t] = (float)mean;
-            o[2 * t + 1] = (float)var;
-        }
-    }
-}
-
-static void build_dense_bank(GaborDense &D)
-{
-    const double PI = 3.14159265358979323846, sigma = 0.45;
-    const double freqs[6] = {0.5, 1.0, 2.0, 4.0, 6.0, 8.0}; // texture.rs:320
-    for (int a = 0; a < 8; ++a)
-        for (int f = 0; f < 6; ++f) {
-            const double th = (double)a * PI / 4.0, ct = cos(th), st = sin(th);
-            for (int i = 0; i < GB_SIZE; ++i)
-                for (int j = 0; j < GB_SIZE; ++j) {
-                    const double x = -1.0 + 2.0 * (double)j / (double)(GB_SIZE - 1), y = -1.0 + 2.0 * (double)i / (double)(GB_SIZE - 1);
-                    D.w[a * 6 + f][i * GB_SIZE + j] = (float)(exp(-(x * x + y * y) / (2.0 * sigma * sigma)) * cos(2.0 * PI * freqs[f] * (x * ct + y * st)));
-                }
-        }
-}
-
 // The bank is the same for every context: built once per process (contexts are created and first used concurrently,
 // one per host thread -- main.rs:146-151), immutable afterwards.
 static const GaborTables &gabor_tables()
@@ -809,20 +863,63 @@ hipError_t prepare_gabor(nfx_ctx *ctx)
     if (e != hipSuccess) return e;
     e = hipMemcpy(tab, &T, sizeof(GaborTables), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(tab); return e; }
-    // the dense bank of the wide kernels (172 KB)
-    static GaborDense D;
-    static std::once_flag dense_once;
-    std::call_once(dense_once, [] { build_dense_bank(D); });
-    float *dense = nullptr;
-    e = hipMalloc(reinterpret_cast<void **>(&dense), sizeof(GaborDense));
-    if (e == hipSuccess) e = hipMemcpy(dense, &D, sizeof(GaborDense), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(tab); if (dense) (void)hipFree(dense); return e; }
-    ctx->gabor_dense = dense;
-    ctx->gabor_tab = tab; // published only once both are complete
+    ctx->gabor_tab = tab; // published only once it is complete
     return hipSuccess;
 }
 
-size_t gabor_scratch_bytes(const Job &job) { return job.ps > NFX_ROW_WORD_PS ? 0 : sizeof(int) * ((size_t)(job.n > 0 ? job.n : 1) + 16); } // redo list + its length
+// wide patches are planned, run and finished in chunks of GBT_CHUNK nuclei: the tile list and the tiles' sums of one chunk
+static constexpr int64_t GBT_CHUNK = 16384;
+struct WideScratch { int *tile_count, *tile_begin, *tile_n, *area; float *mu; GaborTile *tiles; double *sums; size_t bytes; };
+static WideScratch wide_scratch(void *scratch, int64_t nc)
+{
+    char *const base = reinterpret_cast<char *>(scratch);
+    char *p = base;
+    auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) & ~(size_t)255; return q; };
+    WideScratch w;
+    w.tile_count = reinterpret_cast<int *>(take(64));
+    w.tile_begin = reinterpret_cast<int *>(take(4 * (size_t)nc));
+    w.tile_n = reinterpret_cast<int *>(take(4 * (size_t)nc));
+    w.area = reinterpret_cast<int *>(take(4 * (size_t)nc));
+    w.mu = reinterpret_cast<float *>(take(4 * (size_t)nc));
+    w.tiles = reinterpret_cast<GaborTile *>(take(sizeof(GaborTile) * (size_t)nc * GB_MAX_TILES));
+    w.sums = reinterpret_cast<double *>(take(sizeof(double) * 2 * GB_MAX_FILTERS * (size_t)nc * GB_MAX_TILES));
+    w.bytes = (size_t)(p - base);
+    return w;
+}
+size_t gabor_scratch_bytes(const Job &job)
+{
+    const size_t n = (size_t)(job.n > 0 ? job.n : 1);
+    if (job.ps <= NFX_ROW_WORD_PS) return sizeof(int) * (n + 16); // redo list + its length
+    return wide_scratch(nullptr, (int64_t)(n < (size_t)GBT_CHUNK ? n : (size_t)GBT_CHUNK)).bytes; // (pointer arithmetic only)
+}
+
+template <typename T>
+static hipError_t launch_gabor_wide(nfx_ctx *ctx, const Job &job, int col0, void *scratch, const GaborTables *tab)
+{
+    const size_t P3 = 3 * (size_t)job.ps * job.ps;
+    for (int64_t i0 = 0; i0 < job.n; i0 += GBT_CHUNK) {
+        const int64_t nc = job.n - i0 < GBT_CHUNK ? job.n - i0 : GBT_CHUNK;
+        const WideScratch w = wide_scratch(scratch, job.n < GBT_CHUNK ? job.n : GBT_CHUNK);
+        const T *patches = reinterpret_cast<const T *>(job.patches) + (size_t)i0 * P3;
+        const uint64_t *rows = job.mask_rows + (size_t)i0 * job.ps * 2;
+        float *out = job.out + (size_t)i0 * job.F;
+        hipError_t e = hipMemsetAsync(w.tile_count, 0, sizeof(int), ctx->stream);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_gabor_plan<T>, dim3((unsigned)(nc < 256 * 8 ? nc : 256 * 8)), dim3(256), 0, ctx->stream, nc, job.ps, patches, rows, w.tiles, w.tile_count,
+                           w.tile_begin, w.tile_n, w.mu, w.area);
+        // the tile launch walks a list whose length only the device knows: sixteen rounds of the resident workgroups at most
+        const int64_t max_tiles = nc * GB_MAX_TILES;
+        const unsigned grid = (unsigned)(max_tiles < 256 * 2 * 16 ? max_tiles : 256 * 2 * 16);
+        GaborTileArgs ta{w.tiles, w.tile_count, w.mu, w.sums};
+        hipLaunchKernelGGL((k_gabor<T, GB_TILES>), dim3(grid), dim3(GB_THREADS), 0, ctx->stream, (int64_t)0, job.ps, patches, rows, tab, out, job.F, col0, 0,
+                           (int *)nullptr, (int *)nullptr, ta);
+        hipLaunchKernelGGL(k_gabor_finish, dim3((unsigned)((nc * GB_MAX_FILTERS + 255) / 256)), dim3(256), 0, ctx->stream, nc, tab, w.tile_begin, w.tile_n, w.mu, w.area,
+                           w.sums, out, job.F, col0);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 
 hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
 {
@@ -831,23 +928,13 @@ hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
     hipError_t e = prepare_gabor(ctx);
     if (e != hipSuccess) return e;
     ScopedTiming t(ctx, KS_GABOR);
-    if (job.ps > NFX_ROW_WORD_PS) {
-        const unsigned wgrid = (unsigned)(job.n < 256 * 2 ? job.n : 256 * 2);
-        const GaborDense *dense = reinterpret_cast<const GaborDense *>(ctx->gabor_dense);
-        if (job.patches_f32)
-            hipLaunchKernelGGL(k_gabor_wide<float>, dim3(wgrid), dim3(GBW_THREADS), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const float *>(job.patches),
-                               job.mask_rows, dense, job.out, job.F, col0);
-        else
-            hipLaunchKernelGGL(k_gabor_wide<uint8_t>, dim3(wgrid), dim3(GBW_THREADS), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const uint8_t *>(job.patches),
-                               job.mask_rows, dense, job.out, job.F, col0);
-        (void)scratch;
-        return hipGetLastError();
-    }
+    const GaborTables *tab = reinterpret_cast<const GaborTables *>(ctx->gabor_tab);
+    if (job.ps > NFX_ROW_WORD_PS)
+        return job.patches_f32 ? launch_gabor_wide<float>(ctx, job, col0, scratch, tab) : launch_gabor_wide<uint8_t>(ctx, job, col0, scratch, tab);
     // 64 rounds of the resident workgroups: nuclei differ several-fold in work, and with few large blocks the launch ends when
     // the unluckiest block does (2 rounds: +5 %); a block still amortises its LDS set-up over some forty nuclei of a large call
     const int64_t maxb = 256 * 2 * 64;
     const unsigned grid = (unsigned)(job.n < maxb ? job.n : maxb);
-    const GaborTables *tab = reinterpret_cast<const GaborTables *>(ctx->gabor_tab);
 #ifdef NFX_EXPERIMENTS // phase-skipping builds for timing experiments only (wrong results): 1 skip row pass, 2 skip column pass, 4 skip all groups
     const char *dbg_env = getenv("NFX_GABOR_DBG");
     const int dbg = dbg_env ? atoi(dbg_env) : 0;
@@ -860,14 +947,15 @@ hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
     // the second launch walks the list the first one filled: two workgroups per CU (its length is only known on the device; on
     // the BASELINE patch sizes it holds a percent of the nuclei or less, on patches smaller than the filter nearly all of them)
     const unsigned grid2 = (unsigned)(job.n < 256 * 2 * 4 ? job.n : 256 * 2 * 4);
+    const GaborTileArgs none{nullptr, nullptr, nullptr, nullptr};
     if (job.patches_f32) {
         const float *pf = reinterpret_cast<const float *>(job.patches);
-        hipLaunchKernelGGL((k_gabor<float, false>), dim3(grid), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps, pf, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count);
-        hipLaunchKernelGGL((k_gabor<float, true>), dim3(grid2), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps, pf, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count);
+        hipLaunchKernelGGL((k_gabor<float, GB_MAIN>), dim3(grid), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps, pf, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none);
+        hipLaunchKernelGGL((k_gabor<float, GB_REFINED>), dim3(grid2), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps, pf, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none);
     } else {
         const uint8_t *pb = reinterpret_cast<const uint8_t *>(job.patches);
-        hipLaunchKernelGGL((k_gabor<uint8_t, false>), dim3(grid), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps, pb, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count);
-        hipLaunchKernelGGL((k_gabor<uint8_t, true>), dim3(grid2), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps, pb, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count);
+        hipLaunchKernelGGL((k_gabor<uint8_t, GB_MAIN>), dim3(grid), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps, pb, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none);
+        hipLaunchKernelGGL((k_gabor<uint8_t, GB_REFINED>), dim3(grid2), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps, pb, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none);
     }
     return hipGetLastError();
 }

@@ -319,7 +319,6 @@ void nfx_ctx_destroy(nfx_ctx *ctx)
     if (ctx->dev_ws.base) (void)hipFree(ctx->dev_ws.base);
     if (ctx->host_ws.base) (void)hipFree(ctx->host_ws.base);
     if (ctx->gabor_tab) (void)hipFree(ctx->gabor_tab);
-    if (ctx->gabor_dense) (void)hipFree(ctx->gabor_dense);
     if (ctx->od_lut) (void)hipFree(ctx->od_lut);
     if (ctx->glcm_lut) (void)hipFree(ctx->glcm_lut);
     delete ctx;

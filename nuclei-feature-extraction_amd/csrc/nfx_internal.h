@@ -77,7 +77,6 @@ struct nfx_ctx {
     double total_ms[nfx::KS_COUNT] = {};
     // Gabor filter tables (device), built lazily
     float *gabor_tab = nullptr;
-    float *gabor_dense = nullptr; // the dense 48 x 30 x 30 bank of the wide (ps > 64) kernel
     // u8 -> optical-density lookup (device), built lazily
     float *od_lut = nullptr;
     // GLCM rank-difference / x ln x tables (device), built lazily
