@@ -787,36 +787,82 @@ __global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3
 }
 
 // ---- patch sizes 65..128: one 256-thread workgroup per nucleus (see k_geometry.hip, "patch sizes 65..128") -----------------
-// Up to 16 384 mask pixels do not fit the LDS lists and hash tables above.  This plainer form counts the pairs of one
-// (level, offset) combination into a DENSE symmetric matrix in global memory (the workgroup's own L x L slab of the workspace,
-// touched only inside the nucleus's level range) with global atomics, exactly as the reference's dense [N,L,L] tensor holds
-// them, then scans that square once for sum G^2 and sum G ln G; the pair sums are accumulated while counting, the marginal
-// and sum histograms are LDS counters.  The ten sums feed the same glcm_features as the wave kernel.
-static constexpr int GW_LMAX = 254;
-template <typename T>
+// Up to 16 384 mask pixels do not fit one wave's LDS lists.  Here a WORKGROUP owns the nucleus: the masked pixels are compacted into an
+// LDS list (position and levels, as in the wave kernel), and each of the 16 (level, offset) combinations is one pass of all 256
+// threads over the list: the partner is located through the mask rows, the unordered cell {a, b} is counted in an open-addressing
+// LDS hash table (claim with compare-and-swap, count with a plain add), the marginal and the sum histogram with LDS atomics, the pair
+// sums in registers.  Afterwards the table and the histograms are swept: sum G^2 and the three entropy sums come from the FINAL
+// counts, the latter in 32.32 FIXED POINT (integer additions: whatever order the waves' atomics landed in and wherever a cell
+// found its slot, the totals are the same bits -- a multi-wave table has no reproducible insertion order to telescope ranks over).
+// Two capacities: masks up to 6144 pixels (62 KB of LDS: two workgroups per CU) and up to 128 x 128 (150 KB); both launches walk
+// all nuclei through one cursor and skip the other's.  The ten sums feed the same glcm_features as the wave kernel.
+static constexpr long long GW_FIX = 1ll << 32;
+static __device__ __forceinline__ long long gw_xlnx_fix(const GlcmLuts *__restrict__ lut, unsigned g) // x ln x in 32.32 fixed point
+{
+    const double v = g < (unsigned)GL_COUNTS ? lut->xlnx[g] : (double)g * log((double)g);
+    return (long long)(v * (double)GW_FIX + 0.5);
+}
+static __device__ __forceinline__ unsigned long long gw_wave_total_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (unsigned long long)__shfl_xor((long long)v, o, 64);
+    return v;
+}
+
+template <typename T, int KCAP, int SLOTS>
 __global__ __launch_bounds__(256) void k_glcm_wide(int64_t n, int ps, const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
-                                                   const GlcmLuts *__restrict__ lut, unsigned *__restrict__ slabs, float *__restrict__ out, int F,
+                                                   const GlcmLuts *__restrict__ lut, int *__restrict__ cursor, int kmin, float *__restrict__ out, int F,
                                                    int col0, int64_t *__restrict__ dbg)
 {
-    __shared__ float s_gray[NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE];
-    __shared__ uint8_t s_q[NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE];
-    __shared__ uint64_t s_rows[NFX_MAX_PATCH_SIZE][2];
+    __shared__ unsigned s_q[KCAP];                       // r << 24 | c << 16 | level128 << 8 | level254
+    __shared__ unsigned s_tab[SLOTS];                    // key << 16 | count of the unordered cell (key = hi << 8 | lo)
     __shared__ unsigned s_hx[256], s_hs[512];
-    __shared__ double s_red[4][8];
+    __shared__ uint64_t s_rows[NFX_MAX_PATCH_SIZE][2];
+    __shared__ unsigned short s_start[NFX_MAX_PATCH_SIZE + 1][2]; // list index of the first pixel of (row, word)
+    __shared__ unsigned long long s_acc[10];             // np, S1, S2, D1, D2, asmn | ents, hxs, hss (fixed point) | spare
+    __shared__ double s_idm[4];                          // per wave: added in wave order
     __shared__ double s_sums[16][GL_NACC];
-    __shared__ int s_range[2];
+    __shared__ int s_i, s_cnt[4];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int P = ps * ps;
-    unsigned *G = slabs + (size_t)blockIdx.x * GW_LMAX * GW_LMAX;
-    const int levels[4] = {32, 64, 128, 254}; // texture.rs:19
-    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
-        const T *pp = patches + (size_t)i * 3 * P;
+    for (;;) {
+        if (t == 0) s_i = atomicAdd(cursor, 1);
+        __syncthreads();
+        const int64_t i = s_i;
+        if (i >= n) break;
+        // ---- mask rows, the list's row starts, the mask's size ----------------------------------------------------------------
         for (int k = t; k < 2 * ps; k += 256) s_rows[k >> 1][k & 1] = mask_rows[(size_t)i * ps * 2 + k];
         __syncthreads();
-        auto masked = [&](int r, int c) -> bool {
-            return (unsigned)r < (unsigned)ps && (unsigned)c < (unsigned)ps && ((s_rows[r][c >> 6] >> (c & 63)) & 1ull);
-        };
-        for (int p = t; p < P; p += 256) {
+        {
+            const int r = t >> 1, w = t & 1; // thread = (row, word)
+            const int cnt = r < ps ? __popcll(s_rows[r][w]) : 0;
+            const int incl = wave_inclusive_scan_i32(cnt);
+            if (lane == 63) s_cnt[wv] = incl;
+            __syncthreads();
+            int base = 0;
+            for (int k = 0; k < wv; ++k) base += s_cnt[k];
+            if (r < ps) s_start[r][w] = (unsigned short)(base + incl - cnt);
+        }
+        const int K = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        if ((KCAP > 8192) != (K > kmin)) { __syncthreads(); continue; } // the other capacity's launch takes it (uniform over the workgroup)
+        // ---- the list: positions, then levels --------------------------------------------------------------------------------
+        {
+            const int r = t >> 1, w = t & 1;
+            if (r < ps) {
+                uint64_t bits = s_rows[r][w];
+                unsigned at = s_start[r][w];
+                while (bits) {
+                    const int c = 64 * w + __ffsll((long long)bits) - 1;
+                    bits &= bits - 1ull;
+                    s_q[at++] = ((unsigned)r << 24) | ((unsigned)c << 16);
+                }
+            }
+        }
+        __syncthreads();
+        const T *pp = patches + (size_t)i * 3 * P;
+        for (int e = t; e < K; e += 256) {
+            const unsigned pos = s_q[e];
+            const int p = (int)(pos >> 24) * ps + (int)((pos >> 16) & 255u);
             float g;
             if (sizeof(T) == 1) {
                 const uint8_t *pb = reinterpret_cast<const uint8_t *>(pp);
@@ -826,66 +872,80 @@ __global__ __launch_bounds__(256) void k_glcm_wide(int64_t n, int ps, const T *_
             } else {
                 g = gray_at<T>(pp, P, p);
             }
-            s_gray[p] = g;
+            s_q[e] = pos | (quant(g, 128) << 8) | quant(g, 254); // texture.rs:19
         }
         __syncthreads();
+        // ---- the sixteen combinations ------------------------------------------------------------------------------------------
+#pragma unroll 1
         for (int li = 0; li < 4; ++li) {
-            const int L = levels[li];
-            if (t == 0) { s_range[0] = L; s_range[1] = -1; }
-            __syncthreads();
-            int qlo = L, qhi = -1;
-            for (int p = t; p < P; p += 256) {
-                const unsigned q = quant(s_gray[p], L);
-                s_q[p] = (uint8_t)q;
-                const int r = p / ps, c = p - r * ps;
-                if (masked(r, c)) { qlo = (int)q < qlo ? (int)q : qlo; qhi = (int)q > qhi ? (int)q : qhi; }
-            }
-            atomicMin(&s_range[0], qlo);
-            atomicMax(&s_range[1], qhi);
-            __syncthreads();
-            const int q0 = s_range[0], R = s_range[1] - s_range[0] + 1; // level range of the mask (R <= 0: empty mask)
+#pragma unroll 1
             for (int oi = 0; oi < 4; ++oi) {
                 const int dy = kGlcmOffsets[oi][0], dx = kGlcmOffsets[oi][1];
-                for (int k = t; k < R * R; k += 256) G[(size_t)(q0 + k / R) * L + q0 + k % R] = 0u;
+                for (int k = t; k < SLOTS; k += 256) s_tab[k] = GL_EMPTY;
                 s_hx[t] = 0u; s_hs[t] = 0u; s_hs[256 + t] = 0u;
-                __syncthreads(); // (workgroup-wide: the slab's zeros are in L2 before the atomics below reach it)
-                double np = 0, S1 = 0, S2 = 0, D1 = 0, D2 = 0, idm = 0;
-                for (int p = t; p < P; p += 256) {
-                    const int r = p / ps, c = p - r * ps;
-                    if (!masked(r, c) || !masked(r + dy, c + dx)) continue;
-                    const unsigned a = s_q[p], b = s_q[(r + dy) * ps + c + dx];
-                    atomicAdd(&G[(size_t)a * L + b], 1u);
-                    atomicAdd(&G[(size_t)b * L + a], 1u);
+                if (t < 10) s_acc[t] = 0ull;
+                __syncthreads();
+                unsigned long long np = 0, S1 = 0, S2 = 0, D1 = 0, D2 = 0;
+                double idm = 0.0;
+                for (int e = t; e < K; e += 256) {
+                    const unsigned qa = s_q[e];
+                    const int r2 = (int)(qa >> 24) + dy, c2 = (int)((qa >> 16) & 255u) + dx;
+                    if ((unsigned)r2 >= (unsigned)ps || (unsigned)c2 >= (unsigned)ps) continue;
+                    const uint64_t w2 = s_rows[r2][c2 >> 6];
+                    if (!((w2 >> (c2 & 63)) & 1ull)) continue;
+                    const unsigned qb = s_q[s_start[r2][c2 >> 6] + (unsigned)__popcll(w2 & ((1ull << (c2 & 63)) - 1ull))];
+                    unsigned a, b;
+                    if (li == 3) { a = qa & 255u; b = qb & 255u; }
+                    else { a = ((qa >> 8) & 255u) >> (2 - li); b = ((qb >> 8) & 255u) >> (2 - li); } // floor(128 g) >> k = floor(2^(7-k) g)
+                    const unsigned lo = a < b ? a : b, hi = a < b ? b : a, d = hi - lo, sm = a + b;
+                    np += 1; S1 += sm; S2 += (unsigned long long)sm * sm; D1 += d; D2 += (unsigned long long)d * d;
+                    idm += 1.0 / (1.0 + (double)(d * d));
                     atomicAdd(&s_hx[a], 1u);
                     atomicAdd(&s_hx[b], 1u);
-                    atomicAdd(&s_hs[a + b], 1u);
-                    const double sm = (double)(a + b), d = (double)(a > b ? a - b : b - a);
-                    np += 1.0; S1 += sm; S2 += sm * sm; D1 += d; D2 += d * d; idm += 1.0 / (1.0 + d * d);
+                    atomicAdd(&s_hs[sm], 1u);
+                    const unsigned key = (hi << 8) | lo;
+                    unsigned h = (unsigned)__umul24(key, 0x9E3779u) >> 8;
+                    h = (unsigned)(((unsigned long long)(h & 0xFFFFu) * (unsigned)SLOTS) >> 16);
+                    for (int probes = 0; probes < SLOTS; ++probes) { // a cell per pair fits (SLOTS > KCAP): the search always ends
+                        const unsigned prev = atomicCAS(&s_tab[h], GL_EMPTY, (key << 16) | 1u);
+                        if (prev == GL_EMPTY) break;
+                        if ((prev >> 16) == key) { atomicAdd(&s_tab[h], 1u); break; }
+                        h = h + 1u == (unsigned)SLOTS ? 0u : h + 1u;
+                    }
                 }
                 __syncthreads();
-                double asmn = 0, ents = 0, hxs = 0, hss = 0;
-                for (int k = t; k < R * R; k += 256) { // atomic loads: the counts live in L2, this CU's L1 may hold the zeros
-                    const unsigned g = __hip_atomic_load(&G[(size_t)(q0 + k / R) * L + q0 + k % R], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asmn += (double)g * (double)g;
-                    ents += lut->xlnx[g < (unsigned)GL_COUNTS ? g : 0u] + (g < (unsigned)GL_COUNTS ? 0.0 : (double)g * log((double)g));
+                // ---- sweep: sum G^2 and sum G ln G over the symmetric matrix from the final counts; marginal and sum entropies ----
+                unsigned long long asmn = 0;
+                long long ents = 0, hxs = 0, hss = 0;
+                for (int k = t; k < SLOTS; k += 256) {
+                    const unsigned v = s_tab[k];
+                    if (v == GL_EMPTY) continue;
+                    const unsigned cnt = v & 0xFFFFu, key = v >> 16;
+                    const bool diag = (key >> 8) == (key & 255u);
+                    const unsigned gsym = diag ? 2u * cnt : cnt;   // the symmetric matrix holds 2 cnt on the diagonal, cnt twice off it
+                    asmn += (unsigned long long)gsym * gsym * (diag ? 1u : 2u);
+                    ents += gw_xlnx_fix(lut, gsym) * (diag ? 1 : 2);
                 }
-                { const unsigned h = s_hx[t]; hxs += h < (unsigned)GL_COUNTS ? lut->xlnx[h] : (double)h * log((double)h); }
-                for (int k = t; k < 512; k += 256) { const unsigned h = s_hs[k]; hss += h < (unsigned)GL_COUNTS ? lut->xlnx[h] : (double)h * log((double)h); }
-                double v[10] = {np, S1, S2, D1, D2, idm, asmn, ents, hxs, hss};
+                hxs += gw_xlnx_fix(lut, s_hx[t]);
+                hss += gw_xlnx_fix(lut, s_hs[t]) + gw_xlnx_fix(lut, s_hs[256 + t]);
+                {
+                    unsigned long long v[9] = {np, S1, S2, D1, D2, asmn, (unsigned long long)ents, (unsigned long long)hxs, (unsigned long long)hss};
 #pragma unroll
-                for (int k = 0; k < 10; ++k) {
-                    // two rounds of eight through the 4 x 8 staging array
-                    v[k] = wave_total_f64(v[k]);
+                    for (int k = 0; k < 9; ++k) {
+                        const unsigned long long w = gw_wave_total_u64(v[k]);
+                        if (lane == 0) atomicAdd(&s_acc[k], w);
+                    }
+                    const double wi = wave_total_f64(idm);
+                    if (lane == 0) s_idm[wv] = wi;
                 }
                 __syncthreads();
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    if (lane == 0)
-                        for (int k = 0; k < 5; ++k) s_red[wv][k] = v[5 * half + k];
-                    __syncthreads();
-                    if (t < 5) s_sums[li * 4 + oi][5 * half + t] = (s_red[0][t] + s_red[1][t]) + (s_red[2][t] + s_red[3][t]);
-                    __syncthreads();
+                if (t == 0) {
+                    double *a = s_sums[li * 4 + oi];
+                    a[0] = (double)s_acc[0]; a[1] = (double)s_acc[1]; a[2] = (double)s_acc[2]; a[3] = (double)s_acc[3]; a[4] = (double)s_acc[4];
+                    a[5] = (s_idm[0] + s_idm[1]) + (s_idm[2] + s_idm[3]); a[6] = (double)s_acc[5];
+                    a[7] = (double)(long long)s_acc[6] / (double)GW_FIX; a[8] = (double)(long long)s_acc[7] / (double)GW_FIX; a[9] = (double)(long long)s_acc[8] / (double)GW_FIX;
                 }
+                __syncthreads();
             }
         }
         if (t < 16) { // combination t = level * 4 + offset, the column order of texture.rs:81-157
@@ -903,10 +963,10 @@ __global__ __launch_bounds__(256) void k_glcm_wide(int64_t n, int ps, const T *_
 #endif
 static constexpr int GL_MAX_GRID = 256 * 12 * NFX_GL_ROUNDS; // resident single-wave workgroups of the largest launch = parking slots
 static size_t glcm_slots_bytes() { return sizeof(double) * 16 * GL_NACC * (size_t)GL_MAX_GRID; }
-static constexpr int GW_GRID = 256; // workgroups (and dense slabs) of the wide kernel
+static constexpr int GW_SMALL_K = 6144; // masks up to this many pixels take the small-capacity launch of the wide kernel
 size_t glcm_scratch_bytes(const Job &job)
 {
-    if (job.ps > 64) return sizeof(unsigned) * (size_t)GW_GRID * GW_LMAX * GW_LMAX; // k_glcm_wide's count slabs (66 MB)
+    if (job.ps > 64) return 256; // k_glcm_wide: the two launches' cursors
     const size_t n = (size_t)(job.n > 0 ? job.n : 1);
     return glcm_slots_bytes() + sizeof(int) * (GL_CLASSES * n + 64);
 }
@@ -986,13 +1046,19 @@ hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
     ScopedTiming t(ctx, KS_GLCM);
     if (job.ps > 64) {
         const GlcmLuts *wlut = reinterpret_cast<const GlcmLuts *>(ctx->glcm_lut);
-        const unsigned wgrid = (unsigned)(job.n < GW_GRID ? job.n : GW_GRID);
-        if (job.patches_f32)
-            hipLaunchKernelGGL(k_glcm_wide<float>, dim3(wgrid), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const float *>(job.patches),
-                               job.mask_rows, wlut, reinterpret_cast<unsigned *>(scratch), job.out, job.F, col0, job.dbg_glcm);
-        else
-            hipLaunchKernelGGL(k_glcm_wide<uint8_t>, dim3(wgrid), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const uint8_t *>(job.patches),
-                               job.mask_rows, wlut, reinterpret_cast<unsigned *>(scratch), job.out, job.F, col0, job.dbg_glcm);
+        int *cursors = reinterpret_cast<int *>(scratch);
+        e = hipMemsetAsync(cursors, 0, 2 * sizeof(int), ctx->stream);
+        if (e != hipSuccess) return e;
+        const unsigned g_small = (unsigned)(job.n < 256 * 2 ? job.n : 256 * 2), g_large = (unsigned)(job.n < 256 ? job.n : 256);
+        if (job.patches_f32) {
+            const float *pf = reinterpret_cast<const float *>(job.patches);
+            hipLaunchKernelGGL((k_glcm_wide<float, GW_SMALL_K, 8192>), dim3(g_small), dim3(256), 0, ctx->stream, job.n, job.ps, pf, job.mask_rows, wlut, cursors, GW_SMALL_K, job.out, job.F, col0, job.dbg_glcm);
+            hipLaunchKernelGGL((k_glcm_wide<float, 16384, 20480>), dim3(g_large), dim3(256), 0, ctx->stream, job.n, job.ps, pf, job.mask_rows, wlut, cursors + 1, GW_SMALL_K, job.out, job.F, col0, job.dbg_glcm);
+        } else {
+            const uint8_t *pb = reinterpret_cast<const uint8_t *>(job.patches);
+            hipLaunchKernelGGL((k_glcm_wide<uint8_t, GW_SMALL_K, 8192>), dim3(g_small), dim3(256), 0, ctx->stream, job.n, job.ps, pb, job.mask_rows, wlut, cursors, GW_SMALL_K, job.out, job.F, col0, job.dbg_glcm);
+            hipLaunchKernelGGL((k_glcm_wide<uint8_t, 16384, 20480>), dim3(g_large), dim3(256), 0, ctx->stream, job.n, job.ps, pb, job.mask_rows, wlut, cursors + 1, GW_SMALL_K, job.out, job.F, col0, job.dbg_glcm);
+        }
         return hipGetLastError();
     }
     double *slots = reinterpret_cast<double *>(scratch);
