@@ -83,8 +83,9 @@ typedef enum {
 typedef enum { NFX_MEM_HOST = 0, NFX_MEM_DEVICE = 1 } nfx_mem;
 
 /* Patch sizes (args.rs:93-94, default 64).  Up to 64 a mask row is one 64-bit word in one lane's registers and the
-   wave-per-nucleus kernels run; 65..128 take a plainer kernel family (one workgroup per nucleus, two words per mask row): same
-   results, far lower throughput.  Larger patches are refused with NFX_ERR_UNSUPPORTED. */
+   wave-per-nucleus kernels run; 65..128 take a second kernel family (one workgroup per nucleus, two words per mask row; Gabor on
+   64 x 64 tiles through the fast kernel): same results, lower throughput (all five sets: 0.5 M nuclei/s at 128 x 128 against 7 M/s
+   at 64 x 64).  Larger patches are refused with NFX_ERR_UNSUPPORTED. */
 #define NFX_MAX_PATCH_SIZE 128
 
 /* ---- registry (no context, no GPU needed) ------------------------------------------------ */
