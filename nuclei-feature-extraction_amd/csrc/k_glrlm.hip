@@ -13,11 +13,12 @@
 //     outside the mask; then (lane = column) for each of the four directions a ballot builds the row's
 //     "continues its predecessor" word C_d[r] (pixel and predecessor in the mask with equal level), filed
 //     under lane r;
-//   * per direction (lane = row): run starts are S = M & ~C.  Step k ANDs in the C word of the row k steps
-//     ahead (a one-lane shuffle), shifted by k*dx bits: what survives are the starts whose run is longer
-//     than k.  A 4-bit bit-sliced counter accumulates the survivors, so after <=15 steps every start
-//     knows min(length,16)-1 -- all pixels of a row advance together, with early exit when no run is alive;
-//   * each lane then walks its row's starts (ffs) and bumps one of the 384 run-length bins per RUN.
+//   * per direction: run starts are S = M & ~C (lane = row).  S and C are re-filed so that a lane holds one LINE of the direction
+//     -- row, column or diagonal (modulo 64) -- with the run direction along its bits: a per-row rotation turns the diagonals
+//     into columns, a 64 x 64 bit transpose across the wave (six butterfly stages) turns columns into rows.  The length of
+//     the run that starts at bit p is then 1 + the number of set C bits right above p: a funnel shift and a find-first-clear,
+//     with no counting loop over the steps of the run;
+//   * each lane walks its line's starts (ffs) and bumps one of the 384 run-length bins per RUN.
 // The 17 features are weighted sums over the bins: with bin = lane + 64k a lane always sees the same run
 // length l = lane % 16 and six fixed gray levels, so every weight is a register computed once per kernel;
 // row/column sums for the non-uniformity features are 16-lane / 4-lane butterfly reductions.
@@ -51,6 +52,45 @@ static __device__ __forceinline__ unsigned eq4(unsigned a, unsigned b)
 static __device__ __forceinline__ unsigned eq16(const unsigned (&a)[4], unsigned b0, unsigned b1, unsigned b2, unsigned b3)
 {
     return eq4(a[0], b0) | (eq4(a[1], b1) << 4) | (eq4(a[2], b2) << 8) | (eq4(a[3], b3) << 12);
+}
+
+static __device__ __forceinline__ uint64_t rotr64(uint64_t x, unsigned s) // s in 0..63
+{
+    const unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
+    const bool sw = s & 32u;
+    const unsigned a = sw ? hi : lo, b = sw ? lo : hi; // rotating by 32 swaps the halves; alignbit takes the amount modulo 32
+    return ((uint64_t)__builtin_amdgcn_alignbit(a, b, s) << 32) | __builtin_amdgcn_alignbit(b, a, s);
+}
+
+// 64 x 64 bit transpose of two matrices held one 64-bit row per lane: bit c of lane r moves to bit r of lane c.  Six butterfly
+// stages; stage j swaps index bit j of the lane with index bit j of the bit position (j x j blocks change places between lanes
+// l and l ^ j), and the stages below 32 treat the two 32-bit halves alike.
+static __device__ __forceinline__ void wave_bit_transpose2(uint64_t &a, uint64_t &b, int lane)
+{
+    unsigned w[4] = {(unsigned)a, (unsigned)(a >> 32), (unsigned)b, (unsigned)(b >> 32)};
+    {
+        const bool up = lane & 32; // lanes below 32 give their high half away and file the partner's low half there; the others mirror it
+        const unsigned ga = up ? w[0] : w[1], gb = up ? w[2] : w[3];
+        const unsigned ra = (unsigned)__shfl_xor((int)ga, 32, 64), rb = (unsigned)__shfl_xor((int)gb, 32, 64);
+        w[0] = up ? ra : w[0]; w[1] = up ? w[1] : ra;
+        w[2] = up ? rb : w[2]; w[3] = up ? w[3] : rb;
+    }
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int j = 16 >> st;
+        const unsigned m = j == 16 ? 0x0000FFFFu : j == 8 ? 0x00FF00FFu : j == 4 ? 0x0F0F0F0Fu : j == 2 ? 0x33333333u : 0x55555555u; // positions with bit j clear
+        const bool up = lane & j;
+        const unsigned rot = up ? (unsigned)j : 32u - (unsigned)j; // rotate right by j: bit p + j comes to p; by 32 - j: bit p - j comes to p
+        const unsigned keep = up ? ~m : m;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned t = (unsigned)__shfl_xor((int)w[k], j, 64);
+            const unsigned r = __builtin_amdgcn_alignbit(t, t, rot);
+            w[k] = (w[k] & keep) | (r & ~keep);
+        }
+    }
+    a = ((uint64_t)w[1] << 32) | w[0];
+    b = ((uint64_t)w[3] << 32) | w[2];
 }
 
 // per-lane constant weights of the 17 features: with bin = lane + 64 k a lane always sees the same run length
@@ -303,45 +343,44 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
         wave_lds_fence();
 
         for (int d = 0; d < 4; ++d) {
-            const int dx = kRlDirs[d][0], dy = kRlDirs[d][1];
-            const uint64_t C = ((uint64_t)(unsigned)chi[d] << 32) | (uint64_t)(unsigned)clo[d];
-            const uint64_t S = myrow & ~C;          // run starts of this lane's row
-            uint64_t alive = S, Y = C;              // alive: starts whose run is still growing; Y: C word of the row k steps ahead
-            uint64_t b0 = 0, b1 = 0, b2 = 0, b3 = 0; // bit-sliced min(length,16)-1 per start
-            for (int k = 1; k < RL_MAXLEN; ++k) {
-                if (dy) {
-                    // the next row's word: whole-wave DPP shift, lane 63 receives zero
-                    const unsigned ylo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)Y, 0x130, 0xF, 0xF, false);
-                    const unsigned yhi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(Y >> 32), 0x130, 0xF, 0xF, false);
-                    Y = ((uint64_t)yhi << 32) | ylo;
+            // Lines: the words are re-filed so that a lane holds one LINE of the direction (a row, a column, a diagonal modulo 64) with
+            // the run direction along its bits -- a skew (row r rotated by -r / +r bits: the two diagonals become columns; where two
+            // diagonals share a column the second one's first pixel has no predecessor, so its C bit is clear and no run crosses)
+            // and a 64 x 64 bit transpose.  Pixel of (line l, bit p): d = 0: (row l, column p); else row p, column (l + sgn p) mod 64.
+            const int sgn = d == 1 ? 1 : (d == 3 ? -1 : 0);
+            int ln = lane;
+            asm volatile("" : "+v"(ln)); // opaque per direction: the butterflies' per-lane masks, amounts and partner addresses are cheap to
+                                         // make and would otherwise be hoisted out of both loops into twenty registers the kernel does not have
+            uint64_t C = ((uint64_t)(unsigned)chi[d] << 32) | (uint64_t)(unsigned)clo[d];
+            uint64_t S = myrow & ~C;                // run starts of this lane's row
+            if (d != 0) {
+                if (sgn) {
+                    const unsigned rot = (unsigned)(sgn > 0 ? ln : 64 - ln) & 63u; // rotate right by rot: bit c -> bit (c - rot) mod 64
+                    C = rotr64(C, rot);
+                    S = rotr64(S, rot);
                 }
-                const uint64_t X = dx > 0 ? (Y >> k) : (dx < 0 ? (Y << k) : Y);
-                alive &= X;
-                if (__ballot(alive != 0ull) == 0ull) break; // no run in this nucleus is longer than k
-                uint64_t c = alive, t;
-                t = b0 & c; b0 ^= c; c = t;
-                t = b1 & c; b1 ^= c; c = t;
-                t = b2 & c; b2 ^= c; c = t;
-                b3 ^= c;
+                wave_bit_transpose2(C, S, ln);
             }
-            // one bin update per run; the row's starts are walked as two 32-bit words (single-instruction find-first-set
-            // and bit-field extracts instead of their 64-bit sequences)
-            {
-                const int rbase = lane * QS;
+            // a start at bit p has the length 1 + (number of set C bits right above p), at most 16; one bin update per run, the
+            // line's starts walked as two 32-bit words (single-instruction find-first-set, funnel shift, find-first-clear)
+            const uint64_t C1 = C >> 1;
+            const unsigned c1lo = (unsigned)C1, c1hi = (unsigned)(C1 >> 32);
+            const int pa = d == 0 ? 1 : QS, la = d == 0 ? QS : 1; // byte-map strides of the bit position and of the line index
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int sh = 32 * half;
-                    unsigned rem = (unsigned)(S >> sh);
-                    const unsigned h0 = (unsigned)(b0 >> sh), h1 = (unsigned)(b1 >> sh), h2 = (unsigned)(b2 >> sh), h3 = (unsigned)(b3 >> sh);
-                    while (rem) {
-                        const int pos = __ffs((int)rem) - 1;
-                        rem &= rem - 1u;
-                        const unsigned len1 = ((h0 >> pos) & 1u) | (((h1 >> pos) & 1u) << 1) | (((h2 >> pos) & 1u) << 2) | (((h3 >> pos) & 1u) << 3);
-                        const unsigned q = s_q[rbase + sh + pos];
-                        // starts lie inside the mask, so q <= 23; the clamp keeps a stray byte (0xFF outside the mask) from ever
-                        // indexing past the 384 bins into a neighbouring wave's table
-                        atomicAdd(&s_R[(q < (unsigned)RL_LEVELS ? q : (unsigned)RL_LEVELS - 1u) * RL_MAXLEN + len1], 1u);
-                    }
+            for (int half = 0; half < 2; ++half) {
+                unsigned rem = half ? (unsigned)(S >> 32) : (unsigned)S;
+                const unsigned whi = half ? 0u : c1hi, wlo = half ? c1hi : c1lo;
+                while (rem) {
+                    const int p = __ffs((int)rem) - 1;
+                    rem &= rem - 1u;
+                    const unsigned above = __builtin_amdgcn_alignbit(whi, wlo, (unsigned)p); // C bits p + 1, p + 2, ...
+                    unsigned len1 = (unsigned)(__ffs((int)~above) - 1);                       // all set: 0xFFFFFFFF -> clamped below
+                    len1 = len1 < (unsigned)RL_MAXLEN - 1u ? len1 : (unsigned)RL_MAXLEN - 1u;
+                    const int pos = 32 * half + p;
+                    const unsigned q = s_q[pos * pa + ((ln + sgn * pos) & 63) * la];
+                    // starts lie inside the mask, so q <= 23; the clamp keeps a stray byte (0xFF outside the mask) from ever
+                    // indexing past the 384 bins into a neighbouring wave's table
+                    atomicAdd(&s_R[(q < (unsigned)RL_LEVELS ? q : (unsigned)RL_LEVELS - 1u) * RL_MAXLEN + len1], 1u);
                 }
             }
             wave_lds_fence();

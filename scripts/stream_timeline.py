@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""One streamed call under the tracer (run on the GPU box), for a timeline of its kernels and copies:
+    rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/tl -- python3 scripts/stream_timeline.py [nuclei] [ps] [chunk]
+    python scripts/stream_timeline.py --read gpurun_out/tl      # afterwards, anywhere: busy time and gaps per chunk"""
+import glob
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def read(d):
+    import csv
+    ev = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "K", r["Kernel_Name"].split("(")[0][:44], r.get("Queue_Id", "")))
+    for f in glob.glob(os.path.join(d, "**", "*memory_copy_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "C", r["Direction"], ""))
+    ev.sort()
+    # the LAST streamed call: everything after the last long idle stretch of kernels before the final burst of k_gather launches
+    t_end = max(e[1] for e in ev)
+    gathers = [e for e in ev if "gather_patches" in e[3]]
+    # calls are separated by a host-side pause; take the events after the largest gap among the last half of the gathers' starts
+    starts = [g[0] for g in gathers]
+    cut = 0
+    if len(starts) > 2:
+        half = starts[len(starts) // 2 - 1:]
+        gaps = [(half[i + 1] - half[i], half[i + 1]) for i in range(len(half) - 1)]
+        cut = max(gaps)[1] - 1 if gaps else 0
+    ev = [e for e in ev if e[0] >= cut - 30_000_000]
+    t0 = min(e[0] for e in ev)
+    print(f"{len(ev)} events over {(t_end - t0) / 1e6:.1f} ms")
+
+    def busy(sel):
+        iv = sorted((e[0], e[1]) for e in ev if sel(e))
+        tot, cur_s, cur_e = 0, None, None
+        for s, e in iv:
+            if cur_e is None or s > cur_e:
+                if cur_e is not None: tot += cur_e - cur_s
+                cur_s, cur_e = s, e
+            else:
+                cur_e = max(cur_e, e)
+        if cur_e is not None: tot += cur_e - cur_s
+        return tot / 1e6
+    feat = lambda e: e[2] == "K" and "gather_patches" not in e[3]
+    print(f"busy: feature kernels {busy(feat):.1f} ms, gathers {busy(lambda e: 'gather_patches' in e[3]):.1f} ms, "
+          f"H2D {busy(lambda e: e[2] == 'C' and 'HOST_TO_DEVICE' in e[3]):.1f} ms, D2H {busy(lambda e: e[2] == 'C' and 'DEVICE_TO_HOST' in e[3]):.1f} ms")
+    by = {}
+    for e in ev:
+        if e[2] == "K":
+            a = by.setdefault(e[3], [0, 0.0]); a[0] += 1; a[1] += (e[1] - e[0]) / 1e6
+    for k, (c, ms) in sorted(by.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"  {k:46s} x{c:4d} {ms:8.2f} ms")
+    # gaps in the feature kernels' union (> 0.2 ms): what the compute stream waited for
+    iv = sorted((e[0], e[1], e[3]) for e in ev if feat(e))
+    end, last = iv[0][1], iv[0][2]
+    for s, e, nm in iv[1:]:
+        if s - end > 200_000:
+            print(f"  gap {(s - end) / 1e6:6.2f} ms at {(end - t0) / 1e6:7.1f} ms after {last} before {nm}")
+        if e > end: end, last = e, nm
+
+
+if len(sys.argv) > 2 and sys.argv[1] == "--read":
+    read(sys.argv[2])
+    sys.exit(0)
+
+import torch
+sys.path.insert(0, ROOT)
+nfx = importlib.import_module("nuclei-feature-extraction_amd")
+synth = importlib.import_module("nuclei-feature-extraction_amd.synth")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000
+ps = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+dev = torch.device("cuda", 0)
+torch.cuda.init()
+ctx = nfx.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+seed = synth.SEED_BASE + 4
+T = synth.tile_side(n, ps)
+cx, cy = synth.centres_slide_order(seed, 0, n, n, ps, T, T)
+off, xy = synth.polygons(seed, 0, n, ps, cx, cy)
+d_off, d_xy = torch.from_numpy(off.astype(np.int32)).to(dev), torch.from_numpy(xy).to(dev)
+cen = ctx.preprocess_polygons(d_off, d_xy)[0].cpu().numpy()
+d_p = synth.patches(seed, 0, n, ps, xp=torch, device=dev)
+tile = synth.tile_from_patches(torch, d_p, cen[:, 0], cen[:, 1], T, T, ps, seed, dev)
+del d_p
+h_tile = nfx.pinned_empty((3, T, T), np.uint8)
+for r0 in range(0, T, 2048):
+    h_tile[:, r0:r0 + 2048] = tile[:, r0:r0 + 2048].cpu().numpy()
+del tile
+torch.cuda.empty_cache()
+sets = [0, 1, 2, 3, 4]
+rows = nfx.pinned_empty((n, sum(nfx.num_columns(s) for s in sets)), np.float32)
+import time
+for _ in range(2):
+    t0 = time.perf_counter()
+    ctx.extract_tile_streamed(sets, off, xy, h_tile, ps, chunk_nuclei=chunk, out=rows)
+    print(f"streamed call {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
+    time.sleep(0.2)
+ctx.set_stream(0)
+ctx.close()
