@@ -306,8 +306,10 @@ void nfx_ctx_destroy(nfx_ctx *ctx)
     if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->alt_stream) { (void)hipStreamSynchronize(ctx->alt_stream); (void)hipStreamDestroy(ctx->alt_stream); }
+    if (ctx->d2h_stream) { (void)hipStreamSynchronize(ctx->d2h_stream); (void)hipStreamDestroy(ctx->d2h_stream); }
     if (ctx->rows_stream) { (void)hipStreamSynchronize(ctx->rows_stream); (void)hipStreamDestroy(ctx->rows_stream); }
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 3; ++b)
         for (hipEvent_t e : {ctx->ev_ready[b], ctx->ev_done[b], ctx->ev_rows[b], ctx->ev_bands[b]})
             if (e) (void)hipEventDestroy(e);
     if (ctx->pin) (void)hipHostFree(ctx->pin);

@@ -52,8 +52,8 @@ struct nfx_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr; // here, beside the rasteriser and the pixel kernels of the same call
     hipEvent_t ev_mid = nullptr;                     // (experiment knob NFX_EXP_GABOR_SIDE: mask rows ready)
     // nfx_extract_tile_streamed (nfx_stream.cpp): block copies + window gathers | rows back to the host, created on first use
-    hipStream_t copy_stream = nullptr, rows_stream = nullptr;
-    hipEvent_t ev_ready[2] = {}, ev_done[2] = {}, ev_rows[2] = {}, ev_bands[2] = {};
+    hipStream_t copy_stream = nullptr, rows_stream = nullptr, d2h_stream = nullptr, alt_stream = nullptr;
+    hipEvent_t ev_ready[3] = {}, ev_done[3] = {}, ev_rows[3] = {}, ev_bands[3] = {};
     void *pin = nullptr;      // grow-only pinned host staging (selection lists, rebased offsets of two chunks)
     size_t pin_cap = 0;
     nfx_addressing addressing = NFX_ADDR_IMAGE;

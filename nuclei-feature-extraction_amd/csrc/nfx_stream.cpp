@@ -17,8 +17,11 @@
 // evicted is copied again; the device keeps as many bands as `cache_bytes` allows -- the whole slide, typically).
 //
 //   copy stream    : H2D bands of chunk k+1, k+2, ... back to back (nothing but copies: the link never waits for a kernel)
-//   rows stream    : gather the windows of chunk k+1 out of its bands into patches[(k+1)&1] | D2H rows of chunk k-1
-//   compute stream :              extract(chunk k) from patches[k&1] -> rows[k&1]
+//   rows stream    : gather the windows of chunk k+1 out of its bands into patches[(k+1)%3]
+//   compute streams: extract(chunk k) from patches[k%3] -> rows[k%3], chunks alternating between TWO streams: the first kernels of
+//                    chunk k+1 fill the CUs that the last workgroups of chunk k's kernels leave idle (every launch of a chunk ends
+//                    in such a tail; with one stream they add up to a fifth of a 200 k-nucleus chunk's time)
+//   d2h stream     : rows of chunk k-1 to the host
 //
 // Results are bit-identical to nfx_extract_tile on the resident image: the same gather kernel fills the same packed patches, the
 // same extraction runs on the same batches.
@@ -125,10 +128,21 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); hi = 0; }
         NFX_HIP(ctx, hipStreamCreateWithPriority(&ctx->rows_stream, hipStreamNonBlocking, hi));
     }
-    for (int b = 0; b < 2; ++b)
+    // the rows leave on a stream of their own, so that they wait for nothing but their chunk's extraction.  (The runtime carries THIS
+    // direction with a copy kernel of its own -- one 512-thread workgroup per CU -- while the bands arrive through the DMA engine: measured,
+    // profiles/r03_stream_d2h.txt; forcing the rows onto the engine as well queues them behind the bands and stalls the extraction.)
+    if (!ctx->d2h_stream) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); hi = 0; }
+        NFX_HIP(ctx, hipStreamCreateWithPriority(&ctx->d2h_stream, hipStreamNonBlocking, hi));
+    }
+    for (int b = 0; b < 3; ++b)
         for (hipEvent_t *e : {&ctx->ev_ready[b], &ctx->ev_done[b], &ctx->ev_rows[b], &ctx->ev_bands[b]})
             if (!*e) NFX_HIP(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
-    hipStream_t const compute = ctx->stream, copy = ctx->copy_stream, rows_s = ctx->rows_stream;
+    if (!ctx->alt_stream) NFX_HIP(ctx, hipStreamCreateWithFlags(&ctx->alt_stream, hipStreamNonBlocking));
+    hipStream_t const compute = ctx->stream, copy = ctx->copy_stream, rows_s = ctx->rows_stream, d2h = ctx->d2h_stream;
+    hipStream_t const cs[2] = {compute, ctx->alt_stream};
+    constexpr int NB = 3; // buffer sets (patches, rows, selection lists): one being filled, two being extracted
     const bool slide = ctx->addressing == NFX_ADDR_SLIDE;
 
     // ---- geometry of the plan: "block" b is the band of rows [b B, b B + B + ps) (clipped to the image), all W columns -----------
@@ -158,24 +172,25 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     }
     const size_t scratch = extract_ws_bytes(sets, n_sets, chunk_cap, (int64_t)max_chunk_nv, ps, batch_size, false, false);
     size_t need = al(4 * ((size_t)n + 1)) + al(8 * (size_t)nv + 8) + al(8 * (size_t)n + 8) + (size_t)n_slots * slot_bytes +
-                  2 * al((size_t)chunk_cap * P3) + 2 * al(4 * (size_t)chunk_cap * F + 8) + 2 * al(4 * (size_t)chunk_cap + 8) +
-                  2 * al(4 * ((size_t)chunk_cap + 1)) + al(scratch) + 8192;
+                  NB * al((size_t)chunk_cap * P3) + NB * al(4 * (size_t)chunk_cap * F + 8) + NB * al(4 * (size_t)chunk_cap + 8) +
+                  NB * al(4 * ((size_t)chunk_cap + 1)) + 2 * al(scratch) + 8192;
     if ((st = ws_reserve(ctx, need, NFX_MEM_HOST)) != NFX_OK) return st;
     uint32_t *d_off_all = (uint32_t *)ws_alloc(ctx, 4 * ((size_t)n + 1));
     float *d_xy = (float *)ws_alloc(ctx, 8 * (size_t)nv + 8);
     float *d_cen = (float *)ws_alloc(ctx, 8 * (size_t)n + 8);
     uint8_t *d_slots = (uint8_t *)ws_alloc(ctx, (size_t)n_slots * slot_bytes);
-    uint8_t *d_patches[2]; float *d_rows[2]; uint32_t *d_sel[2], *d_off[2];
-    for (int b = 0; b < 2; ++b) {
+    uint8_t *d_patches[NB]; float *d_rows[NB]; uint32_t *d_sel[NB], *d_off[NB];
+    for (int b = 0; b < NB; ++b) {
         d_patches[b] = (uint8_t *)ws_alloc(ctx, (size_t)chunk_cap * P3);
         d_rows[b] = (float *)ws_alloc(ctx, 4 * (size_t)chunk_cap * F + 8);
         d_sel[b] = (uint32_t *)ws_alloc(ctx, 4 * (size_t)chunk_cap + 8);
         d_off[b] = (uint32_t *)ws_alloc(ctx, 4 * ((size_t)chunk_cap + 1));
     }
-    if (!d_off_all || !d_xy || !d_cen || !d_slots || !d_patches[1] || !d_rows[1] || !d_sel[1] || !d_off[1])
+    if (!d_off_all || !d_xy || !d_cen || !d_slots || !d_patches[NB - 1] || !d_rows[NB - 1] || !d_sel[NB - 1] || !d_off[NB - 1])
         return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
-    const size_t ws_mark = ctx->ws->off; // every chunk's extraction bump-allocates its scratch from here
-    if (ctx->ws->cap - ws_mark < scratch) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    // a chunk's extraction bump-allocates its scratch from one of two marks: two extractions are in flight, on two streams
+    const size_t ws_mark[2] = {ctx->ws->off, ctx->ws->off + al(scratch)};
+    if (ctx->ws->cap - ws_mark[0] < 2 * al(scratch)) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
     if ((st = prepare_sets(ctx, sets, n_sets)) != NFX_OK) return st;
     NFX_HIP(ctx, hipMemcpyAsync(d_off_all, ring_offsets, 4 * ((size_t)n + 1), hipMemcpyHostToDevice, compute));
     if (nv) NFX_HIP(ctx, hipMemcpyAsync(d_xy, ring_xy, 8 * (size_t)nv, hipMemcpyHostToDevice, compute));
@@ -235,17 +250,17 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         }
         return true;
     };
-    Chunk plans[2]; // chunk k lives in plans[k & 1] from its planning to the enqueue of its extraction
+    Chunk plans[2]; // chunk k lives in plans[k & 1] from its planning to the enqueue of its copies
 
     // ---- pinned staging: selection lists and rebased offsets of two chunks -------------------------------------------------------
     const bool img_pinned = is_pinned(image_u8); // (a pageable image is copied by the runtime through its own staging: correct, not overlapped)
-    const size_t stage_bytes = 2 * (4 * (size_t)chunk_cap + 4 * ((size_t)chunk_cap + 1) + 128) + 512;
+    const size_t stage_bytes = NB * (4 * (size_t)chunk_cap + 4 * ((size_t)chunk_cap + 1) + 128) + 512;
     uint8_t *pin = (uint8_t *)Pinned::get(ctx, stage_bytes);
     if (!pin) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "pinned staging");
-    uint32_t *h_sel[2], *h_off[2];
+    uint32_t *h_sel[NB], *h_off[NB];
     {
         uint8_t *q = pin;
-        for (int b = 0; b < 2; ++b) { h_sel[b] = (uint32_t *)q; q += 4 * (size_t)chunk_cap + 32; h_off[b] = (uint32_t *)q; q += 4 * ((size_t)chunk_cap + 1) + 32; }
+        for (int b = 0; b < NB; ++b) { h_sel[b] = (uint32_t *)q; q += 4 * (size_t)chunk_cap + 32; h_off[b] = (uint32_t *)q; q += 4 * ((size_t)chunk_cap + 1) + 32; }
     }
 
     // ---- block cache ---------------------------------------------------------------------------------------------------------
@@ -253,7 +268,8 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     int64_t img_h2d = 0, blocks_copied = 0, rows_d2h = 0;
 
     auto fail_sync = [&](nfx_status s) { // an error mid-way: nothing may still be in flight on the private streams when the call returns
-        (void)hipStreamSynchronize(copy); (void)hipStreamSynchronize(compute); (void)hipStreamSynchronize(rows_s);
+        (void)hipStreamSynchronize(copy); (void)hipStreamSynchronize(cs[0]); (void)hipStreamSynchronize(cs[1]); (void)hipStreamSynchronize(rows_s); (void)hipStreamSynchronize(d2h);
+        ctx->stream = compute;
         return s;
     };
 #define NFX_HIP_S(expr)                                                                                                                  \
@@ -267,9 +283,9 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     // gathers of its windows behind them on the rows stream (which also carries the rows home)
     auto enqueue_copy = [&](int64_t k) -> nfx_status {
         const Chunk &c = plans[k & 1];
-        const int b = (int)(k & 1);
+        const int b = (int)(k % NB);
         const int64_t m = c.i1 - c.i0;
-        if (k >= 2) NFX_HIP_S(hipEventSynchronize(ctx->ev_done[b])); // extract(k-2) has finished: patches[b], sel[b], off[b] and their staging are free
+        if (k >= NB) NFX_HIP_S(hipEventSynchronize(ctx->ev_done[b])); // extract(k-3) has finished: patches[b], sel[b], off[b] and their staging are free
         memcpy(h_sel[b], c.sel.data(), 4 * (size_t)m);
         const uint32_t v0 = ring_offsets[c.i0];
         for (int64_t j = 0; j <= m; ++j) h_off[b][j] = ring_offsets[c.i0 + j] - v0;
@@ -291,7 +307,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
                     block_slot[slot_block[s]] = -1;
                     // an evicted band may still be read by the gathers of an earlier chunk (they run on the other stream, in order):
                     // the overwriting copy waits for the latest of them
-                    if (!evicted_waited && k >= 1) { NFX_HIP_S(hipStreamWaitEvent(copy, ctx->ev_ready[(k - 1) & 1], 0)); evicted_waited = true; }
+                    if (!evicted_waited && k >= 1) { NFX_HIP_S(hipStreamWaitEvent(copy, ctx->ev_ready[(k - 1) % NB], 0)); evicted_waited = true; }
                 }
                 slot_block[s] = bid; block_slot[bid] = s; slot_use[s] = k;
                 uint8_t *dst = d_slots + (size_t)s * slot_bytes;
@@ -317,11 +333,9 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         return NFX_OK;
     };
 
-    // Order of the host's work per chunk k: plan chunk k+1 (host only: the device is still busy with chunk k-1), send its bands
-    // on their way (waits for extract(k-1): its buffers are then free -- and the device is idle at that moment, so the copies and
-    // gathers start at once), THEN enqueue extract(k), which runs beside them.  (Enqueueing extract(k) first was measured: the
-    // copies then queue up behind the extraction's chip-filling kernels and nothing overlaps: 151 ms instead of 116 for 500 k
-    // nuclei at 64 x 64, all sets.)
+    // Order of the host's work per chunk k: enqueue extract(k) -- its windows were gathered while chunk k-1 ran --, THEN plan chunk
+    // k+1 and send its bands on their way (the host first waits for extract(k-2), whose buffers chunk k+1 takes over: two
+    // extractions are queued on the device at that moment, so it never runs dry while the host sleeps), and the rows of chunk k home.
     int64_t nchunks = 0;
     bool have = plan_next < n, have_next = false;
     if (have) {
@@ -329,30 +343,35 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         if ((st = enqueue_copy(0)) != NFX_OK) return st;
     }
     for (int64_t k = 0; have; ++k, have = have_next) {
-        const int b = (int)(k & 1);
-        const int64_t i0 = plans[b].i0, i1 = plans[b].i1, m = i1 - i0;
+        const int b = (int)(k % NB);
+        hipStream_t const cstream = cs[k & 1];
+        const int64_t i0 = plans[k & 1].i0, i1 = plans[k & 1].i1, m = i1 - i0;
         ++nchunks;
-        have_next = plan_next < n;
-        if (have_next) {
-            if (!plan(plans[b ^ 1])) return fail_sync(api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "one reference batch touches more bands than the band cache holds: raise cache_bytes"));
-            if ((st = enqueue_copy(k + 1)) != NFX_OK) return st;
-        }
-        NFX_HIP_S(hipStreamWaitEvent(compute, ctx->ev_ready[b], 0));
-        if (k >= 2) NFX_HIP_S(hipStreamWaitEvent(compute, ctx->ev_rows[b], 0)); // rows[b] of chunk k-2 have left for the host
-        ctx->ws->off = ws_mark;
+        NFX_HIP_S(hipStreamWaitEvent(cstream, ctx->ev_ready[b], 0));
+        if (k >= NB) NFX_HIP_S(hipStreamWaitEvent(cstream, ctx->ev_rows[b], 0)); // rows[b] of chunk k-3 have left for the host
+        ctx->ws->off = ws_mark[k & 1];
+        ctx->stream = cstream;
         const uint32_t v0 = ring_offsets[i0], v1 = ring_offsets[i1];
         st = extract_device(ctx, sets, n_sets, m, (int64_t)(v1 - v0), d_off[b], d_xy + 2 * (size_t)v0, d_patches[b], nullptr, 0, 0, ps, batch_size, d_rows[b], nullptr);
+        ctx->stream = compute;
         if (st != NFX_OK) return fail_sync(st);
-        NFX_HIP_S(hipEventRecord(ctx->ev_done[b], compute));
-        NFX_HIP_S(hipStreamWaitEvent(rows_s, ctx->ev_done[b], 0));
-        NFX_HIP_S(hipMemcpyAsync(out_rows + (size_t)i0 * F, d_rows[b], 4 * (size_t)m * F, hipMemcpyDeviceToHost, rows_s));
-        NFX_HIP_S(hipEventRecord(ctx->ev_rows[b], rows_s));
+        NFX_HIP_S(hipEventRecord(ctx->ev_done[b], cstream));
+        NFX_HIP_S(hipStreamWaitEvent(d2h, ctx->ev_done[b], 0));
+        NFX_HIP_S(hipMemcpyAsync(out_rows + (size_t)i0 * F, d_rows[b], 4 * (size_t)m * F, hipMemcpyDeviceToHost, d2h));
+        NFX_HIP_S(hipEventRecord(ctx->ev_rows[b], d2h));
         rows_d2h += 4 * m * F;
+        have_next = plan_next < n;
+        if (have_next) {
+            if (!plan(plans[(k + 1) & 1])) return fail_sync(api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "one reference batch touches more bands than the band cache holds: raise cache_bytes"));
+            if ((st = enqueue_copy(k + 1)) != NFX_OK) return st;
+        }
     }
 #undef NFX_HIP_S
     NFX_HIP(ctx, hipStreamSynchronize(copy));
-    NFX_HIP(ctx, hipStreamSynchronize(compute));
+    NFX_HIP(ctx, hipStreamSynchronize(cs[0]));
+    NFX_HIP(ctx, hipStreamSynchronize(cs[1]));
     NFX_HIP(ctx, hipStreamSynchronize(rows_s));
+    NFX_HIP(ctx, hipStreamSynchronize(d2h));
     if (stats) {
         stats->image_bytes_h2d = img_h2d; stats->other_bytes_h2d = other_h2d; stats->rows_bytes_d2h = rows_d2h + 8 * n;
         stats->blocks_copied = blocks_copied; stats->blocks_total = nblocks; stats->chunks = nchunks; stats->block_slots = n_slots;
