@@ -208,10 +208,11 @@ nfx_status nfx_extract_tile(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n
    of the context's own.  image_u8 [3][H][W] is cut into horizontal bands of `block` rows (0 = 2048; at least 64) over the full
    width, each with a patch-size halo below -- a band's rows are contiguous in the planar image, so it travels as three large
    contiguous copies; nuclei are processed in index order in chunks of whole reference batches (`chunk_nuclei`, 0 = 100 000,
-   rounded down to a multiple of batch_size): while chunk k is extracted, the bands chunk k+1 touches travel to the device (only
+   rounded down to a multiple of batch_size; the workspace holds three chunks' patches and rows): while chunks k-1 and k are
+   extracted (two at a time, on two streams: one's first kernels fill the other's tails), the bands chunk k+1 touches travel to the device (only
    those not resident: the device keeps `cache_bytes` of bands, 0 = the whole slide if 60 % of the free device memory holds it,
    least recently used out first) and its nuclei's windows are gathered from them by load_image_dataset's rules (utils.rs:159-191;
-   NFX_ADDR_SLIDE: utils.rs:97-122), and the rows of chunk k-1 travel back.  Rows are bit-identical to nfx_extract_tile on the
+   NFX_ADDR_SLIDE: utils.rs:97-122), and the rows of chunk k-2 travel back.  Rows are bit-identical to nfx_extract_tile on the
    resident image, whatever the order of the nuclei (slide order -- what segmentation tools emit -- makes a chunk touch one or
    two bands; any other order only costs copies; a single batch that touches more bands than the cache holds fails with
    NFX_ERR_OUT_OF_MEMORY).  For the link's full rate and for copies that overlap compute, image_u8 and out_rows should be pinned
