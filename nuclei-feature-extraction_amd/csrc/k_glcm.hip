@@ -422,8 +422,11 @@ static __device__ void glcm_features(const double (&a)[GL_NACC], double base, co
 //       textures a third to a half of the pairs open a new cell -- which is one more wave per CU in every class; a nucleus whose
 //       cells do not fit (white noise) is abandoned at the end of the pass that filled the table and handed to the next class,
 //       whose table holds a cell for every pair it can have (3/4 of a capacity at least 4/3 as large).
+// Occupancy asked of the compiler: three waves per SIMD (168 registers) wherever the class's LDS lets a CU hold more than eight waves.  At
+// 64 x 64 (twelve prefetch registers of four words) that costs 8 spilled registers in the small classes and buys a ninth and tenth wave
+// per CU: 31.34 -> 30.87 ms per 600 k nuclei (round 3; rounds 1-2 kept those classes at two waves per SIMD, 189 registers).
 template <typename T, int QCAP, int NPRE, bool FULL>
-__global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3 : (QCAP <= 2048 ? 2 : 1))) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int *__restrict__ cursor,
+__global__ __launch_bounds__(64, (QCAP <= (FULL ? 768 : 1024) ? 3 : (QCAP <= 2048 ? 2 : 1))) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int *__restrict__ cursor,
                                              int *__restrict__ next_list, int *__restrict__ next_count, int *__restrict__ top_list, int *__restrict__ top_count, int ps,
                                              const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
                                              const GlcmLuts *__restrict__ lut, double *__restrict__ slots, float *__restrict__ out, int F,
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(64, ((QCAP <= (FULL ? 768 : 1024) && NPRE <= 7) ? 3
     const int n16 = (3 * P) / 16;
     static_assert(sizeof(T) != 1 || (int)sizeof(s_mem) >= NPRE * 1024, "the staging area holds all NPRE KiB the prefetch registers put down");
     const bool stage = sizeof(T) == 1 && ((3 * P) & 15) == 0 && 3 * P <= (int)sizeof(s_mem) && 3 * P <= NPRE * 1024 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0;
-    u32x4 pre[NPRE]; // a native vector type: HIP's uint4 struct is copied with memcpy, which keeps the array in scratch memory
+    u32x4 pre[NPRE > 0 ? NPRE : 1]; // a native vector type: HIP's uint4 struct is copied with memcpy, which keeps the array in scratch memory
     uint64_t row_next;
     int i_next = list[j];
 #define NFX_GLCM_REQUEST(I)                                                                                       \
@@ -1018,6 +1021,12 @@ static void launch_class(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, doub
                        reinterpret_cast<const T *>(job.patches), job.mask_rows, lut, slots, job.out, job.F, col0, job.dbg_glcm);
 }
 
+// At 64 x 64 the two smallest classes read their (at most 768) mask pixels where they lie instead of staging the 12 KB patch through LDS: the
+// staging area no longer sets those classes' LDS size, there are no prefetch registers, and a CU holds twelve waves instead of ten
+// (30.90 -> 30.51 ms per 600 k nuclei; a third unstaged class changes nothing).  Same arithmetic on the same bytes: identical rows.
+#ifndef NFX_GL_NOSTAGE_CLS
+#define NFX_GL_NOSTAGE_CLS 2
+#endif
 template <typename T, int NPRE>
 static void launch_classes(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *slots, const int *lists, const int *counts, int col0, int only)
 {
@@ -1026,7 +1035,7 @@ static void launch_classes(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, do
 #define NFX_GL_CLASS(CLS, QCAP)                                                                                         \
     if (run(CLS)) {                                                                                                     \
         if (CLS == top) launch_class<T, QCAP, NPRE, true>(ctx, job, lut, slots, lists, counts, CLS, top, col0);         \
-        else launch_class<T, QCAP, NPRE, false>(ctx, job, lut, slots, lists, counts, CLS, top, col0);                   \
+        else launch_class<T, QCAP, (NPRE == 12 && CLS < NFX_GL_NOSTAGE_CLS) ? 0 : NPRE, false>(ctx, job, lut, slots, lists, counts, CLS, top, col0); \
     }
     NFX_GL_CLASS(0, 512)
     NFX_GL_CLASS(1, 768)
