@@ -77,6 +77,52 @@ def test_counts_of_extreme_textures(ctx, ps):
     assert int(got[1][0, 0].sum()) == ps and int(got[1][0, 0, :, 15].sum()) == ps
 
 
+@pytest.mark.parametrize("ps", [64, 63, 48, 33, 17])
+def test_counts_of_blocky_images_under_ragged_masks(ctx, ps):
+    """Run structure in every direction: images of a few gray levels in blocks of 1..7 pixels (runs of every length from 1 up to
+    the clip at 16, along rows, columns and both diagonals, across the word halves and -- at 64 -- round the wrap of the diagonal
+    lines), under masks with many boundaries: stars, combs, and the full patch.  Every GLRLM bin and GLCM integer `==` the oracle's."""
+    rng = np.random.default_rng(1000 + ps)
+    c = ps / 2.0
+    rings, patches = [], []
+    def star(k, r0, r1, phase):
+        a = np.arange(2 * k) * np.pi / k + phase
+        r = np.where(np.arange(2 * k) % 2 == 0, r1, r0)
+        return np.stack([c + r * np.cos(a), c + r * np.sin(a)], 1)
+    def comb(teeth):
+        pts = [(1.0, 1.0)]
+        w = (ps - 2.0) / (2 * teeth)
+        for t in range(teeth):
+            x0 = 1.0 + 2 * t * w
+            pts += [(x0, ps - 1.5), (x0 + w, ps - 1.5), (x0 + w, 4.0), (x0 + 2 * w, 4.0)]
+        pts += [(ps - 1.0, 1.0)]
+        return np.array(pts)
+    shapes = [star(5, 0.18 * ps, 0.49 * ps, 0.3), star(9, 0.3 * ps, 0.5 * ps, 1.1), comb(3), comb(max(2, ps // 8)),
+              np.array([[-ps, -ps], [2 * ps, -ps], [2 * ps, 2 * ps], [-ps, 2 * ps]], float)]
+    for shape in shapes:
+        for block in (1, 2, 3, 5, 7):
+            levels = rng.integers(0, 4, size=((ps + block - 1) // block + 1, (ps + block - 1) // block + 1))
+            oy, ox = rng.integers(0, block, 2)
+            img = np.kron(levels, np.ones((block, block), int))[oy:oy + ps, ox:ox + ps]
+            gray = (img * 60 + 20).astype(np.uint8)         # four levels far apart on every quantisation scale
+            if block == 3:                                  # ... and one diagonal-striped variant: runs along the diagonals only
+                yy, xx = np.mgrid[0:ps, 0:ps]
+                gray = ((((yy + xx) // 2) % 3) * 80 + 10).astype(np.uint8)
+            if block == 5:
+                yy, xx = np.mgrid[0:ps, 0:ps]
+                gray = ((((yy - xx) // 3) % 3) * 80 + 10).astype(np.uint8)
+            rings.append(np.concatenate([shape, shape[:1]]).astype(np.float32))
+            patches.append(np.repeat(gray[None], 3, 0))
+    off = np.zeros(len(rings) + 1, np.uint32)
+    np.cumsum([len(r) for r in rings], out=off[1:])
+    xy = np.concatenate(rings).astype(np.float32)
+    pu8 = np.stack(patches)
+    got = ctx.debug_texture_counts(off, xy, pu8, ps)
+    want = orc.texture_counts(off, xy, pu8, ps)
+    _assert_counts_equal(got, want, f"blocky images ps {ps}")
+    assert int(want[1].sum()) > 0 and int(want[1][:, :, :, 15].sum()) > 0 and int(want[1][:, 1].sum()) > 0  # clipped runs and diagonal runs are there
+
+
 def test_count_outputs_are_optional(ctx):
     off, xy, pu8 = par.make_inputs(2, 8, 48)
     g, r = ctx.debug_texture_counts(off, xy, pu8, 48, glrlm=False)
