@@ -313,7 +313,6 @@ void nfx_ctx_destroy(nfx_ctx *ctx)
         for (hipEvent_t e : {ctx->ev_ready[b], ctx->ev_done[b], ctx->ev_rows[b], ctx->ev_bands[b]})
             if (e) (void)hipEventDestroy(e);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
-    if (ctx->ev_mid) (void)hipEventDestroy(ctx->ev_mid);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (auto &t : ctx->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
@@ -502,16 +501,6 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
         }
     }
     NFX_HIP(ctx, launch_raster_shape(ctx, n, ring_off, centred, ps, rows, geo_col >= 0 ? out_rows : nullptr, F, geo_col >= 0 ? geo_col : 0, areas));
-    // EXPERIMENT ("Gabor beside GLCM"): NFX_EXP_GABOR_SIDE=1 puts k_gabor on the side stream, behind the polygon kernel
-    // and the mask rows, so that it runs beside the colour / GLCM / GLRLM kernels of the main stream.  Off in the product.
-    static const bool exp_gabor_side = getenv("NFX_EXP_GABOR_SIDE") != nullptr;
-    const bool gabor_side = exp_gabor_side && forked && count_set(sets, n_sets, NFX_SET_GABOR) && count_set(sets, n_sets, NFX_SET_GLCM);
-    if (gabor_side) {
-        if (!ctx->ev_mid) NFX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_mid, hipEventDisableTiming));
-        NFX_HIP(ctx, hipEventRecord(ctx->ev_mid, main_stream));
-        NFX_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_mid, 0));
-    }
-
     Job job;
     job.n = n; job.ps = ps; job.batch_size = batch_size; job.poly_off = ring_off; job.poly_xy = centred;
     job.patches = patches_u8; job.patches_f32 = false; job.mask_rows = rows; job.areas = areas; job.out = out_rows; job.F = F;
@@ -550,10 +539,7 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
         case NFX_SET_GABOR: {
             if (!gabor_scr) gabor_scr = ws_alloc(ctx, gabor_scratch_bytes(job)); // (a repeated "gabor" runs after the first on the same stream: shared)
             if (!gabor_scr && gabor_scratch_bytes(job)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
-            if (gabor_side) ctx->stream = ctx->side_stream;
-            const hipError_t ge = launch_gabor(ctx, job, col, gabor_scr);
-            ctx->stream = main_stream;
-            NFX_HIP(ctx, ge);
+            NFX_HIP(ctx, launch_gabor(ctx, job, col, gabor_scr));
             break;
         }
         }

@@ -50,7 +50,6 @@ struct nfx_ctx {
                                       // different host threads overlap on the GPU instead of queueing on the default stream
     hipStream_t side_stream = nullptr; // the polygon kernel (64 serial programs per wave: latency-bound, hardly any issue slots) runs
     hipEvent_t ev_fork = nullptr, ev_join = nullptr; // here, beside the rasteriser and the pixel kernels of the same call
-    hipEvent_t ev_mid = nullptr;                     // (experiment knob NFX_EXP_GABOR_SIDE: mask rows ready)
     // nfx_extract_tile_streamed (nfx_stream.cpp): block copies + window gathers | rows back to the host, created on first use
     hipStream_t copy_stream = nullptr, rows_stream = nullptr, d2h_stream = nullptr, alt_stream = nullptr;
     hipEvent_t ev_ready[3] = {}, ev_done[3] = {}, ev_rows[3] = {}, ev_bands[3] = {};
