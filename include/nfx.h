@@ -256,7 +256,8 @@ nfx_status nfx_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids_xy
    exchanged during extraction.  nfx_gather_rows then moves every shard's [count, F] f32 rows once, device to device, to the
    root: grouped ncclSend / ncclRecv (ragged shards need no padding), enqueued on the context's stream -- stream-ordered like
    every NFX_MEM_DEVICE call, no host synchronisation.  No PyTorch / libtorch is involved: librccl is opened (dlopen) at the first
-   nfx_comm_* call; a process that never calls them never loads it.  Returns NFX_ERR_UNSUPPORTED if librccl is not there.
+   nfx_comm_* call; a process that never calls them never loads it.  Returns NFX_ERR_UNSUPPORTED if librccl is not there (the
+   environment variable NFX_RCCL_PATH, when set, names the ONE library file that is tried instead of the usual sonames).
 
      nfx_comm_unique_id   one rank (by convention rank 0) makes the 128-byte id; the host distributes it out of band (file, socket,
                           environment -- ncclGetUniqueId semantics) and every rank passes the same bytes to nfx_comm_create

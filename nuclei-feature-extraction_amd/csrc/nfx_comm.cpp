@@ -43,13 +43,18 @@ std::once_flag g_rccl_once;
 
 void load_rccl()
 {
-    const char *names[4] = {getenv("NFX_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *nm : names) {
-        if (!nm || !*nm) continue;
+    // NFX_RCCL_PATH, when set, is the ONLY library tried (an explicit choice is not second-guessed); otherwise the usual names.
+    const char *forced = getenv("NFX_RCCL_PATH");
+    const char *defaults[3] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::string last;
+    auto try_open = [&](const char *nm) {
         g_rccl.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
-        if (g_rccl.handle) break;
-    }
-    if (!g_rccl.handle) { g_rccl.why = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "not found"); return; }
+        if (!g_rccl.handle) { const char *e = dlerror(); last = e ? e : "not found"; } // dlerror() clears itself: read ONCE
+        return g_rccl.handle != nullptr;
+    };
+    if (forced && *forced) try_open(forced);
+    else for (const char *nm : defaults) if (try_open(nm)) break;
+    if (!g_rccl.handle) { g_rccl.why = std::string("librccl could not be loaded: ") + (last.empty() ? "not found" : last); return; }
     auto sym = [&](const char *s) { void *p = dlsym(g_rccl.handle, s); if (!p && g_rccl.why.empty()) g_rccl.why = std::string("librccl lacks ") + s; return p; };
     g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(sym("ncclGetUniqueId"));
     g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(sym("ncclCommInitRank"));

@@ -82,3 +82,22 @@ def test_column_dtypes_follow_the_reference_frame(nfx):
     for s in range(1, 5):
         assert set(nfx.column_dtypes(s)) == {"f32"}
     assert nfx.lib().nfx_feature_set_column_dtype(0, 12) == -1 and nfx.lib().nfx_feature_set_column_dtype(5, 0) == -1
+
+
+def test_a_host_without_rccl_gets_unsupported_not_a_crash():
+    """include/nfx.h: nfx_comm_* return NFX_ERR_UNSUPPORTED when librccl cannot be loaded.  NFX_RCCL_PATH names the one file that
+    is tried; a fresh process (the loader runs once per process) pointed at a file that does not exist must come back with
+    status 2 -- the first build of this path built its message from two dlerror() calls, the second of which returns NULL."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        f"L = C.CDLL({os.path.join(ROOT, 'nuclei-feature-extraction_amd', 'libnfx.so')!r})\n"
+        "buf = C.create_string_buffer(128)\n"
+        "st = [L.nfx_comm_unique_id(buf) for _ in range(2)]\n"   # the second call takes the cached failure
+        "print('status', st)\n"
+    )
+    env = dict(os.environ, NFX_RCCL_PATH="/nonexistent/librccl-not-here.so")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr[-400:])
+    assert "status [2, 2]" in r.stdout, r.stdout
