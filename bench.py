@@ -121,7 +121,7 @@ def parse_args():
     ap.add_argument("--transport", default="torch", choices=["torch", "nfx"],
                     help="N>1: what carries the rows to rank 0 -- torch.distributed.gather (c10d over RCCL; default) or the engine's own "
                          "nfx_gather_rows (include/nfx.h: grouped ncclSend / ncclRecv below any framework; torch.distributed only hands out the "
-                         "communicator id)")
+                         "communicator id; has only ever run with one rank -- tests/test_comm_gpu.py needs two GPUs for more -- so unverified for N>1)")
     ap.add_argument("--ipc-legacy", default="env", choices=["env", "0", "1"],
                     help="N>1: HSA_ENABLE_IPC_MODE_LEGACY for the ranks (RCCL peer access across processes).  env (default) = whatever the "
                          "environment holds, 0 if it holds nothing (dmabuf IPC: what this pool's host driver supports); recorded in the line")

@@ -210,12 +210,14 @@ nfx_status nfx_extract_tile(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n
    contiguous copies; nuclei are processed in index order in chunks of whole reference batches (`chunk_nuclei`, 0 = 100 000,
    rounded down to a multiple of batch_size; the workspace holds three chunks' patches and rows): while chunks k-1 and k are
    extracted (two at a time, on two streams: one's first kernels fill the other's tails), the bands chunk k+1 touches travel to the device (only
-   those not resident: the device keeps `cache_bytes` of bands, 0 = the whole slide if 60 % of the free device memory holds it,
+   those not resident: the device keeps `cache_bytes` of bands, 0 = the whole slide if 60 % of the free device memory (this
+   context's own reusable staging arena counted as free) holds it,
    least recently used out first) and its nuclei's windows are gathered from them by load_image_dataset's rules (utils.rs:159-191;
    NFX_ADDR_SLIDE: utils.rs:97-122), and the rows of chunk k-2 travel back.  Rows are bit-identical to nfx_extract_tile on the
    resident image, whatever the order of the nuclei (slide order -- what segmentation tools emit -- makes a chunk touch one or
-   two bands; any other order only costs copies; a single batch that touches more bands than the cache holds fails with
-   NFX_ERR_OUT_OF_MEMORY).  For the link's full rate and for copies that overlap compute, image_u8 and out_rows should be pinned
+   two bands; any other order only costs copies).  `cache_bytes` is honoured down to ONE band (a smaller value keeps one): a batch
+   whose windows start in more bands than the cache holds is gathered in several passes over its bands -- the gather needs one band
+   at a time, only the extraction needs all of a batch's patches -- so no cache size makes a call fail, a small one only re-copies.  For the link's full rate and for copies that overlap compute, image_u8 and out_rows should be pinned
    for THIS library's HIP runtime (nfx_host_alloc, or nfx_host_register on memory of the caller's own; memory pinned by another
    runtime in the process, e.g. PyTorch's, counts as pageable and is staged by the runtime).
    stats (may be NULL): what travelled ("blocks" = bands). */
@@ -225,6 +227,7 @@ typedef struct {
     int64_t rows_bytes_d2h;   /* feature rows + centroids */
     int64_t blocks_copied, blocks_total, block_slots, chunks;
     int64_t image_pinned;     /* 1: the image is pinned for this runtime (asynchronous copies); 0: pageable */
+    int64_t split_gather_passes; /* band passes made by chunks whose bands did not fit the cache at once (0: one pass per chunk) */
 } nfx_stream_stats;
 nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t n_vertices,
                                      const uint32_t *ring_offsets, const float *ring_xy, const uint8_t *image_u8, int64_t H, int64_t W,

@@ -401,10 +401,11 @@ class Context:
             out = np.empty((n, F), np.float32)
         assert out.shape == (n, F) and out.dtype == np.float32 and out.flags.c_contiguous
         cen = np.empty((n, 2), np.float32)
-        st = (C.c_int64 * 8)()
+        st = (C.c_int64 * 9)()
         self._check(lib().nfx_extract_tile_streamed(self._h, sets_arr, len(sets), n, nv, _ptr(off), _ptr(xy), _ptr(image_u8), int(image_u8.shape[1]),
                                                     int(image_u8.shape[2]), ps, batch_size, block, chunk_nuclei, cache_bytes, _ptr(out), _ptr(cen), st))
-        names = ("image_bytes_h2d", "other_bytes_h2d", "rows_bytes_d2h", "blocks_copied", "blocks_total", "block_slots", "chunks", "image_pinned")
+        names = ("image_bytes_h2d", "other_bytes_h2d", "rows_bytes_d2h", "blocks_copied", "blocks_total", "block_slots", "chunks", "image_pinned",
+                 "split_gather_passes")
         return out, cen, {k: int(st[j]) for j, k in enumerate(names)}
 
     def gather_patches(self, centroids, image_u8, ps: int):

@@ -40,6 +40,7 @@
 // The ten sums of every (level, offset) combination are parked in a 1280-byte slot the wave owns in global memory (one
 // slot per resident wave: 14 MB in all, rewritten for every nucleus, so it lives in the XCD's L2 and never travels to
 // HBM); after the fourth offset sixteen lanes read them back and evaluate the 14 features of their combination.
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -1001,11 +1002,15 @@ hipError_t prepare_glcm(nfx_ctx *ctx)
 template <typename T, int QCAP, int NPRE, bool FULL>
 static void launch_class(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *slots, const int *lists, const int *counts, int cls, int top, int col0)
 {
-    static int wgs_per_cu = 0; // same answer for every context: one device type per process
+    // same answer for every context (one device type per process); contexts are driven from concurrent host threads, so the cached
+    // answer is an atomic: two threads may both ask the runtime the first time, they store the same value
+    static std::atomic<int> wgs_cached{0};
+    int wgs_per_cu = wgs_cached.load(std::memory_order_relaxed);
     if (wgs_per_cu == 0) {
         int b = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_glcm<T, QCAP, NPRE, FULL>, 64, 0) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 1; }
         wgs_per_cu = b > 12 ? 12 : b;
+        wgs_cached.store(wgs_per_cu, std::memory_order_relaxed);
     }
     const int64_t m = 256ll * wgs_per_cu * NFX_GL_ROUNDS;
     static_assert(256 * 12 * NFX_GL_ROUNDS <= GL_MAX_GRID, "every launch's waves have a parking slot");

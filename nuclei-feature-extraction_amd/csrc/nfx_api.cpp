@@ -312,6 +312,7 @@ void nfx_ctx_destroy(nfx_ctx *ctx)
     for (int b = 0; b < 3; ++b)
         for (hipEvent_t e : {ctx->ev_ready[b], ctx->ev_done[b], ctx->ev_rows[b], ctx->ev_bands[b]})
             if (e) (void)hipEventDestroy(e);
+    if (ctx->ev_pass) (void)hipEventDestroy(ctx->ev_pass);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);

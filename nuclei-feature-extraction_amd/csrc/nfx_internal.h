@@ -52,7 +52,7 @@ struct nfx_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr; // here, beside the rasteriser and the pixel kernels of the same call
     // nfx_extract_tile_streamed (nfx_stream.cpp): block copies + window gathers | rows back to the host, created on first use
     hipStream_t copy_stream = nullptr, rows_stream = nullptr, d2h_stream = nullptr, alt_stream = nullptr;
-    hipEvent_t ev_ready[3] = {}, ev_done[3] = {}, ev_rows[3] = {}, ev_bands[3] = {};
+    hipEvent_t ev_ready[3] = {}, ev_done[3] = {}, ev_rows[3] = {}, ev_bands[3] = {}, ev_pass = nullptr;
     void *pin = nullptr;      // grow-only pinned host staging (selection lists, rebased offsets of two chunks)
     size_t pin_cap = 0;
     nfx_addressing addressing = NFX_ADDR_IMAGE;

@@ -14,7 +14,8 @@
 // The reference's batch partition is kept (the hue mean couples the nuclei of a batch, color.rs:144-155): nuclei are processed
 // in index order in CHUNKS of whole batches; a chunk runs when every band it touches is resident.  Segmentation tools emit
 // nuclei tile by tile, so a chunk touches one or two bands; any order is correct (a band that is needed again after it was
-// evicted is copied again; the device keeps as many bands as `cache_bytes` allows -- the whole slide, typically).
+// evicted is copied again; the device keeps as many bands as `cache_bytes` allows -- the whole slide, typically -- and never fewer
+// than one: a batch that touches more bands than that is gathered in several passes over its bands).
 //
 //   copy stream    : H2D bands of chunk k+1, k+2, ... back to back (nothing but copies: the link never waits for a kernel)
 //   rows stream    : gather the windows of chunk k+1 out of its bands into patches[(k+1)%3]
@@ -139,6 +140,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     for (int b = 0; b < 3; ++b)
         for (hipEvent_t *e : {&ctx->ev_ready[b], &ctx->ev_done[b], &ctx->ev_rows[b], &ctx->ev_bands[b]})
             if (!*e) NFX_HIP(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    if (!ctx->ev_pass) NFX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pass, hipEventDisableTiming));
     if (!ctx->alt_stream) NFX_HIP(ctx, hipStreamCreateWithFlags(&ctx->alt_stream, hipStreamNonBlocking));
     hipStream_t const compute = ctx->stream, copy = ctx->copy_stream, rows_s = ctx->rows_stream, d2h = ctx->d2h_stream;
     hipStream_t const cs[2] = {compute, ctx->alt_stream};
@@ -154,14 +156,16 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     const int64_t chunk_cap = std::min<int64_t>(chunk_max, ((n + batch_size - 1) / batch_size) * batch_size);
     int64_t want_slots;
     if (cache_bytes > 0) want_slots = cache_bytes / (int64_t)slot_bytes;
-    else { // default: the whole slide if it fits beside everything else (60 % of what is free now), else what fits
+    else { // default: the whole slide if it fits beside everything else (60 % of what is free), else what fits.  The host arena this call
+           // is about to reuse (or replace) counts as free: a second call must not plan with less than the first
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)16 << 30; }
+        free_b += ctx->host_ws.cap;
         want_slots = (int64_t)((free_b / 10 * 6) / slot_bytes);
     }
-    // slide-ordered nuclei touch one or two bands per batch; whatever the order, a batch can always run with as many bands as it
-    // has nuclei (or the whole slide)
-    const int64_t n_slots = std::min<int64_t>(nblocks, std::max<int64_t>(std::max<int64_t>(want_slots, 2), std::min<int64_t>(batch_size, nblocks)));
+    // `cache_bytes` is honoured down to ONE band (a batch whose windows start in more bands than the cache holds is gathered in several
+    // passes over its bands: the gather needs one band at a time, only the extraction needs all of a batch's patches)
+    const int64_t n_slots = std::min<int64_t>(nblocks, std::max<int64_t>(want_slots, 1));
 
     // ---- stage the rings, centroids of every nucleus (k_preprocess: the arithmetic that addresses the windows) ------------------
     const size_t P3 = 3 * (size_t)ps * ps;
@@ -213,7 +217,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     std::vector<uint32_t> band_count((size_t)nblocks, 0);
     std::vector<int64_t> blk_buf((size_t)chunk_cap);
     int64_t plan_next = 0, plan_index = 0;             // first nucleus / index of the chunk the next plan() call makes
-    auto plan = [&](Chunk &c) -> bool {                // false: a single batch needs more bands than the cache holds
+    auto plan = [&](Chunk &c) {                        // a single batch that needs more bands than the cache holds is a chunk of its own
         c.i0 = plan_next; c.blocks.clear(); c.sel.clear(); c.sel_off.clear();
         const int64_t ck = plan_index++;
         int64_t i = c.i0, distinct = 0;
@@ -231,9 +235,9 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
                 if (m == -2 - ck) m = (fits || i == c.i0) ? ck : -1;
             }
             if (!fits && i > c.i0) break;      // this batch opens the next chunk
-            if (!fits) return false;           // ... a chunk of one batch that does not fit: nothing to be done
             distinct += add;
             i = e;
+            if (!fits) break;                  // ... one batch wider than the cache: gathered in several passes (enqueue_copy)
         }
         c.i1 = i;
         plan_next = i;
@@ -248,7 +252,6 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
             for (int64_t j = 0; j < m; ++j) c.sel[at[blk_buf[(size_t)j]]++] = (uint32_t)j;
             for (size_t q = 0; q < c.blocks.size(); ++q) at[c.blocks[q]] = 0;
         }
-        return true;
     };
     Chunk plans[2]; // chunk k lives in plans[k & 1] from its planning to the enqueue of its copies
 
@@ -265,7 +268,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
 
     // ---- block cache ---------------------------------------------------------------------------------------------------------
     std::vector<int64_t> slot_block((size_t)n_slots, -1), slot_use((size_t)n_slots, -1), block_slot((size_t)nblocks, -1);
-    int64_t img_h2d = 0, blocks_copied = 0, rows_d2h = 0;
+    int64_t img_h2d = 0, blocks_copied = 0, rows_d2h = 0, use_tick = 0, gather_passes = 0;
 
     auto fail_sync = [&](nfx_status s) { // an error mid-way: nothing may still be in flight on the private streams when the call returns
         (void)hipStreamSynchronize(copy); (void)hipStreamSynchronize(cs[0]); (void)hipStreamSynchronize(cs[1]); (void)hipStreamSynchronize(rows_s); (void)hipStreamSynchronize(d2h);
@@ -275,8 +278,10 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
 #define NFX_HIP_S(expr)                                                                                                                  \
     do {                                                                                                                                 \
         hipError_t e_ = (expr);                                                                                                          \
-        if (e_ != hipSuccess)                                                                                                            \
+        if (e_ != hipSuccess) {                                                                                                          \
+            (void)hipGetLastError(); /* reported here: the next call must not find it again */                                           \
             return fail_sync(api_fail(ctx, e_ == hipErrorOutOfMemory ? NFX_ERR_OUT_OF_MEMORY : NFX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_))); \
+        }                                                                                                                                \
     } while (0)
 
     // H2D of chunk k's missing bands on the copy stream -- nothing but copies there, so the link never waits for a kernel -- and the
@@ -292,42 +297,56 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         NFX_HIP_S(hipMemcpyAsync(d_sel[b], h_sel[b], 4 * (size_t)m, hipMemcpyHostToDevice, copy));
         NFX_HIP_S(hipMemcpyAsync(d_off[b], h_off[b], 4 * ((size_t)m + 1), hipMemcpyHostToDevice, copy));
         other_h2d += 8 * m + 4;
-        for (size_t q = 0; q < c.blocks.size(); ++q) if (block_slot[c.blocks[q]] >= 0) slot_use[block_slot[c.blocks[q]]] = k;
+        // The chunk's bands in PASSES of at most n_slots (one pass unless a single batch is wider than the cache): the bands of a pass
+        // that are not resident take the slots that have gone unused longest, their copies go out back to back, the windows that start
+        // in them are gathered behind the copies; a later pass overwrites slots the pass before it has gathered from and waits for those gathers.
         std::vector<int64_t> slot_of_q(c.blocks.size());
         bool evicted_waited = false;
-        for (size_t q = 0; q < c.blocks.size(); ++q) {
-            const int64_t bid = c.blocks[q];
-            const int64_t wy0 = bid * B, wh = std::min<int64_t>(H - wy0, B + ps), ww = W;
-            int64_t s = block_slot[bid];
-            if (s < 0) { // not resident: take the slot that has gone unused longest (never one this chunk needs)
-                s = 0;
-                for (int64_t t = 1; t < n_slots; ++t) if (slot_use[t] < slot_use[s]) s = t;
-                if (slot_use[s] == k) return fail_sync(api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "band cache too small for one chunk"));
-                if (slot_block[s] >= 0) {
-                    block_slot[slot_block[s]] = -1;
-                    // an evicted band may still be read by the gathers of an earlier chunk (they run on the other stream, in order):
-                    // the overwriting copy waits for the latest of them
-                    if (!evicted_waited && k >= 1) { NFX_HIP_S(hipStreamWaitEvent(copy, ctx->ev_ready[(k - 1) % NB], 0)); evicted_waited = true; }
-                }
-                slot_block[s] = bid; block_slot[bid] = s; slot_use[s] = k;
-                uint8_t *dst = d_slots + (size_t)s * slot_bytes;
-                for (int ch = 0; ch < 3; ++ch) // rows [wy0, wy0 + wh) of a channel are contiguous in the planar image
-                    NFX_HIP_S(hipMemcpyAsync(dst + (size_t)ch * wh * ww, image_u8 + ((size_t)ch * H + wy0) * W, (size_t)wh * ww, hipMemcpyHostToDevice, copy));
-                img_h2d += 3 * wh * ww;
-                ++blocks_copied;
+        for (size_t q0 = 0; q0 < c.blocks.size();) {
+            const size_t q1 = std::min(c.blocks.size(), q0 + (size_t)n_slots);
+            ++use_tick;
+            for (size_t q = q0; q < q1; ++q) if (block_slot[c.blocks[q]] >= 0) slot_use[block_slot[c.blocks[q]]] = use_tick;
+            if (q0 > 0) { // the gathers of the pass before read slots this pass may overwrite
+                NFX_HIP_S(hipEventRecord(ctx->ev_pass, rows_s));
+                NFX_HIP_S(hipStreamWaitEvent(copy, ctx->ev_pass, 0));
+                evicted_waited = true; // (the rows stream is in order: that covers the earlier chunks' gathers as well)
             }
-            slot_of_q[q] = s;
-        }
-        NFX_HIP_S(hipEventRecord(ctx->ev_bands[b], copy));
-        NFX_HIP_S(hipStreamWaitEvent(rows_s, ctx->ev_bands[b], 0));
-        for (size_t q = 0; q < c.blocks.size(); ++q) {
-            const int64_t bid = c.blocks[q];
-            const int64_t wy0 = bid * B, wh = std::min<int64_t>(H - wy0, B + ps);
-            ctx->stream = rows_s;
-            const hipError_t ge = launch_gather_patches_window(ctx, c.sel_off[q + 1] - c.sel_off[q], d_sel[b] + c.sel_off[q], d_cen + 2 * c.i0,
-                                                               d_slots + (size_t)slot_of_q[q] * slot_bytes, H, W, wy0, 0, wh, W, ps, d_patches[b]);
-            ctx->stream = compute;
-            NFX_HIP_S(ge);
+            for (size_t q = q0; q < q1; ++q) {
+                const int64_t bid = c.blocks[q];
+                const int64_t wy0 = bid * B, wh = std::min<int64_t>(H - wy0, B + ps), ww = W;
+                int64_t s = block_slot[bid];
+                if (s < 0) { // not resident: take the slot that has gone unused longest (never one this pass needs)
+                    s = 0;
+                    for (int64_t t = 1; t < n_slots; ++t) if (slot_use[t] < slot_use[s]) s = t;
+                    if (slot_use[s] == use_tick) return fail_sync(api_fail(ctx, NFX_ERR_DEVICE, "band cache: no free slot within a pass (internal)"));
+                    if (slot_block[s] >= 0) {
+                        block_slot[slot_block[s]] = -1;
+                        // an evicted band may still be read by the gathers of an earlier chunk (they run on the other stream, in order):
+                        // the overwriting copy waits for the latest of them
+                        if (!evicted_waited && k >= 1) { NFX_HIP_S(hipStreamWaitEvent(copy, ctx->ev_ready[(k - 1) % NB], 0)); evicted_waited = true; }
+                    }
+                    slot_block[s] = bid; block_slot[bid] = s; slot_use[s] = use_tick;
+                    uint8_t *dst = d_slots + (size_t)s * slot_bytes;
+                    for (int ch = 0; ch < 3; ++ch) // rows [wy0, wy0 + wh) of a channel are contiguous in the planar image
+                        NFX_HIP_S(hipMemcpyAsync(dst + (size_t)ch * wh * ww, image_u8 + ((size_t)ch * H + wy0) * W, (size_t)wh * ww, hipMemcpyHostToDevice, copy));
+                    img_h2d += 3 * wh * ww;
+                    ++blocks_copied;
+                }
+                slot_of_q[q] = s;
+            }
+            NFX_HIP_S(hipEventRecord(ctx->ev_bands[b], copy));
+            NFX_HIP_S(hipStreamWaitEvent(rows_s, ctx->ev_bands[b], 0));
+            for (size_t q = q0; q < q1; ++q) {
+                const int64_t bid = c.blocks[q];
+                const int64_t wy0 = bid * B, wh = std::min<int64_t>(H - wy0, B + ps);
+                ctx->stream = rows_s;
+                const hipError_t ge = launch_gather_patches_window(ctx, c.sel_off[q + 1] - c.sel_off[q], d_sel[b] + c.sel_off[q], d_cen + 2 * c.i0,
+                                                                   d_slots + (size_t)slot_of_q[q] * slot_bytes, H, W, wy0, 0, wh, W, ps, d_patches[b]);
+                ctx->stream = compute;
+                NFX_HIP_S(ge);
+            }
+            if (q1 - q0 < c.blocks.size()) ++gather_passes;
+            q0 = q1;
         }
         NFX_HIP_S(hipEventRecord(ctx->ev_ready[b], rows_s));
         return NFX_OK;
@@ -339,7 +358,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     int64_t nchunks = 0;
     bool have = plan_next < n, have_next = false;
     if (have) {
-        if (!plan(plans[0])) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "one reference batch touches more bands than the band cache holds: raise cache_bytes");
+        plan(plans[0]);
         if ((st = enqueue_copy(0)) != NFX_OK) return st;
     }
     for (int64_t k = 0; have; ++k, have = have_next) {
@@ -362,7 +381,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         rows_d2h += 4 * m * F;
         have_next = plan_next < n;
         if (have_next) {
-            if (!plan(plans[(k + 1) & 1])) return fail_sync(api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "one reference batch touches more bands than the band cache holds: raise cache_bytes"));
+            plan(plans[(k + 1) & 1]);
             if ((st = enqueue_copy(k + 1)) != NFX_OK) return st;
         }
     }
@@ -375,7 +394,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     if (stats) {
         stats->image_bytes_h2d = img_h2d; stats->other_bytes_h2d = other_h2d; stats->rows_bytes_d2h = rows_d2h + 8 * n;
         stats->blocks_copied = blocks_copied; stats->blocks_total = nblocks; stats->chunks = nchunks; stats->block_slots = n_slots;
-        stats->image_pinned = img_pinned ? 1 : 0;
+        stats->image_pinned = img_pinned ? 1 : 0; stats->split_gather_passes = gather_passes;
     }
     return NFX_OK;
 }
