@@ -49,6 +49,13 @@ static_assert(GB_WAVES == 4, "four strips of TSR <= 16 columns tile the plane's 
 #ifndef NFX_GB_REDO_RATIO
 #define NFX_GB_REDO_RATIO 8.0 // (s1/K)^2 / var beyond which a nucleus is done again with the measured mean as shift (k_gabor)
 #endif
+// The envelope groups' three column passes share their folded window (gabor_nucleus, column_passes_env); 0 = the generic passes
+#ifndef NFX_GB_ENV_FUSED
+#define NFX_GB_ENV_FUSED 1
+#endif
+#ifndef NFX_GB_ENV_MAX_CT
+#define NFX_GB_ENV_MAX_CT 16 // strips of more rows than this take the generic passes (register budget: 6 CT accumulators beside the window)
+#endif
 static constexpr int GB_GW = NFX_ROW_WORD_PS + GB_SIZE - 1; // gray row with apron: 93 floats
 static constexpr int GB_UW = NFX_ROW_WORD_PS + 1;           // U/W row stride (odd: conflict-free both ways)
 static constexpr int GB_UH = NFX_ROW_WORD_PS + GB_SIZE - 1; // U/W rows incl. zero aprons: 93
@@ -227,6 +234,8 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
         const float *__restrict__ img = tab->groups[g].image; // wave-uniform: the taps arrive through the scalar cache
         // ---- row pass ---------------------------------------------------------------------------------------------
         const bool envelope = __float_as_int(img[GB_META + 1]) != 0; // both row kernels are the bare envelope (90 / 0 degree groups)
+        const int n_pass = __float_as_int(img[GB_META]);
+        const bool fused = NFX_GB_ENV_FUSED && envelope && n_pass == GB_MAX_PASSES && ct <= NFX_GB_ENV_MAX_CT; // wave-uniform
         auto load_window = [&](auto win_tag, float (&x)[decltype(win_tag)::value]) {
             constexpr int WIN = decltype(win_tag)::value;
             if (tr) { // window element j is gray row c0 + j - 15 (wave-uniform): outside the patch it is the apron's zero
@@ -271,10 +280,19 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
                 for (int q = 0; q < TP; ++q) acc[q] = __builtin_elementwise_fma(wr[j], (f2){x[2 * q + j], x[2 * q + j + 1]}, acc[q]);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (fused) { // ONE plane, as floats in the first half of the wave's own columns of the plane pair (column_passes_env reads it back)
+                float *duf = reinterpret_cast<float *>(S.UW) + (rr + GB_PAD) * (2 * GB_UW) + 2 * c0;
 #pragma unroll
-            for (int q = 0; q < TP; ++q) {
-                du[2 * q] = (f2){acc[q].x, acc[q].x};
-                if (2 * q + 1 < TS) du[2 * q + 1] = (f2){acc[q].y, acc[q].y};
+                for (int q = 0; q < TP; ++q) {
+                    duf[2 * q] = acc[q].x;
+                    if (2 * q + 1 < TS) duf[2 * q + 1] = acc[q].y;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < TP; ++q) {
+                    du[2 * q] = (f2){acc[q].x, acc[q].x};
+                    if (2 * q + 1 < TS) du[2 * q + 1] = (f2){acc[q].y, acc[q].y};
+                }
             }
         };
         if (!(dbg & 1)) {
@@ -318,7 +336,6 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
         }
         wave_lds_fence(); // the wave's own plane columns: written above, read below
         // ---- column passes ------------------------------------------------------------------------------------------
-        const int n_pass = __float_as_int(img[GB_META]);
         auto column_passes = [&](auto ct_tag) {
             constexpr int CT = decltype(ct_tag)::value, CWIN = CT + GB_SIZE - 1;
             f2 x[CWIN];
@@ -377,7 +394,98 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
                 }
             }
         };
-        if (!(dbg & 2)) {
+        // ENVELOPE GROUPS (90 degrees; 0 degrees on the transposed view): the plane is ONE plane (both row kernels are the bare envelope) and
+        // all six column kernels G(y) cos(B y) are EVEN about the middle of the 30-tap grid (t_{29-j} = -t_j), so taps j and 29 - j share a
+        // multiplication: per output 15 additions x[o+j] + x[o+29-j], shared by the three passes, and 3 x 15 packed FMAs instead of 3 x 30.
+        // The window is a plain float window (CT + 29 registers instead of twice that), which is what lets the three accumulator
+        // sets (6 CT registers) sit beside it.  Tap-major order pinned as in taps2; the tap pairs of tap j are three scalar pairs.
+        auto column_passes_env = [&](auto ct_tag) {
+            constexpr int CT = decltype(ct_tag)::value, CWIN = CT + GB_SIZE - 1, HALF = GB_SIZE / 2;
+            float x[CWIN];
+            {
+                const float *suf = reinterpret_cast<const float *>(S.UW) + r0c * (2 * GB_UW) + 2 * c0 + cj;
+#pragma unroll
+                for (int j = 0; j < CWIN; ++j) x[j] = suf[j * (2 * GB_UW)];
+            }
+            const float *__restrict__ wp0 = img + GB_WSLOT, *__restrict__ wp1 = img + 2 * GB_WSLOT, *__restrict__ wp2 = img + 3 * GB_WSLOT;
+            int meta[GB_MAX_PASSES];
+            f2 acc[GB_MAX_PASSES][CT];
+#pragma unroll
+            for (int p = 0; p < GB_MAX_PASSES; ++p) {
+                const float *__restrict__ wp = img + (1 + p) * GB_WSLOT;
+                meta[p] = __float_as_int(wp[GB_META + 2]);
+                float sh0, sh1;
+                if constexpr (REFINED) {
+                    const int fs0 = (meta[p] >> 8) & 255, fs1 = (meta[p] >> 16) & 255;
+                    sh0 = s_shift[fs0 != 255 ? fs0 : 0];
+                    sh1 = fs1 != 255 ? s_shift[fs1] : 0.0f;
+                } else {
+                    sh0 = wp[GB_META] * mu_gray;
+                    sh1 = wp[GB_META + 1] * mu_gray;
+                }
+#pragma unroll
+                for (int o = 0; o < CT; ++o) acc[p][o] = (f2){-sh0, -sh1};
+            }
+#pragma unroll
+            for (int j = 0; j < HALF; ++j) {
+                const f2 w0 = {wp0[2 * j], wp0[2 * j + 1]}, w1 = {wp1[2 * j], wp1[2 * j + 1]}, w2 = {wp2[2 * j], wp2[2 * j + 1]};
+#pragma unroll
+                for (int o = 0; o < CT; ++o) {
+                    const float tf = x[o + j] + x[o + GB_SIZE - 1 - j];
+                    const f2 tt = {tf, tf};
+                    acc[0][o] = __builtin_elementwise_fma(w0, tt, acc[0][o]);
+                    acc[1][o] = __builtin_elementwise_fma(w1, tt, acc[1][o]);
+                    acc[2][o] = __builtin_elementwise_fma(w2, tt, acc[2][o]);
+                }
+                // the accumulators are pinned at the end of every tap: left alone, instruction selection lays the block out pass-major
+                // (all of pass 0's FMAs, the 15 CT folded sums kept alive -- in scratch memory -- for passes 1 and 2)
+#pragma unroll
+                for (int o = 0; o < CT; ++o) {
+                    asm volatile("" : "+v"(acc[0][o]));
+                    asm volatile("" : "+v"(acc[1][o]));
+                    asm volatile("" : "+v"(acc[2][o]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int p = 0; p < GB_MAX_PASSES; ++p) {
+                f2 a = {0.0f, 0.0f}, b = {0.0f, 0.0f};
+#pragma unroll
+                for (int q = 0; q < CT; ++q) {
+                    const float mq = ((mbits >> q) & 1u) ? 1.0f : 0.0f;
+                    const f2 d = acc[p][q] * (f2){mq, mq};
+                    a += d;
+                    b = __builtin_elementwise_fma(d, d, b);
+                }
+                float tot[4] = {a.x, b.x, a.y, b.y};
+                const float mine = wave_reduce_scatter(tot, lane);
+                if (lane < 4) {
+                    const int which = scatter_index<4>(lane);
+                    const int f = (meta[p] >> (8 + 8 * (which >> 1))) & 255;
+                    if (f != 255) s_part[wv][f][which & 1] = (double)mine;
+                }
+            }
+        };
+        if (fused && !(dbg & 2)) {
+            switch (ct) {
+            NFX_GB_CASE(2, (GB_MAX_CT < NFX_GB_ENV_MAX_CT ? GB_MAX_CT : NFX_GB_ENV_MAX_CT), column_passes_env)
+            NFX_GB_CASE(3, (GB_MAX_CT < NFX_GB_ENV_MAX_CT ? GB_MAX_CT : NFX_GB_ENV_MAX_CT), column_passes_env)
+            NFX_GB_CASE(4, (GB_MAX_CT < NFX_GB_ENV_MAX_CT ? GB_MAX_CT : NFX_GB_ENV_MAX_CT), column_passes_env)
+            NFX_GB_CASE(5, (GB_MAX_CT < NFX_GB_ENV_MAX_CT ? GB_MAX_CT : NFX_GB_ENV_MAX_CT), column_passes_env)
+            NFX_GB_CASE(6, (GB_MAX_CT < NFX_GB_ENV_MAX_CT ? GB_MAX_CT : NFX_GB_ENV_MAX_CT), column_passes_env)
+            NFX_GB_CASE(7, (GB_MAX_CT < NFX_GB_ENV_MAX_CT ? GB_MAX_CT : NFX_GB_ENV_MAX_CT), column_passes_env)
+            NFX_GB_CASE(8, (GB_MAX_CT < NFX_GB_ENV_MAX_CT ? GB_MAX_CT : NFX_GB_ENV_MAX_CT), column_passes_env)
+            NFX_GB_CASE(9, (GB_MAX_CT < NFX_GB_ENV_MAX_CT ? GB_MAX_CT : NFX_GB_ENV_MAX_CT), column_passes_env)
+            NFX_GB_CASE(10, (GB_MAX_CT < NFX_GB_ENV_MAX_CT ? GB_MAX_CT : NFX_GB_ENV_MAX_CT), column_passes_env)
+            NFX_GB_CASE(11, (GB_MAX_CT < NFX_GB_ENV_MAX_CT ? GB_MAX_CT : NFX_GB_ENV_MAX_CT), column_passes_env)
+            NFX_GB_CASE(12, (GB_MAX_CT < NFX_GB_ENV_MAX_CT ? GB_MAX_CT : NFX_GB_ENV_MAX_CT), column_passes_env)
+            NFX_GB_CASE(13, (GB_MAX_CT < NFX_GB_ENV_MAX_CT ? GB_MAX_CT : NFX_GB_ENV_MAX_CT), column_passes_env)
+            NFX_GB_CASE(14, (GB_MAX_CT < NFX_GB_ENV_MAX_CT ? GB_MAX_CT : NFX_GB_ENV_MAX_CT), column_passes_env)
+            NFX_GB_CASE(15, (GB_MAX_CT < NFX_GB_ENV_MAX_CT ? GB_MAX_CT : NFX_GB_ENV_MAX_CT), column_passes_env)
+            NFX_GB_CASE(16, (GB_MAX_CT < NFX_GB_ENV_MAX_CT ? GB_MAX_CT : NFX_GB_ENV_MAX_CT), column_passes_env)
+            default: break;
+            }
+        } else if (!(dbg & 2)) {
             switch (ct) {
             NFX_GB_CASE(2, GB_MAX_CT, column_passes)
             NFX_GB_CASE(3, GB_MAX_CT, column_passes)
