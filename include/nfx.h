@@ -65,7 +65,7 @@ typedef struct nfx_ctx nfx_ctx;
 typedef enum {
     NFX_OK = 0,
     NFX_ERR_INVALID_ARGUMENT = 1,
-    NFX_ERR_UNSUPPORTED = 2,   /* e.g. patch size > 128 */
+    NFX_ERR_UNSUPPORTED = 2,   /* e.g. patch size > NFX_MAX_PATCH_SIZE */
     NFX_ERR_DEVICE = 3,        /* HIP runtime error, text in nfx_last_error */
     NFX_ERR_OUT_OF_MEMORY = 4
 } nfx_status;
@@ -85,8 +85,11 @@ typedef enum { NFX_MEM_HOST = 0, NFX_MEM_DEVICE = 1 } nfx_mem;
 /* Patch sizes (args.rs:93-94, default 64).  Up to 64 a mask row is one 64-bit word in one lane's registers and the
    wave-per-nucleus kernels run; 65..128 take a second kernel family (one workgroup per nucleus, two words per mask row; Gabor on
    64 x 64 tiles through the fast kernel): same results, lower throughput (all five sets: 0.5 M nuclei/s at 128 x 128 against 7 M/s
-   at 64 x 64).  Larger patches are refused with NFX_ERR_UNSUPPORTED. */
-#define NFX_MAX_PATCH_SIZE 128
+   at 64 x 64); 129..512 take a third, plainer family (the same workgroup-per-nucleus kernels with mask rows of up to eight words,
+   level maps and dense count tables in device scratch memory instead of LDS, Gabor on up to 15 x 15 tiles): same results, a
+   correctness path with no claim to speed.  Larger patches are refused with NFX_ERR_UNSUPPORTED (the reference's `-p` takes any
+   u32, args.rs:93-94; its default is 64). */
+#define NFX_MAX_PATCH_SIZE 512
 
 /* ---- registry (no context, no GPU needed) ------------------------------------------------ */
 int nfx_version(void);
@@ -170,7 +173,7 @@ nfx_status nfx_preprocess_polygons(nfx_ctx *ctx, int64_t n, int64_t n_vertices, 
 /* ---- R2: tch_utils::shapes::polygon call sites utils.rs:90-95,152-157 ---------------------
    centred polygons in, masks out.  Either output may be NULL:
      masks_f32  [n][1][ps][ps] f32 in {0,1}  (the reference's tensor)
-     mask_rows  [n][ps][W] u64, W = 1 for ps <= 64 (bit c of word r == pixel (r,c)) and 2 for ps 65..128 (bit c & 63 of word
+     mask_rows  [n][ps][W] u64, W = ceil(ps / 64): 1 for ps <= 64 (bit c of word r == pixel (r,c)), 2 for ps 65..128, up to 8 (bit c & 63 of word
                 c >> 6)  (the engine's native form) */
 nfx_status nfx_rasterize_polygons(nfx_ctx *ctx, int64_t n, int64_t n_vertices, const uint32_t *poly_offsets,
                                   const float *poly_xy, int ps, float *masks_f32, uint64_t *mask_rows, nfx_mem mem);

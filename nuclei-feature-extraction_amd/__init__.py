@@ -285,10 +285,10 @@ class Context:
         if dev:
             import torch
             masks = torch.empty((n, 1, ps, ps), dtype=torch.float32, device=xy.device)
-            r = torch.empty((n, ps) if ps <= 64 else (n, ps, 2), dtype=torch.int64, device=xy.device) if rows else None
+            r = torch.empty((n, ps) if ps <= 64 else (n, ps, (ps + 63) // 64), dtype=torch.int64, device=xy.device) if rows else None
         else:
             masks = np.empty((n, 1, ps, ps), np.float32)
-            r = np.empty((n, ps) if ps <= 64 else (n, ps, 2), np.uint64) if rows else None   # one word per row up to 64, two up to 128
+            r = np.empty((n, ps) if ps <= 64 else (n, ps, (ps + 63) // 64), np.uint64) if rows else None   # ceil(ps / 64) words per row
         self._check(lib().nfx_rasterize_polygons(self._h, n, nv, _ptr(off), _ptr(xy), ps, _ptr(masks), _ptr(r), int(dev)))
         return (masks, r) if rows else masks
 

@@ -386,9 +386,9 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
     }
 }
 
-// ---- patch sizes 65..128: one 256-thread workgroup per nucleus (see k_geometry.hip, "patch sizes 65..128") -----------------
+// ---- patch sizes 65..512: one 256-thread workgroup per nucleus (see k_geometry.hip, "patch sizes 65..128" and "129..512") ----
 // Same per-pixel arithmetic (pixel_channels), same finishing formulas; the threads stride over the patch, test the mask bit
-// in the [ps][2] row words, and the twenty sums are reduced per wave (DPP) and across the four waves through LDS.
+// in the [ps][W] row words (W = ceil(ps / 64)), and the twenty sums are reduced per wave (DPP) and across the four waves through LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void k_color_wide(int64_t n, int ps, int batch_size, const T *__restrict__ patches,
                                                     const uint64_t *__restrict__ mask_rows, const double *__restrict__ SC,
@@ -403,7 +403,8 @@ __global__ __launch_bounds__(256) void k_color_wide(int64_t n, int ps, int batch
     const int P = ps * ps;
     for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
         const T *pp = patches + (size_t)i * 3 * P;
-        const uint64_t *rows = mask_rows + (size_t)i * ps * 2;
+        const int W = (ps + 63) >> 6;
+        const uint64_t *rows = mask_rows + (size_t)i * ps * W;
         const double *S = SC + (size_t)(i / batch_size) * 2 * P;
         const double *Cc = S + P;
         double acc[20]; // sum x (9), sum x^2 (9), sum sin, sum cos
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(256) void k_color_wide(int64_t n, int ps, int batch
         int K = 0;
         for (int p = t; p < P; p += 256) {
             const int r = p / ps, c = p - r * ps;
-            if (!((rows[2 * r + (c >> 6)] >> (c & 63)) & 1ull)) continue;
+            if (!((rows[W * r + (c >> 6)] >> (c & 63)) & 1ull)) continue;
             ++K;
             float x[9];
             if (sizeof(T) == 1) {

@@ -513,27 +513,28 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
 // ---- patch sizes 65..128: the same kernel on TILES ------------------------------------------------------------------------------
 // The planes of a 128 x 128 patch do not fit the LDS, but a response only depends on the 30 x 30 pixels around it: a 64 x 64 WINDOW of
 // the patch (zeros outside the patch, as the reference's padding has them) gives the exact responses of its central 35 x 35 pixels
-// (15 taps before, 14 after).  k_gabor_plan cuts a wide nucleus's mask into such central squares -- up to 16 tiles, only those that hold
+// (15 taps before, 14 after).  k_gabor_plan cuts a wide nucleus's mask into such central squares -- up to 16 tiles at 128 x 128 (225 at 512 x 512), only those that hold
 // mask pixels -- k_gabor<T, GB_TILES> runs every tile as a nucleus of its own (window as the patch, central mask as the mask, the
 // WHOLE mask's shift) and writes the tile's masked sums, and k_gabor_finish adds a nucleus's tiles in a fixed order and forms the
 // 96 columns.
 static constexpr int GB_MAIN = 0, GB_REFINED = 1, GB_TILES = 2;
 static constexpr int GB_CENTRAL = NFX_ROW_WORD_PS - (GB_SIZE - 1);                 // 35: rows / columns [15, 50) of a window
-static constexpr int GB_TILES_PER_DIM = (NFX_MAX_PATCH_SIZE + GB_CENTRAL - 1) / GB_CENTRAL; // 4
-static constexpr int GB_MAX_TILES = GB_TILES_PER_DIM * GB_TILES_PER_DIM;           // per nucleus
+static __host__ __device__ constexpr int gb_max_tiles(int ps) { return ((ps + GB_CENTRAL - 1) / GB_CENTRAL) * ((ps + GB_CENTRAL - 1) / GB_CENTRAL); } // per nucleus: 16 at 128, 225 at 512
+static_assert(gb_max_tiles(NFX_MAX_PATCH_SIZE) <= 256, "k_gabor_plan: one thread per candidate tile");
 struct GaborTile { int nucleus, wr, wc, pad; };                                    // window origin in patch coordinates (may be negative)
 struct GaborTileArgs {
     const GaborTile *tiles; const int *tile_count; const float *mu_gray; double *tile_sums; // [tile][GB_MAX_FILTERS][2]
 };
 
-// bits [off, off + 64) of the 128-bit row (w1 : w0), zeros outside
-static __device__ __forceinline__ uint64_t window_bits(uint64_t w0, uint64_t w1, int off)
+// bits [off, off + 64) of a mask row of W words, zeros outside the row
+static __device__ __forceinline__ uint64_t window_bits(const uint64_t *row, int W, int off)
 {
-    if (off <= -64 || off >= 128) return 0ull;
-    if (off < 0) return w0 << (-off);
-    if (off == 0) return w0;
-    if (off < 64) return (w0 >> off) | (w1 << (64 - off));
-    return off == 64 ? w1 : (w1 >> (off - 64));
+    if (off <= -64 || off >= 64 * W) return 0ull;
+    if (off < 0) return row[0] << (-off);
+    const int wi = off >> 6, sh = off & 63;
+    uint64_t v = row[wi] >> sh;
+    if (sh && wi + 1 < W) v |= row[wi + 1] << (64 - sh);
+    return v;
 }
 
 // MODE = GB_MAIN: the launch over all n nuclei; a nucleus one of whose variances came out of a badly centred sum is appended to
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
                 const int r = wr + t;
                 uint64_t bits = 0ull;
                 if (t >= GB_PAD && t < GB_PAD + GB_CENTRAL && r >= 0 && r < ps)
-                    bits = window_bits(mask_rows[((size_t)i * ps + r) * 2], mask_rows[((size_t)i * ps + r) * 2 + 1], wc) & (((1ull << GB_CENTRAL) - 1ull) << GB_PAD);
+                    bits = window_bits(mask_rows + ((size_t)i * ps + r) * ((ps + 63) >> 6), (ps + 63) >> 6, wc) & (((1ull << GB_CENTRAL) - 1ull) << GB_PAD);
                 s_rows[t] = bits;
             }
         } else if (t < 64) s_rows[t] = row_next;
@@ -744,25 +745,26 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
 // One workgroup per wide nucleus: mask area and masked gray sum (the shift), bounding box, and the tiles -- central squares of
 // GB_CENTRAL pixels laid over the bounding box from its top-left corner, those without a mask pixel left out -- written as ONE run
 // of the tile list (tile_begin / tile_n per nucleus), in row-major order: the order k_gabor_finish adds them in.
-template <typename T>
+template <typename T, int MAXPS>
 __global__ __launch_bounds__(256) void k_gabor_plan(int64_t n, int ps, const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
                                                     GaborTile *__restrict__ tiles, int *__restrict__ tile_count, int *__restrict__ tile_begin,
                                                     int *__restrict__ tile_n, float *__restrict__ mu_gray, int *__restrict__ area_out)
 {
-    __shared__ uint64_t s_rows[NFX_MAX_PATCH_SIZE][2];
+    constexpr int MAXW = MAXPS / 64;
+    __shared__ uint64_t s_rows[MAXPS * MAXW];
     __shared__ float s_g[4];
-    __shared__ int s_box[4], s_k[4], s_base;
+    __shared__ int s_box[4], s_k[4], s_votes[4], s_base;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int P = ps * ps;
+    const int P = ps * ps, W = (ps + 63) >> 6;
     for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
-        for (int k = t; k < 2 * ps; k += 256) s_rows[k >> 1][k & 1] = mask_rows[(size_t)i * ps * 2 + k];
+        for (int k = t; k < W * ps; k += 256) s_rows[k] = mask_rows[(size_t)i * ps * W + k];
         __syncthreads();
         const T *pp = patches + (size_t)i * 3 * P;
         float gsum = 0.0f;
         int cnt = 0;
         for (int p = t; p < P; p += 256) {
             const int r = p / ps, c = p - r * ps;
-            if ((s_rows[r][c >> 6] >> (c & 63)) & 1ull) {
+            if ((s_rows[r * W + (c >> 6)] >> (c & 63)) & 1ull) {
                 float gs = BPx<T>::ld(pp, p) + BPx<T>::ld(pp, P + p);
                 gs = gs + BPx<T>::ld(pp, 2 * P + p);
                 gsum += sizeof(T) == 1 ? third_of_u8_sum(gs) : gs / 3.0f;
@@ -772,41 +774,48 @@ __global__ __launch_bounds__(256) void k_gabor_plan(int64_t n, int ps, const T *
         gsum = wave_total_f32(gsum);
         cnt = wave_total_i32(cnt);
         if (lane == 0) { s_g[wv] = gsum; s_k[wv] = cnt; }
-        if (t == 0) { // bounding box (a serial look at <= 128 rows: nothing beside the 16 k pixels above)
-            int rmin = ps, rmax = -1;
-            uint64_t o0 = 0ull, o1 = 0ull;
+        if (t == 0) { // bounding box (a serial look at the row words: nothing beside the pixels above)
+            int rmin = ps, rmax = -1, cmin = ps, cmax = -1;
             for (int r = 0; r < ps; ++r) {
-                const uint64_t a = s_rows[r][0], b = s_rows[r][1];
-                if (a | b) { rmin = r < rmin ? r : rmin; rmax = r; }
-                o0 |= a; o1 |= b;
+                bool any = false;
+                for (int w = 0; w < W; ++w) {
+                    const uint64_t a = s_rows[r * W + w];
+                    if (!a) continue;
+                    any = true;
+                    const int lo = 64 * w + __ffsll((long long)a) - 1, hi = 64 * w + 63 - __clzll((long long)a);
+                    cmin = lo < cmin ? lo : cmin; cmax = hi > cmax ? hi : cmax;
+                }
+                if (any) { rmin = r < rmin ? r : rmin; rmax = r; }
             }
-            s_box[0] = rmin; s_box[1] = rmax;
-            s_box[2] = o0 ? __ffsll((long long)o0) - 1 : (o1 ? 64 + __ffsll((long long)o1) - 1 : ps);
-            s_box[3] = o1 ? 127 - __clzll((long long)o1) : (o0 ? 63 - __clzll((long long)o0) : -1);
+            s_box[0] = rmin; s_box[1] = rmax; s_box[2] = cmin; s_box[3] = cmax;
         }
         __syncthreads();
         const int area = (s_k[0] + s_k[1]) + (s_k[2] + s_k[3]);
         const int rmin = s_box[0], rmax = s_box[1], cmin = s_box[2], cmax = s_box[3];
         const int tr = area ? (rmax - rmin) / GB_CENTRAL + 1 : 0, tc = area ? (cmax - cmin) / GB_CENTRAL + 1 : 0;
-        // thread a * tc + b looks at tile (a, b): does its central square hold a mask pixel?
+        // thread a * tc + b looks at tile (a, b): does its central square hold a mask pixel?  (tr * tc <= gb_max_tiles(MAXPS) <= 256)
         bool has = false;
         if (t < tr * tc) {
             const int a = t / tc, b = t - a * tc, r0 = rmin + a * GB_CENTRAL, c0 = cmin + b * GB_CENTRAL;
             for (int r = r0; r < r0 + GB_CENTRAL && r < ps && !has; ++r)
-                has = (window_bits(s_rows[r][0], s_rows[r][1], c0) & ((1ull << GB_CENTRAL) - 1ull)) != 0ull;
+                has = (window_bits(&s_rows[r * W], W, c0) & ((1ull << GB_CENTRAL) - 1ull)) != 0ull;
         }
-        const uint64_t votes = __ballot(has); // tr * tc <= 16: all in wave 0
+        const uint64_t votes = __ballot(has);
+        if (lane == 0) s_votes[wv] = __popcll(votes);
+        __syncthreads();
         if (t == 0) {
-            const int m = __popcll(votes);
+            const int m = (s_votes[0] + s_votes[1]) + (s_votes[2] + s_votes[3]);
             s_base = m ? atomicAdd(tile_count, m) : 0;
             tile_begin[i] = s_base; tile_n[i] = m;
             mu_gray[i] = ((s_g[0] + s_g[1]) + (s_g[2] + s_g[3])) / (float)area;
             area_out[i] = area;
         }
         __syncthreads();
-        if (has) {
+        if (has) { // row-major order of the tiles: the waves before this one, then the lanes before this one
             const int a = t / tc, b = t - a * tc;
-            const int slot = s_base + __popcll(votes & ((1ull << t) - 1ull));
+            int before = 0;
+            for (int w = 0; w < wv; ++w) before += s_votes[w];
+            const int slot = s_base + before + __popcll(votes & ((1ull << lane) - 1ull));
             tiles[slot] = GaborTile{(int)i, rmin + a * GB_CENTRAL - GB_PAD, cmin + b * GB_CENTRAL - GB_PAD, 0};
         }
         __syncthreads();
@@ -975,22 +984,24 @@ hipError_t prepare_gabor(nfx_ctx *ctx)
     return hipSuccess;
 }
 
-// wide patches are planned, run and finished in chunks of GBT_CHUNK nuclei: the tile list and the tiles' sums of one chunk
-static constexpr int64_t GBT_CHUNK = 16384;
+// wide patches are planned, run and finished in chunks of nuclei: the tile list and the tiles' sums of one chunk (100 MB of sums:
+// 16 384 nuclei of up to 16 tiles at 128 x 128, 1 165 nuclei of up to 225 tiles at 512 x 512)
+static int64_t gbt_chunk(int ps) { return ps <= NFX_WIDE_PS ? 16384 : (16384 * 16) / gb_max_tiles(ps); }
 struct WideScratch { int *tile_count, *tile_begin, *tile_n, *area; float *mu; GaborTile *tiles; double *sums; size_t bytes; };
-static WideScratch wide_scratch(void *scratch, int64_t nc)
+static WideScratch wide_scratch(void *scratch, int64_t nc, int ps)
 {
     char *const base = reinterpret_cast<char *>(scratch);
     char *p = base;
     auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) & ~(size_t)255; return q; };
+    const size_t mt = (size_t)gb_max_tiles(ps);
     WideScratch w;
     w.tile_count = reinterpret_cast<int *>(take(64));
     w.tile_begin = reinterpret_cast<int *>(take(4 * (size_t)nc));
     w.tile_n = reinterpret_cast<int *>(take(4 * (size_t)nc));
     w.area = reinterpret_cast<int *>(take(4 * (size_t)nc));
     w.mu = reinterpret_cast<float *>(take(4 * (size_t)nc));
-    w.tiles = reinterpret_cast<GaborTile *>(take(sizeof(GaborTile) * (size_t)nc * GB_MAX_TILES));
-    w.sums = reinterpret_cast<double *>(take(sizeof(double) * 2 * GB_MAX_FILTERS * (size_t)nc * GB_MAX_TILES));
+    w.tiles = reinterpret_cast<GaborTile *>(take(sizeof(GaborTile) * (size_t)nc * mt));
+    w.sums = reinterpret_cast<double *>(take(sizeof(double) * 2 * GB_MAX_FILTERS * (size_t)nc * mt));
     w.bytes = (size_t)(p - base);
     return w;
 }
@@ -998,25 +1009,32 @@ size_t gabor_scratch_bytes(const Job &job)
 {
     const size_t n = (size_t)(job.n > 0 ? job.n : 1);
     if (job.ps <= NFX_ROW_WORD_PS) return sizeof(int) * (n + 16); // redo list + its length
-    return wide_scratch(nullptr, (int64_t)(n < (size_t)GBT_CHUNK ? n : (size_t)GBT_CHUNK)).bytes; // (pointer arithmetic only)
+    const size_t chunk = (size_t)gbt_chunk(job.ps);
+    return wide_scratch(nullptr, (int64_t)(n < chunk ? n : chunk), job.ps).bytes; // (pointer arithmetic only)
 }
 
 template <typename T>
 static hipError_t launch_gabor_wide(nfx_ctx *ctx, const Job &job, int col0, void *scratch, const GaborTables *tab)
 {
     const size_t P3 = 3 * (size_t)job.ps * job.ps;
-    for (int64_t i0 = 0; i0 < job.n; i0 += GBT_CHUNK) {
-        const int64_t nc = job.n - i0 < GBT_CHUNK ? job.n - i0 : GBT_CHUNK;
-        const WideScratch w = wide_scratch(scratch, job.n < GBT_CHUNK ? job.n : GBT_CHUNK);
+    const int W = mask_words_per_row(job.ps);
+    const int64_t chunk = gbt_chunk(job.ps);
+    const int64_t mt = gb_max_tiles(job.ps);
+    for (int64_t i0 = 0; i0 < job.n; i0 += chunk) {
+        const int64_t nc = job.n - i0 < chunk ? job.n - i0 : chunk;
+        const WideScratch w = wide_scratch(scratch, job.n < chunk ? job.n : chunk, job.ps);
         const T *patches = reinterpret_cast<const T *>(job.patches) + (size_t)i0 * P3;
-        const uint64_t *rows = job.mask_rows + (size_t)i0 * job.ps * 2;
+        const uint64_t *rows = job.mask_rows + (size_t)i0 * job.ps * W;
         float *out = job.out + (size_t)i0 * job.F;
         hipError_t e = hipMemsetAsync(w.tile_count, 0, sizeof(int), ctx->stream);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_gabor_plan<T>, dim3((unsigned)(nc < 256 * 8 ? nc : 256 * 8)), dim3(256), 0, ctx->stream, nc, job.ps, patches, rows, w.tiles, w.tile_count,
-                           w.tile_begin, w.tile_n, w.mu, w.area);
+        const dim3 pgrid((unsigned)(nc < 256 * 8 ? nc : 256 * 8));
+        if (job.ps <= NFX_WIDE_PS)
+            hipLaunchKernelGGL((k_gabor_plan<T, NFX_WIDE_PS>), pgrid, dim3(256), 0, ctx->stream, nc, job.ps, patches, rows, w.tiles, w.tile_count, w.tile_begin, w.tile_n, w.mu, w.area);
+        else
+            hipLaunchKernelGGL((k_gabor_plan<T, NFX_MAX_PATCH_SIZE>), pgrid, dim3(256), 0, ctx->stream, nc, job.ps, patches, rows, w.tiles, w.tile_count, w.tile_begin, w.tile_n, w.mu, w.area);
         // the tile launch walks a list whose length only the device knows: sixteen rounds of the resident workgroups at most
-        const int64_t max_tiles = nc * GB_MAX_TILES;
+        const int64_t max_tiles = nc * mt;
         const unsigned grid = (unsigned)(max_tiles < 256 * 2 * 16 ? max_tiles : 256 * 2 * 16);
         GaborTileArgs ta{w.tiles, w.tile_count, w.mu, w.sums};
         hipLaunchKernelGGL((k_gabor<T, GB_TILES>), dim3(grid), dim3(GB_THREADS), 0, ctx->stream, (int64_t)0, job.ps, patches, rows, tab, out, job.F, col0, 0,

@@ -224,7 +224,9 @@ struct ShapeAxes {
     float major, minor, angle, ecc, cen0, cen1; // cen0 / cen1: centre of mass (row, column) minus ps / 2 (shape.rs:71-73)
 };
 
-static __device__ __forceinline__ ShapeAxes shape_axes(int K, int sr, int scs, int srr, int src, int sccs, int ps)
+// (I = int for patches up to 128 x 128, whose sums stay below 2^31; long long above)
+template <typename I>
+static __device__ __forceinline__ ShapeAxes shape_axes(I K, I sr, I scs, I srr, I src, I sccs, int ps)
 {
     ShapeAxes A;
     // center_of_mass (shape.rs:219-226): integer sums < 2^24 are exact in f32
@@ -912,12 +914,148 @@ __global__ __launch_bounds__(256) void k_polygon(int64_t n, const uint32_t *__re
     }
 }
 
+// ---- patch sizes 129..512: the same workgroup-per-nucleus shape with rows of W = ceil(ps / 64) <= 8 words ------------------------
+// Thread t rasterises rows t and t + 256 (every row tests every edge, as the wide kernel), keeps their words in registers for the
+// ellipse step, and adds its rows' integer moments -- 64-bit now: sum r^2 over a 512 x 512 mask is 2^34 -- to the workgroup's
+// totals through LDS atomics.  Same expression trees as the kernels above: a nucleus gives the same columns in any family.
+static constexpr int HUGE_W = NFX_MAX_ROW_WORDS, HUGE_ROWS = NFX_MAX_PATCH_SIZE / 256;
+static_assert(NFX_MAX_PATCH_SIZE % 256 == 0 && NFX_MAX_PATCH_SIZE % 64 == 0, "rows per thread, words per row");
+
+// integer moments of one row from its words: count, sum of columns, sum of squared columns
+static __device__ __forceinline__ void row_moments_huge(const uint64_t (&w)[HUGE_W], long long &kr, long long &sc, long long &scc)
+{
+    kr = 0; sc = 0; scc = 0;
+#pragma unroll
+    for (int k = 0; k < HUGE_W; ++k) {
+        int p, s1, q;
+        word_moments(w[k], p, s1, q);
+        const long long b = 64ll * k; // (b + j)^2 = b^2 + 2 b j + j^2
+        kr += p; sc += s1 + b * p; scc += q + 2 * b * s1 + b * b * p;
+    }
+}
+
+// rows in registers -> moments into s_tot[0..5], then (SHAPE) the columns that come from the mask; shared by the two kernels below
+template <bool SHAPE>
+static __device__ __forceinline__ void shape_from_rows_huge(const uint64_t (&row)[HUGE_ROWS][HUGE_W], int ps, int t, unsigned long long *s_tot,
+                                                            float *__restrict__ o, int *__restrict__ area_out)
+{
+    long long a[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < HUGE_ROWS; ++u) {
+        const long long r = t + 256 * u;
+        long long kr, sc, scc;
+        row_moments_huge(row[u], kr, sc, scc); // (rows at or beyond ps are all zero)
+        a[0] += kr; a[1] += r * kr; a[2] += sc; a[3] += r * r * kr; a[4] += r * sc; a[5] += scc;
+    }
+    if (a[0]) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicAdd(&s_tot[k], (unsigned long long)a[k]);
+    }
+    __syncthreads();
+    const long long K = (long long)s_tot[0];
+    if (area_out && t == 0) *area_out = (int)K;
+    if (SHAPE) {
+        const ShapeAxes A = shape_axes<long long>(K, (long long)s_tot[1], (long long)s_tot[2], (long long)s_tot[3], (long long)s_tot[4], (long long)s_tot[5], ps);
+        const EllipseFrame E = ellipse_frame(A, ps);
+        int x = 0;
+#pragma unroll
+        for (int u = 0; u < HUGE_ROWS; ++u) {
+            const int r = t + 256 * u;
+            if (r < ps) {
+                int lo, len;
+                ellipse_row_span(E, ps, r, lo, len);
+#pragma unroll
+                for (int k = 0; k < HUGE_W; ++k) {
+                    const uint64_t e = low_bits(lo + len - 64 * k) & ~low_bits(lo - 64 * k);
+                    x += __popcll(e ^ row[u][k]);
+                }
+            }
+        }
+        if (x) atomicAdd(&s_tot[6], (unsigned long long)x);
+        __syncthreads();
+        if (t == 0) {
+            o[1] = A.major; o[2] = A.minor; o[3] = A.ecc; o[4] = A.angle;
+            o[8] = (float)(long long)s_tot[6] / (float)K;
+        }
+    }
+}
+
+template <bool SHAPE>
+__global__ __launch_bounds__(256) void k_raster_shape_huge(int64_t n, const uint32_t *__restrict__ poly_off, const float *__restrict__ poly_xy,
+                                                           int ps, uint64_t *__restrict__ rows_out, float *__restrict__ out, int F, int col0,
+                                                           int *__restrict__ areas_out)
+{
+    __shared__ unsigned long long s_tot[8];
+    const int t = threadIdx.x;
+    const int W = (ps + 63) >> 6;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        if (t < 8) s_tot[t] = 0ull;
+        __syncthreads();
+        const uint32_t v0 = poly_off[i];
+        const int V = (int)(poly_off[i + 1] - v0);
+        const double half = (double)ps / 2.0;
+        uint64_t row[HUGE_ROWS][HUGE_W];
+#pragma unroll
+        for (int u = 0; u < HUGE_ROWS; ++u) {
+#pragma unroll
+            for (int k = 0; k < HUGE_W; ++k) row[u][k] = 0ull;
+            const int r = t + 256 * u;
+            if (r < ps) {
+                const double py = (double)r - half;
+                for (int e = 0; e < V; ++e) {
+                    const float2 p1 = reinterpret_cast<const float2 *>(poly_xy)[v0 + e];
+                    const float2 p2 = reinterpret_cast<const float2 *>(poly_xy)[v0 + (e + 1 == V ? 0 : e + 1)];
+                    const double x1 = (double)p1.x, y1 = (double)p1.y, x2 = (double)p2.x, y2 = (double)p2.y;
+                    if ((y1 > py) != (y2 > py)) {
+                        const int k = crossing_count(x1, y1, x2, y2, py, half, ps); // <= ps: words at or beyond W stay zero
+#pragma unroll
+                        for (int w = 0; w < HUGE_W; ++w) row[u][w] ^= low_bits(k - 64 * w);
+                    }
+                }
+                if (rows_out) {
+#pragma unroll
+                    for (int w = 0; w < HUGE_W; ++w)
+                        if (w < W) rows_out[((size_t)i * ps + r) * W + w] = row[u][w];
+                }
+            }
+        }
+        shape_from_rows_huge<SHAPE>(row, ps, t, s_tot, SHAPE ? out + i * (int64_t)F + col0 : nullptr, areas_out ? areas_out + i : nullptr);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_shape_from_rows_huge(int64_t n, const uint64_t *__restrict__ rows, int ps, float *__restrict__ out, int F, int col0)
+{
+    __shared__ unsigned long long s_tot[8];
+    const int t = threadIdx.x;
+    const int W = (ps + 63) >> 6;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        if (t < 8) s_tot[t] = 0ull;
+        __syncthreads();
+        uint64_t row[HUGE_ROWS][HUGE_W];
+#pragma unroll
+        for (int u = 0; u < HUGE_ROWS; ++u) {
+            const int r = t + 256 * u;
+#pragma unroll
+            for (int w = 0; w < HUGE_W; ++w) row[u][w] = (r < ps && w < W) ? rows[((size_t)i * ps + r) * W + w] : 0ull;
+        }
+        shape_from_rows_huge<true>(row, ps, t, s_tot, out + i * (int64_t)F + col0, nullptr);
+        __syncthreads();
+    }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
 hipError_t launch_raster_shape(nfx_ctx *ctx, int64_t n, const uint32_t *poly_off, const float *poly_xy, int ps,
                                uint64_t *rows_out, float *out, int F, int col0, int *areas_out)
 {
     if (n == 0) return hipSuccess;
     ScopedTiming t(ctx, KS_RASTER_SHAPE);
+    if (ps > NFX_WIDE_PS) {
+        const unsigned wgrid = (unsigned)(n < 256 * 8 ? n : 256 * 8);
+        if (out) hipLaunchKernelGGL(k_raster_shape_huge<true>, dim3(wgrid), dim3(256), 0, ctx->stream, n, poly_off, poly_xy, ps, rows_out, out, F, col0, areas_out);
+        else hipLaunchKernelGGL(k_raster_shape_huge<false>, dim3(wgrid), dim3(256), 0, ctx->stream, n, poly_off, poly_xy, ps, rows_out, out, F, col0, areas_out);
+        return hipGetLastError();
+    }
     if (ps > 64) {
         const unsigned wgrid = (unsigned)(n < 256 * 16 ? n : 256 * 16);
         if (out) hipLaunchKernelGGL(k_raster_shape_wide<true>, dim3(wgrid), dim3(256), 0, ctx->stream, n, poly_off, poly_xy, ps, rows_out, out, F, col0, areas_out);
@@ -936,6 +1074,10 @@ hipError_t launch_shape_from_rows(nfx_ctx *ctx, int64_t n, const uint64_t *rows,
 {
     if (n == 0) return hipSuccess;
     ScopedTiming t(ctx, KS_RASTER_SHAPE);
+    if (ps > NFX_WIDE_PS) {
+        hipLaunchKernelGGL(k_shape_from_rows_huge, dim3((unsigned)(n < 256 * 8 ? n : 256 * 8)), dim3(256), 0, ctx->stream, n, rows, ps, out, F, col0);
+        return hipGetLastError();
+    }
     if (ps > 64) {
         hipLaunchKernelGGL(k_shape_from_rows_wide, dim3((unsigned)(n < 256 * 16 ? n : 256 * 16)), dim3(256), 0, ctx->stream, n, rows, ps, out, F, col0);
         return hipGetLastError();

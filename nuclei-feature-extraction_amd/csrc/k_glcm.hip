@@ -962,6 +962,133 @@ __global__ __launch_bounds__(256) void k_glcm_wide(int64_t n, int ps, const T *_
     }
 }
 
+// ---- patch sizes 129..512: dense count tables in device memory ------------------------------------------------------------------
+// Up to 2^18 mask pixels: neither a pixel list nor a hash table of that size fits the LDS, and with that many pairs a dense L x L table
+// is no longer mostly zeros.  One 256-thread workgroup per nucleus owns a slice of scratch memory: a level map of the patch (one
+// 16-bit word per pixel: level128 << 8 | level254, 0xFFFF outside the mask) and ONE dense table of 254 x 254 counters, reused by the
+// sixteen (level, offset) combinations.  A pass: clear L^2 counters, every thread walks its pixels, finds the partner through the
+// level map and bumps the unordered cell [lo][hi] with a device-memory atomic (they execute in L2; the table is cleared and read
+// with agent-scope stores and loads, which bypass this CU's L1), the marginal and the sum histogram with LDS atomics, the pair
+// sums in registers; then a sweep over the table as in k_glcm_wide (sum G^2 and the entropy sums from the FINAL counts, in fixed
+// point: the same bits whatever order the atomics landed in).  A correctness path: no claim to speed.
+static constexpr int GS_GRID = 256;          // workgroups (= scratch slices) of the launch
+static constexpr int GS_TAB = 254 * 254;     // counters per slice
+static size_t glcm_slab_bytes(int64_t n, int ps)
+{
+    const size_t g = (size_t)(n < GS_GRID ? (n > 0 ? n : 1) : GS_GRID);
+    return g * (sizeof(unsigned) * GS_TAB + sizeof(unsigned short) * (size_t)ps * ps) + 512;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_glcm_slab(int64_t n, int ps, const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
+                                                   const GlcmLuts *__restrict__ lut, unsigned *__restrict__ tab_all, unsigned short *__restrict__ lvl_all,
+                                                   float *__restrict__ out, int F, int col0, int64_t *__restrict__ dbg)
+{
+    __shared__ unsigned s_hx[256], s_hs[512];
+    __shared__ unsigned long long s_acc[10];             // np, S1, S2, D1, D2, asmn | ents, hxs, hss (fixed point) | spare
+    __shared__ double s_idm[4];                          // per wave: added in wave order
+    __shared__ double s_sums[16][GL_NACC];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int P = ps * ps, W = (ps + 63) >> 6;
+    unsigned *const tab = tab_all + (size_t)blockIdx.x * GS_TAB;
+    unsigned short *const lvl = lvl_all + (size_t)blockIdx.x * P;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        __syncthreads(); // every thread is done with the previous nucleus's map and sums
+        const T *pp = patches + (size_t)i * 3 * P;
+        const uint64_t *rows = mask_rows + (size_t)i * ps * W;
+        for (int p = t; p < P; p += 256) {
+            const int r = p / ps, c = p - r * ps;
+            unsigned code = 0xFFFFu;
+            if ((rows[W * r + (c >> 6)] >> (c & 63)) & 1ull) {
+                float g;
+                if (sizeof(T) == 1) {
+                    const uint8_t *pb = reinterpret_cast<const uint8_t *>(pp);
+                    float gs = u8_unit(pb[p]) + u8_unit(pb[P + p]); // utils.rs:172
+                    gs = gs + u8_unit(pb[2 * P + p]);
+                    g = third_of_u8_sum(gs);                          // texture.rs:36
+                } else {
+                    g = gray_at<T>(pp, P, p);
+                }
+                code = (quant(g, 128) << 8) | quant(g, 254);          // texture.rs:19 (level128 <= 127: never 0xFFFF)
+            }
+            lvl[p] = (unsigned short)code;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int li = 0; li < 4; ++li) {
+            const int L = li == 3 ? 254 : (32 << li);
+#pragma unroll 1
+            for (int oi = 0; oi < 4; ++oi) {
+                const int dy = kGlcmOffsets[oi][0], dx = kGlcmOffsets[oi][1];
+                for (int k = t; k < L * L; k += 256) __hip_atomic_store(&tab[k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_hx[t] = 0u; s_hs[t] = 0u; s_hs[256 + t] = 0u;
+                if (t < 10) s_acc[t] = 0ull;
+                __syncthreads(); // (workgroup release / acquire: the cleared counters are in L2 before the first atomic reaches it)
+                unsigned long long np = 0, S1 = 0, S2 = 0, D1 = 0, D2 = 0;
+                double idm = 0.0;
+                for (int p = t; p < P; p += 256) {
+                    const unsigned qa = lvl[p];
+                    if (qa == 0xFFFFu) continue;
+                    const int r = p / ps, c = p - r * ps;
+                    const int r2 = r + dy, c2 = c + dx;
+                    if ((unsigned)r2 >= (unsigned)ps || (unsigned)c2 >= (unsigned)ps) continue;
+                    const unsigned qb = lvl[r2 * ps + c2];
+                    if (qb == 0xFFFFu) continue;
+                    unsigned a, b;
+                    if (li == 3) { a = qa & 255u; b = qb & 255u; }
+                    else { a = (qa >> 8) >> (2 - li); b = (qb >> 8) >> (2 - li); } // floor(128 g) >> k = floor(2^(7-k) g)
+                    const unsigned lo = a < b ? a : b, hi = a < b ? b : a, d = hi - lo, sm = a + b;
+                    np += 1; S1 += sm; S2 += (unsigned long long)sm * sm; D1 += d; D2 += (unsigned long long)d * d;
+                    idm += 1.0 / (1.0 + (double)(d * d));
+                    atomicAdd(&s_hx[a], 1u);
+                    atomicAdd(&s_hx[b], 1u);
+                    atomicAdd(&s_hs[sm], 1u);
+                    __hip_atomic_fetch_add(&tab[lo * L + hi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads(); // every wave's atomics have been performed (its vmcnt has drained) before any counter is read back
+                // ---- sweep: sum G^2 and sum G ln G over the symmetric matrix from the final counts; marginal and sum entropies ----
+                unsigned long long asmn = 0;
+                long long ents = 0, hxs = 0, hss = 0;
+                for (int k = t; k < L * L; k += 256) {
+                    const unsigned cnt = __hip_atomic_load(&tab[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!cnt) continue;
+                    const int lo = k / L, hi = k - lo * L;
+                    const bool diag = lo == hi;
+                    const unsigned gsym = diag ? 2u * cnt : cnt;   // the symmetric matrix holds 2 cnt on the diagonal, cnt twice off it
+                    asmn += (unsigned long long)gsym * gsym * (diag ? 1u : 2u);
+                    ents += gw_xlnx_fix(lut, gsym) * (diag ? 1 : 2);
+                }
+                hxs += gw_xlnx_fix(lut, s_hx[t]);
+                hss += gw_xlnx_fix(lut, s_hs[t]) + gw_xlnx_fix(lut, s_hs[256 + t]);
+                {
+                    unsigned long long v[9] = {np, S1, S2, D1, D2, asmn, (unsigned long long)ents, (unsigned long long)hxs, (unsigned long long)hss};
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const unsigned long long w = gw_wave_total_u64(v[k]);
+                        if (lane == 0) atomicAdd(&s_acc[k], w);
+                    }
+                    const double wi = wave_total_f64(idm);
+                    if (lane == 0) s_idm[wv] = wi;
+                }
+                __syncthreads();
+                if (t == 0) {
+                    double *a = s_sums[li * 4 + oi];
+                    a[0] = (double)s_acc[0]; a[1] = (double)s_acc[1]; a[2] = (double)s_acc[2]; a[3] = (double)s_acc[3]; a[4] = (double)s_acc[4];
+                    a[5] = (s_idm[0] + s_idm[1]) + (s_idm[2] + s_idm[3]); a[6] = (double)s_acc[5];
+                    a[7] = (double)(long long)s_acc[6] / (double)GW_FIX; a[8] = (double)(long long)s_acc[7] / (double)GW_FIX; a[9] = (double)(long long)s_acc[8] / (double)GW_FIX;
+                }
+                __syncthreads();
+            }
+        }
+        if (t < 16) { // combination t = level * 4 + offset, the column order of texture.rs:81-157
+            double a[GL_NACC];
+#pragma unroll
+            for (int k = 0; k < GL_NACC; ++k) a[k] = s_sums[t][k];
+            glcm_features<true>(a, 0.0, lut, out + i * (int64_t)F + col0 + t * 14, dbg ? dbg + (i * 16 + t) * 6 : nullptr);
+        }
+    }
+}
+
 #ifndef NFX_GL_ROUNDS
 #define NFX_GL_ROUNDS 2
 #endif
@@ -970,6 +1097,7 @@ static size_t glcm_slots_bytes() { return sizeof(double) * 16 * GL_NACC * (size_
 static constexpr int GW_SMALL_K = 6144; // masks up to this many pixels take the small-capacity launch of the wide kernel
 size_t glcm_scratch_bytes(const Job &job)
 {
+    if (job.ps > NFX_WIDE_PS) return glcm_slab_bytes(job.n, job.ps); // k_glcm_slab: count tables and level maps
     if (job.ps > 64) return 256; // k_glcm_wide: the two launches' cursors
     const size_t n = (size_t)(job.n > 0 ? job.n : 1);
     return glcm_slots_bytes() + sizeof(int) * (GL_CLASSES * n + 64);
@@ -1058,6 +1186,19 @@ hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
     hipError_t e = prepare_glcm(ctx);
     if (e != hipSuccess) return e;
     ScopedTiming t(ctx, KS_GLCM);
+    if (job.ps > NFX_WIDE_PS) {
+        const GlcmLuts *hlut = reinterpret_cast<const GlcmLuts *>(ctx->glcm_lut);
+        const unsigned g = (unsigned)(job.n < GS_GRID ? job.n : GS_GRID);
+        unsigned *tab = reinterpret_cast<unsigned *>(scratch);
+        unsigned short *lvl = reinterpret_cast<unsigned short *>(tab + (size_t)g * GS_TAB);
+        if (job.patches_f32)
+            hipLaunchKernelGGL(k_glcm_slab<float>, dim3(g), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const float *>(job.patches), job.mask_rows, hlut, tab, lvl,
+                               job.out, job.F, col0, job.dbg_glcm);
+        else
+            hipLaunchKernelGGL(k_glcm_slab<uint8_t>, dim3(g), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, hlut, tab, lvl,
+                               job.out, job.F, col0, job.dbg_glcm);
+        return hipGetLastError();
+    }
     if (job.ps > 64) {
         const GlcmLuts *wlut = reinterpret_cast<const GlcmLuts *>(ctx->glcm_lut);
         int *cursors = reinterpret_cast<int *>(scratch);

@@ -390,32 +390,35 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
     }
 }
 
-// ---- patch sizes 65..128: one 256-thread workgroup per nucleus (see k_geometry.hip, "patch sizes 65..128") -----------------
-// The level map (0xFF outside the mask) sits in LDS as bytes; every thread walks its pixels, and a pixel that starts a run
-// (its predecessor along the direction is outside the mask or of another level) follows the run for at most 16 steps and bumps
-// one of the 384 bins; wave 0 turns the bins into the 17 features with the same code as the wave kernel.
-template <typename T>
+// ---- patch sizes 65..512: one 256-thread workgroup per nucleus (see k_geometry.hip, "patch sizes 65..128" and "129..512") ----
+// The level map (0xFF outside the mask) is kept as bytes -- in LDS up to 128 x 128, in the workgroup's slice of a scratch buffer in
+// device memory above (GLOBAL_MAP: 256 KB at 512 x 512; written and read by this workgroup only, with workgroup barriers between);
+// every thread walks its pixels, and a pixel that starts a run (its predecessor along the direction is outside the mask or of
+// another level) follows the run for at most 16 steps and bumps one of the 384 bins; wave 0 turns the bins into the 17 features
+// with the same code as the wave kernel.
+template <typename T, bool GLOBAL_MAP>
 __global__ __launch_bounds__(256) void k_glrlm_wide(int64_t n, int ps, const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
-                                                    float *__restrict__ out, int F, int col0, uint32_t *__restrict__ dbg_bins)
+                                                    float *__restrict__ out, int F, int col0, uint32_t *__restrict__ dbg_bins, uint8_t *__restrict__ map_scratch)
 {
-    __shared__ uint8_t s_q[NFX_MAX_PATCH_SIZE * NFX_MAX_PATCH_SIZE];
+    __shared__ uint8_t s_q_lds[GLOBAL_MAP ? 16 : NFX_WIDE_PS * NFX_WIDE_PS];
     __shared__ unsigned s_R[RL_BINS];
     __shared__ int s_np;
     const int t = threadIdx.x, lane = t & 63;
-    const int P = ps * ps;
+    const int P = ps * ps, W = (ps + 63) >> 6;
+    uint8_t *const s_q = GLOBAL_MAP ? map_scratch + (size_t)blockIdx.x * P : s_q_lds;
     RlWeights Wt;
     Wt.init(lane);
     for (int k = t; k < RL_BINS; k += 256) s_R[k] = 0u;
     for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
         if (t == 0) s_np = 0;
-        __syncthreads();
+        __syncthreads(); // (also: every thread is done with the previous nucleus's map)
         const T *pp = patches + (size_t)i * 3 * P;
-        const uint64_t *rows = mask_rows + (size_t)i * ps * 2;
+        const uint64_t *rows = mask_rows + (size_t)i * ps * W;
         int np = 0;
         for (int p = t; p < P; p += 256) {
             const int r = p / ps, c = p - r * ps;
             unsigned q = 0xFFu;
-            if ((rows[2 * r + (c >> 6)] >> (c & 63)) & 1ull) {
+            if ((rows[W * r + (c >> 6)] >> (c & 63)) & 1ull) {
                 float gs = RPx<T>::ld(pp, p) + RPx<T>::ld(pp, P + p);
                 gs = gs + RPx<T>::ld(pp, 2 * P + p);
                 gs = sizeof(T) == 1 ? third_of_u8_sum(gs) : gs / 3.0f; // texture.rs:189
@@ -449,18 +452,38 @@ __global__ __launch_bounds__(256) void k_glrlm_wide(int64_t n, int ps, const T *
     }
 }
 
-hipError_t launch_glrlm(nfx_ctx *ctx, const Job &job, int col0)
+static constexpr int RL_HUGE_GRID = 512; // workgroups of the launch over patches above 128 x 128: one map slice each
+size_t glrlm_scratch_bytes(const Job &job)
+{
+    if (job.ps <= NFX_WIDE_PS) return 0;
+    const size_t g = (size_t)(job.n < RL_HUGE_GRID ? (job.n > 0 ? job.n : 1) : RL_HUGE_GRID);
+    return g * (size_t)job.ps * job.ps + 256;
+}
+
+hipError_t launch_glrlm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
 {
     if (job.n == 0) return hipSuccess;
     ScopedTiming t(ctx, KS_GLRLM);
+    if (job.ps > NFX_WIDE_PS) {
+        if (!scratch) return hipErrorInvalidValue;
+        const unsigned hgrid = (unsigned)(job.n < RL_HUGE_GRID ? job.n : RL_HUGE_GRID);
+        uint8_t *map = reinterpret_cast<uint8_t *>(scratch);
+        if (job.patches_f32)
+            hipLaunchKernelGGL((k_glrlm_wide<float, true>), dim3(hgrid), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const float *>(job.patches),
+                               job.mask_rows, job.out, job.F, col0, job.dbg_glrlm, map);
+        else
+            hipLaunchKernelGGL((k_glrlm_wide<uint8_t, true>), dim3(hgrid), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const uint8_t *>(job.patches),
+                               job.mask_rows, job.out, job.F, col0, job.dbg_glrlm, map);
+        return hipGetLastError();
+    }
     if (job.ps > NFX_ROW_WORD_PS) {
         const unsigned wgrid = (unsigned)(job.n < 256 * 8 ? job.n : 256 * 8);
         if (job.patches_f32)
-            hipLaunchKernelGGL(k_glrlm_wide<float>, dim3(wgrid), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const float *>(job.patches),
-                               job.mask_rows, job.out, job.F, col0, job.dbg_glrlm);
+            hipLaunchKernelGGL((k_glrlm_wide<float, false>), dim3(wgrid), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const float *>(job.patches),
+                               job.mask_rows, job.out, job.F, col0, job.dbg_glrlm, (uint8_t *)nullptr);
         else
-            hipLaunchKernelGGL(k_glrlm_wide<uint8_t>, dim3(wgrid), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const uint8_t *>(job.patches),
-                               job.mask_rows, job.out, job.F, col0, job.dbg_glrlm);
+            hipLaunchKernelGGL((k_glrlm_wide<uint8_t, false>), dim3(wgrid), dim3(256), 0, ctx->stream, job.n, job.ps, reinterpret_cast<const uint8_t *>(job.patches),
+                               job.mask_rows, job.out, job.F, col0, job.dbg_glrlm, (uint8_t *)nullptr);
         return hipGetLastError();
     }
     const int64_t maxb = 256 * 7 * 2, need = (job.n + 3) / 4; // 7 workgroups (28 waves) fit a CU's LDS

@@ -392,7 +392,7 @@ nfx_status check_common(nfx_ctx *ctx, int64_t n, int64_t nv, int ps)
     if (!ctx) return NFX_ERR_INVALID_ARGUMENT;
     if (n < 0 || nv < 0) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "negative size");
     if (ps < 1) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "patch size must be >= 1");
-    if (ps > NFX_MAX_PATCH_SIZE) return fail(ctx, NFX_ERR_UNSUPPORTED, "patch size > 128 is not supported");
+    if (ps > NFX_MAX_PATCH_SIZE) return fail(ctx, NFX_ERR_UNSUPPORTED, "patch size > " + std::to_string(NFX_MAX_PATCH_SIZE) + " is not supported");
     if (nv > 0xFFFFFFFFll) return fail(ctx, NFX_ERR_UNSUPPORTED, "more than 2^32-1 vertices in one call");
     return NFX_OK;
 }
@@ -446,6 +446,7 @@ size_t extract_ws_bytes(const int *sets, int n_sets, int64_t n, int64_t nv, int 
     b += (size_t)count_set(sets, n_sets, NFX_SET_COLOR) * al(color_scratch_bytes(j)); // a repeated "color" gets scratch of its own
     if (count_set(sets, n_sets, NFX_SET_GLCM)) b += al(glcm_scratch_bytes(j));
     if (count_set(sets, n_sets, NFX_SET_GABOR)) b += al(gabor_scratch_bytes(j));
+    if (count_set(sets, n_sets, NFX_SET_GLRLM)) b += al(glrlm_scratch_bytes(j));
     return b + 4096;
 }
 
@@ -508,7 +509,7 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
 
     int col = 0;
     bool geo_done = false;
-    void *poly_scr = nullptr, *glcm_scr = nullptr, *gabor_scr = nullptr;
+    void *poly_scr = nullptr, *glcm_scr = nullptr, *gabor_scr = nullptr, *glrlm_scr = nullptr;
     for (int s = 0; s < n_sets; ++s) {
         switch (sets[s]) {
         case NFX_SET_GEOMETRY: {
@@ -536,7 +537,12 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
             NFX_HIP(ctx, launch_glcm(ctx, job, col, glcm_scr));
             break;
         }
-        case NFX_SET_GLRLM: NFX_HIP(ctx, launch_glrlm(ctx, job, col)); break;
+        case NFX_SET_GLRLM: {
+            if (!glrlm_scr && glrlm_scratch_bytes(job)) glrlm_scr = ws_alloc(ctx, glrlm_scratch_bytes(job)); // (level maps of patches above 128 x 128 only)
+            if (!glrlm_scr && glrlm_scratch_bytes(job)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
+            NFX_HIP(ctx, launch_glrlm(ctx, job, col, glrlm_scr));
+            break;
+        }
         case NFX_SET_GABOR: {
             if (!gabor_scr) gabor_scr = ws_alloc(ctx, gabor_scratch_bytes(job)); // (a repeated "gabor" runs after the first on the same stream: shared)
             if (!gabor_scr && gabor_scratch_bytes(job)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
@@ -587,6 +593,7 @@ static size_t trait_ws_bytes(int set, int64_t n, int64_t nv, int ps)
     if (set == NFX_SET_COLOR) need += al(color_scratch_bytes(job));
     if (set == NFX_SET_GLCM) need += al(glcm_scratch_bytes(job));
     if (set == NFX_SET_GABOR) need += al(gabor_scratch_bytes(job));
+    if (set == NFX_SET_GLRLM) need += al(glrlm_scratch_bytes(job));
     return need;
 }
 
@@ -770,7 +777,12 @@ nfx_status nfx_compute_features_batched(nfx_ctx *ctx, int set, int64_t n, int64_
         NFX_HIP(ctx, launch_glcm(ctx, job, 0, scr));
         break;
     }
-    case NFX_SET_GLRLM: NFX_HIP(ctx, launch_glrlm(ctx, job, 0)); break;
+    case NFX_SET_GLRLM: {
+        void *scr = glrlm_scratch_bytes(job) ? ws_alloc(ctx, glrlm_scratch_bytes(job)) : nullptr;
+        if (!scr && glrlm_scratch_bytes(job)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+        NFX_HIP(ctx, launch_glrlm(ctx, job, 0, scr));
+        break;
+    }
     case NFX_SET_GABOR: {
         void *scr = ws_alloc(ctx, gabor_scratch_bytes(job));
         if (!scr && gabor_scratch_bytes(job)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
@@ -882,7 +894,7 @@ nfx_status nfx_debug_texture_counts(nfx_ctx *ctx, int64_t n, int64_t nv, const u
     const size_t gb = sizeof(int64_t) * 96 * (size_t)n, rb = sizeof(uint32_t) * 4 * 384 * (size_t)n, fb = sizeof(float) * 224 * (size_t)n;
     Job job;
     job.n = n; job.ps = ps; job.batch_size = 100;
-    size_t need = al(8 * nv + 8) + al(8 * (size_t)n * ps * mask_words_per_row(ps) + 8) + al(glcm_scratch_bytes(job)) + al(fb + 8) + 4096;
+    size_t need = al(8 * nv + 8) + al(8 * (size_t)n * ps * mask_words_per_row(ps) + 8) + al(glcm_scratch_bytes(job)) + al(glrlm_scratch_bytes(job)) + al(fb + 8) + 4096;
     if (mem == NFX_MEM_HOST) {
         if ((st = check_offsets(ctx, ring_offsets, n, nv, "ring_offsets")) != NFX_OK) return st;
         need += al(4 * (n + 1)) + al(8 * nv + 8) + al(3 * n * P + 8) + al(gb + 8) + al(rb + 8);
@@ -902,7 +914,8 @@ nfx_status nfx_debug_texture_counts(nfx_ctx *ctx, int64_t n, int64_t nv, const u
     uint64_t *rows = (uint64_t *)ws_alloc(ctx, 8 * (size_t)n * ps * mask_words_per_row(ps) + 8);
     float *feat = (float *)ws_alloc(ctx, fb + 8); // the feature columns themselves are computed and dropped
     void *scr = ws_alloc(ctx, glcm_scratch_bytes(job));
-    if (!centred || !rows || !feat || !scr) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+    void *rl_scr = glrlm_scratch_bytes(job) ? ws_alloc(ctx, glrlm_scratch_bytes(job)) : nullptr;
+    if (!centred || !rows || !feat || !scr || (!rl_scr && glrlm_scratch_bytes(job))) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
     const int glcm_set = NFX_SET_GLCM;
     if ((st = prepare_sets(ctx, &glcm_set, 1)) != NFX_OK) return st;
     NFX_HIP(ctx, launch_preprocess(ctx, n, ring_offsets, ring_xy, nullptr, centred));
@@ -910,7 +923,7 @@ nfx_status nfx_debug_texture_counts(nfx_ctx *ctx, int64_t n, int64_t nv, const u
     job.poly_off = ring_offsets; job.poly_xy = centred; job.patches = patches_u8; job.patches_f32 = false; job.mask_rows = rows;
     job.out = feat; job.F = 224; job.dbg_glcm = d_g; job.dbg_glrlm = d_r;
     if (d_g) NFX_HIP(ctx, launch_glcm(ctx, job, 0, scr));
-    if (d_r) NFX_HIP(ctx, launch_glrlm(ctx, job, 0));
+    if (d_r) NFX_HIP(ctx, launch_glrlm(ctx, job, 0, rl_scr));
     if (mem == NFX_MEM_HOST) {
         if (glcm_sums && n) NFX_HIP(ctx, hipMemcpyAsync(glcm_sums, d_g, gb, hipMemcpyDeviceToHost, ctx->stream));
         if (glrlm_bins && n) NFX_HIP(ctx, hipMemcpyAsync(glrlm_bins, d_r, rb, hipMemcpyDeviceToHost, ctx->stream));

@@ -27,9 +27,13 @@ extern const char *const kKernelSlotNames[KS_COUNT];
 
 static constexpr int kNumCols[NFX_SET_COUNT] = {12, 18, 224, 68, 96};
 // The fast kernels hold one mask row in one lane's 64-bit word; patches above this size take the "wide" family
-// (one 256-thread workgroup per nucleus, mask rows of two words), up to NFX_MAX_PATCH_SIZE
+// (one 256-thread workgroup per nucleus, mask rows of two words, lists and level maps in LDS) up to NFX_WIDE_PS, and above
+// that the "huge" family (the same workgroup-per-nucleus shape, rows of up to NFX_MAX_PATCH_SIZE / 64 words, maps and count
+// tables in global scratch memory) up to NFX_MAX_PATCH_SIZE
 #define NFX_ROW_WORD_PS 64
-static inline int mask_words_per_row(int ps) { return ps > NFX_ROW_WORD_PS ? 2 : 1; }
+#define NFX_WIDE_PS 128
+#define NFX_MAX_ROW_WORDS (NFX_MAX_PATCH_SIZE / 64)
+static inline int mask_words_per_row(int ps) { return (ps + 63) / 64; }
 
 struct Timing {
     hipEvent_t start, stop;
@@ -193,7 +197,8 @@ hipError_t launch_color(nfx_ctx *ctx, const Job &job, int col0, void *scratch);
 size_t color_scratch_bytes(const Job &job);
 hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch);
 size_t glcm_scratch_bytes(const Job &job);
-hipError_t launch_glrlm(nfx_ctx *ctx, const Job &job, int col0);
+hipError_t launch_glrlm(nfx_ctx *ctx, const Job &job, int col0, void *scratch);
+size_t glrlm_scratch_bytes(const Job &job); // 0 up to NFX_WIDE_PS
 hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0, void *scratch);
 size_t gabor_scratch_bytes(const Job &job);
 // device tables of a feature set (no-ops once built).  Building allocates and copies synchronously: nfx_ctx_reserve does it

@@ -171,7 +171,7 @@ int main(int argc, char **argv)
     }
     if (n_sets == 0) { log_error("No feature set selected (the reference panics on features[0], main.rs:76)"); return 1; }
     sets.resize((size_t)n_sets);
-    if (args.patch_size < 1 || args.patch_size > NFX_MAX_PATCH_SIZE) { log_error("patch size must be in 1..128 for the MI355X engine"); return 1; }
+    if (args.patch_size < 1 || args.patch_size > NFX_MAX_PATCH_SIZE) { log_error("patch size must be in 1.." + std::to_string(NFX_MAX_PATCH_SIZE) + " for the MI355X engine"); return 1; }
     if (args.batch_size < 1) { log_error("batch size must be >= 1"); return 1; }
     // validate_gpu (args.rs:173-183): here a GPU is always required
     std::vector<int> gpus = args.gpus;

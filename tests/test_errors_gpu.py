@@ -40,7 +40,7 @@ def test_invalid_arguments_are_reported_not_executed(nfx):
         (dict(sets=[]), INVALID, "no feature set"),
         (dict(batch=0), INVALID, "batch_size"),
         (dict(ps=0), INVALID, "patch size"),
-        (dict(ps=129), UNSUPPORTED, "patch size > 128"),
+        (dict(ps=513), UNSUPPORTED, "patch size > 512"),
         (dict(n=-1), INVALID, "negative"),
         (dict(nv=int(off[-1]) - 1), INVALID, "ring_offsets[n] != n_vertices"),
         (dict(out=False), INVALID, "null"),
