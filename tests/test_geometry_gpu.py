@@ -88,7 +88,7 @@ def test_geometry_trait_entry_f32_masks(nfx, ctx):
 def test_unsupported_patch_size_is_an_error(nfx, ctx):
     off, xy = par.edge_case_rings(64)
     with pytest.raises(nfx.NfxError, match="UNSUPPORTED"):
-        ctx.extract([0], off, xy, None, 129)   # 65..128 run on the wide kernel family (tests/test_wide_patches_gpu.py)
+        ctx.extract([0], off, xy, None, 513)   # 65..128 and 129..512 run on the wide / huge kernel families (tests/test_wide_patches_gpu.py)
 
 
 def test_empty_call(nfx, ctx):
