@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Throughput of the wide kernel family (patch sizes 65..128) per feature set, device-resident inputs (run on the GPU box).
+"""Throughput of the wide (65..128) and huge (129..512) kernel families per feature set, device-resident inputs (run on the GPU box).
     python scripts/wide_throughput.py [ps] [nuclei]"""
 import importlib
 import os
