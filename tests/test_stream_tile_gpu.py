@@ -32,9 +32,10 @@ def _scene(synth, ps, n, H, W, seed, slide_order):
     (33, True, 64, 96, 40, False, 16),    # odd patch size (byte path of the gather)
     (64, False, 96, 48, 2, True, 3),      # batches of three nuclei in random order over two band slots: some batches are gathered in two passes
     (48, False, 64, 24, 1, True, 8),      # ONE band slot (cache_bytes is honoured down to one band): every batch in as many passes as it has bands
+    (136, True, 192, 40, 2, True, 10),    # a patch size of the huge kernel family (129..512): three-word mask rows, halo of 136 rows per band
 ])
 def test_streamed_rows_equal_resident_rows(nfx, synth, ps, slide_order, block, chunk, cache_slots, pinned, B):
-    n, H, W = 310, 520, 700
+    n, H, W = (310, 520, 700) if ps <= 64 else (40, 520, 700)
     off, xy, img = _scene(synth, ps, n, H, W, 23, slide_order)
     e_off, e_xy = par.edge_case_rings(ps)                     # an empty ring among them: NaN centroid, window at the origin
     off, xy = par.concat_rings((off, xy), (e_off, e_xy))
