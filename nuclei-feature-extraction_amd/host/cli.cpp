@@ -193,7 +193,7 @@ int main(int argc, char **argv)
 
     try {
         // load_input_image (main.rs:20-35) beside the geojson: the PNG's inflate is one serial stream (0.73 s for an 8192 x 8192 tile), the
-        // geojson one streaming pass (0.31 s for 200 k features) -- two host threads, the wall time of the longer one
+        // geojson one streaming pass (0.31 s for 200 k features on one thread; large files on several) -- the wall time of the longer one
         const std::string sext = extension(args.slide);
         if (sext == "svs" || sext == "jpg" || sext == "jpeg") {
             log_error("." + sext + " slides need OpenSlide / a JPEG decoder, which this image does not have; convert the region to .png");
@@ -218,7 +218,10 @@ int main(int argc, char **argv)
         Polygons poly;
         try {
             const std::vector<uint8_t> gj = read_file(args.geometry);
-            poly = GeoJsonReader(std::string_view(reinterpret_cast<const char *>(gj.data()), gj.size())).parse();
+            // documents of 8 MB and more are parsed by several threads (-t / the hardware's count; geojson.hpp): same polygons, same errors
+            GeoJsonReader reader(std::string_view(reinterpret_cast<const char *>(gj.data()), gj.size()), false, args.thread_count > 0 ? (int)std::min(args.thread_count, 32l) : 0);
+            poly = reader.parse();
+            log_debug("geojson reader: " + std::to_string(reader.threads_used) + " thread(s)");
         } catch (...) { img_thread.join(); throw; }
         log_debug("Loaded geojson in " + std::to_string(now_s() - t0) + " s (" + std::to_string(poly.size()) + " features)");
         img_thread.join();

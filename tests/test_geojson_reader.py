@@ -21,7 +21,10 @@ int main(int argc, char **argv)
     std::ifstream f(argv[1], std::ios::binary);
     std::string text((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     try {
-        nfxhost::Polygons p = nfxhost::GeoJsonReader(text).parse();
+        nfxhost::GeoJsonReader reader(text, false, argc > 2 ? atoi(argv[2]) : 1);
+        if (argc > 2) reader.parallel_min_bytes = 0;   // the threaded path even on a small document
+        nfxhost::Polygons p = reader.parse();
+        if (argc > 2) fprintf(stderr, "threads_used %%d\n", reader.threads_used);
         printf("%%zu\n", p.size());
         for (size_t i = 0; i <= p.size(); ++i) printf("%%u ", p.ring_offsets[i]);
         printf("\n");
@@ -42,13 +45,13 @@ def driver(tmp_path_factory):
     src = d / "driver.cpp"
     src.write_text(DRIVER % HEADER)
     exe = d / "driver"
-    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-o", str(exe), str(src)], check=True)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-pthread", "-o", str(exe), str(src)], check=True)
     return exe
 
 
-def parse(driver, tmp_path, text):
+def parse(driver, tmp_path, text, threads=None):
     (tmp_path / "a.geojson").write_text(text)
-    r = subprocess.run([str(driver), str(tmp_path / "a.geojson")], capture_output=True, text=True)
+    r = subprocess.run([str(driver), str(tmp_path / "a.geojson")] + ([str(threads)] if threads else []), capture_output=True, text=True)
     if r.returncode != 0:
         return r.returncode, r.stderr
     lines = r.stdout.split("\n")
@@ -103,3 +106,44 @@ def test_well_formed_collection(driver, tmp_path):
 def test_rejected_documents(driver, tmp_path, text, message):
     rc, err = parse(driver, tmp_path, text)
     assert rc == 3 and message in err, err
+
+
+def test_threaded_reader_gives_the_serial_readers_result(driver, tmp_path):
+    """Large collections are parsed by several threads (chunk scan for string state and bracket depth, element offsets, runs of
+    features parsed by the same code): polygons identical to the serial reader's, whatever sits in the ignored fields -- brackets,
+    braces, quotes and backslashes inside strings, nested arrays of objects -- and however the chunk boundaries fall."""
+    rng = np.random.default_rng(5)
+    nasty = ['}{][', 'a "quoted" \\ name', '\\', '\\\\"', '{"features":[', 'tail\\', '[[[', 'é\u00e9 \n']
+    feats = []
+    for i in range(1500):
+        nv = int(rng.integers(0, 9))
+        ring = [[float(np.float32(rng.uniform(-1e4, 1e4))), float(np.float32(rng.uniform(-1e4, 1e4)))] for _ in range(nv)]
+        props = {"name": nasty[i % len(nasty)], "list": [{"k": nasty[(i + 3) % len(nasty)], "v": [i, [i, {"d": None}]]}], nasty[(i + 1) % len(nasty)]: i}
+        feats.append(feature(ring, [ring[:2]] if i % 7 == 0 else (), properties=props, id=nasty[(i + 5) % len(nasty)]))
+    doc = {"type": "FeatureCollection", "crs": {"x": [{"y": "]"}]}, "features": feats, "trailer": [{"z": "{"}]}
+    for text in (json.dumps(doc), json.dumps(doc, indent=1)):
+        rc1, (off1, xy1) = parse(driver, tmp_path, text)
+        assert rc1 == 0 and len(off1) == 1501
+        for threads in (2, 5, 16, 31):
+            (tmp_path / "a.geojson").write_text(text)
+            r = subprocess.run([str(driver), str(tmp_path / "a.geojson"), str(threads)], capture_output=True, text=True)
+            assert r.returncode == 0 and f"threads_used {threads}" in r.stderr, r.stderr[-300:]
+            lines = r.stdout.split("\n")
+            assert np.array_equal(np.array(lines[1].split(), np.int64), off1)
+            assert np.array_equal(np.array(lines[2].split(), np.float32).reshape(-1, 2), xy1)
+
+
+@pytest.mark.parametrize("text,message", [
+    ('{"features":[{"bbox":[],"geometry":{"type":"Polygon","coordinates":[[[1,2]]]}},{"geometry":{"type":"Polygon","coordinates":[[[1,2]]]}}]}', "missing field `bbox`"),
+    ('{"features":[{"bbox":[],"geometry":{"type":"Polygon","coordinates":[[[1,2]]]}},7]}', "expected `{`"),
+    ('{"features":[{"bbox":[],"geometry":{"type":"Polygon","coordinates":[[[1,2]]]}} {"bbox":[],"geometry":{"type":"Polygon","coordinates":[[[1,2]]]}}]}', "expected `]`"),
+    ('{"features":[{"bbox":[],"geometry":{"type":"Polygon","coordinates":[[[1,2]]]}},]}', "expected `{`"),
+    ('{"features":[x{"bbox":[],"geometry":{"type":"Polygon","coordinates":[[[1,2]]]}}]}', "expected `{`"),
+    ('{"features":[{"bbox":[],"geometry":{"type":"Polygon","coordinates":[[[1,2]]]}}', "expected"),
+])
+def test_threaded_reader_reports_errors_as_the_serial_reader_does(driver, tmp_path, text, message):
+    """Anything the threaded attempt cannot make sense of is parsed again serially: same message, same byte offset."""
+    rc1, err1 = parse(driver, tmp_path, text)
+    rc4, err4 = parse(driver, tmp_path, text, threads=4)
+    assert rc1 == 3 and message in err1, err1
+    assert rc4 == 3 and err4.strip().splitlines()[-1] == err1.strip().splitlines()[-1], (err1, err4)
