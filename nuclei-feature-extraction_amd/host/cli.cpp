@@ -220,6 +220,7 @@ int main(int argc, char **argv)
             const std::vector<uint8_t> gj = read_file(args.geometry);
             // documents of 8 MB and more are parsed by several threads (-t / the hardware's count; geojson.hpp): same polygons, same errors
             GeoJsonReader reader(std::string_view(reinterpret_cast<const char *>(gj.data()), gj.size()), false, args.thread_count > 0 ? (int)std::min(args.thread_count, 32l) : 0);
+            if (const char *mb = getenv("NFX_GEOJSON_PARALLEL_MIN_BYTES")) reader.parallel_min_bytes = (size_t)strtoull(mb, nullptr, 10); // (tests: the threaded path on a small file)
             poly = reader.parse();
             log_debug("geojson reader: " + std::to_string(reader.threads_used) + " thread(s)");
         } catch (...) { img_thread.join(); throw; }

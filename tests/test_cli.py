@@ -108,6 +108,13 @@ def test_config1_end_to_end_csv(nfx, tmp_path):
     want, cen = orc.extract([0, 1], off, xy, patches, ps, batch_size=100)
     assert [r_[0] for r_ in rows[1:]] == nfx.centroids_to_key_strings(cen)           # utils.rs:226-232
     par.assert_rows_close(got, want, par.column_scales(nfx, [0, 1], ps), what="cli csv")
+    # the same file through the threaded GeoJSON reader (large collections take it by themselves; here it is forced): the same rows
+    out_t = tmp_path / "features_threaded.csv"
+    env = dict(os.environ, NFX_GEOJSON_PARALLEL_MIN_BYTES="0")
+    r = subprocess.run([CLI, "-v", "-t", "5", "-g", "0", str(tmp_path / "nuclei.geojson"), str(tmp_path / "tile.png"), str(out_t), "geometry", "color"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "geojson reader: 5 thread(s)" in r.stderr, r.stderr[-400:]
+    assert open(out_t).read() == open(out).read()
     # refuses to overwrite without -o, accepts with -o (args.rs:147-153)
     assert run(str(tmp_path / "nuclei.geojson"), str(tmp_path / "tile.png"), str(out), "geometry").returncode == 1
     assert run("-o", "-p", "32", "-b", "50", str(tmp_path / "nuclei.geojson"), str(tmp_path / "tile.png"), str(out), "GEOMETRY").returncode == 0
