@@ -10,6 +10,9 @@ import sys
 import numpy as np
 import pytest
 
+# the host code under AddressSanitizer + UndefinedBehaviorSanitizer (CPU build only; any report aborts the driver: the test fails)
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"]
+
 pa = pytest.importorskip("pyarrow")
 import pyarrow.feather  # noqa: E402
 import pyarrow.ipc  # noqa: E402
@@ -66,7 +69,7 @@ def driver(tmp_path_factory):
     src = d / "driver.cpp"
     src.write_text(DRIVER % HEADER)
     exe = d / "driver"
-    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-o", str(exe), str(src)], check=True)
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Werror", *SAN, "-o", str(exe), str(src)], check=True)
     return exe
 
 

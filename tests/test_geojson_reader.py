@@ -8,6 +8,9 @@ import subprocess
 import numpy as np
 import pytest
 
+# the host code under AddressSanitizer + UndefinedBehaviorSanitizer (CPU build only; any report aborts the driver: the test fails)
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"]
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "nuclei-feature-extraction_amd", "host", "geojson.hpp")
 
@@ -45,7 +48,7 @@ def driver(tmp_path_factory):
     src = d / "driver.cpp"
     src.write_text(DRIVER % HEADER)
     exe = d / "driver"
-    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-pthread", "-o", str(exe), str(src)], check=True)
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-pthread", *SAN, "-o", str(exe), str(src)], check=True)
     return exe
 
 
@@ -147,3 +150,17 @@ def test_threaded_reader_reports_errors_as_the_serial_reader_does(driver, tmp_pa
     rc4, err4 = parse(driver, tmp_path, text, threads=4)
     assert rc1 == 3 and message in err1, err1
     assert rc4 == 3 and err4.strip().splitlines()[-1] == err1.strip().splitlines()[-1], (err1, err4)
+
+
+def test_threaded_reader_under_thread_sanitizer(tmp_path_factory, tmp_path):
+    """The four passes share nothing but read-only input, per-thread outputs and the barrier: ThreadSanitizer (CPU build) agrees."""
+    d = tmp_path_factory.mktemp("geojson_tsan")
+    src = d / "driver.cpp"
+    src.write_text(DRIVER % HEADER)
+    exe = d / "driver_tsan"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-pthread", "-fsanitize=thread", "-o", str(exe), str(src)], check=True)
+    feats = [feature([[float(i), 1.5], [2.0, float(i)], [float(i), 1.5]], properties={"n": 'a "b" ] \\'}) for i in range(400)]
+    (tmp_path / "a.geojson").write_text(json.dumps({"features": feats}))
+    r = subprocess.run([str(exe), str(tmp_path / "a.geojson"), "6"], capture_output=True, text=True)
+    assert r.returncode == 0 and "threads_used 6" in r.stderr and "ThreadSanitizer" not in r.stderr, r.stderr[-600:]
+    assert r.stdout.split("\n")[0] == "400"
