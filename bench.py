@@ -345,6 +345,8 @@ def main():
     dev = torch.device("cuda", local_rank % max(1, n_dev))
     # the collective path is taken for N > 1 (or when forced, to rehearse RCCL itself with one rank)
     use_dist = world > 1 or (os.environ.get("NFX_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    wire_cpu = rehearsal          # the gathers travel through host memory (gloo): a rehearsal, or RCCL failed to come up
+    rccl_failure = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL announces itself on stdout ("Librccl path : ...") when its first communicator comes up; stdout carries the
@@ -356,7 +358,20 @@ def main():
             if rehearsal:
                 dist.init_process_group("gloo")
             else:
-                dist.init_process_group("nccl", device_id=dev)
+                try:
+                    dist.init_process_group("nccl", device_id=dev)
+                    probe = torch.ones(1, device=dev)
+                    dist.all_reduce(probe)                      # the first collective brings the communicator up: a failure shows here
+                    torch.cuda.synchronize()
+                    if int(probe.item()) != world:
+                        raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
+                except Exception as e:                          # RCCL did not come up (every rank sees the same environment): the scaling run
+                    rccl_failure = repr(e)[:300]                # still measures sharding and compute, with the rows gathered over gloo through host
+                    print(f"bench.py: RCCL failed on rank {rank} ({rccl_failure}); falling back to gloo through host memory", file=sys.stderr, flush=True)
+                    if dist.is_initialized():
+                        dist.destroy_process_group()
+                    dist.init_process_group("gloo")
+                    wire_cpu = True
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -402,8 +417,8 @@ def main():
             pipeline.extract_streamed(ctx, sets, res.off, res.xy, h_patches, ps, batch_size=B, chunk_nuclei=args.chunk, out=d_out,
                                       host_rows=h_rows, want_centroids=False)
     elif use_dist and args.gather == "rank0":
-        transport = "torch" if rehearsal else args.transport      # (the native gather needs one GPU per rank)
-        sx = D.ShardedExtraction(world * n_local, F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if rehearsal else None,
+        transport = "torch" if wire_cpu else args.transport       # (the native gather needs one GPU per rank and a working RCCL)
+        sx = D.ShardedExtraction(world * n_local, F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if wire_cpu else None,
                                  transport=transport)
         assert (sx.i0, sx.i1) == (rank * n_local, (rank + 1) * n_local)
 
@@ -469,8 +484,8 @@ def main():
     if not args.no_also and not stream_mode and world > 1 and use_dist and 0 < n_strong <= n_local:
         # configs[3]: the SAME n_strong nuclei cut into `world` batch-aligned shards (strong scaling); rank 0's weak-scaling
         # inputs start with exactly those nuclei, so it can check the gathered matrix against its own single-GPU result
-        ssx = D.ShardedExtraction(n_strong, F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if rehearsal else None,
-                                  transport="torch" if rehearsal else args.transport)
+        ssx = D.ShardedExtraction(n_strong, F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if wire_cpu else None,
+                                  transport="torch" if wire_cpu else args.transport)
         rs = Resident(nfx, synth, torch, dev, args.workload, ssx.n_local, ssx.i0, set_names)
         el_s, _ = timed(torch, dist, True, ctx, args.steps, 1, lambda: ssx.step(lambda b0, b1, out: rs.extract(ctx, b0, b1, out, B)),
                         lambda: fence(ssx))
@@ -519,8 +534,8 @@ def main():
         ctx.reserve(r5.sets, r5.n, len(r5.xy), r5.ps, batch_size=B)
         k5 = max(2, args.steps // 2)
         if use_dist:
-            sx5 = D.ShardedExtraction(world * n5, r5.F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if rehearsal else None,
-                                      transport="torch" if rehearsal else args.transport)
+            sx5 = D.ShardedExtraction(world * n5, r5.F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if wire_cpu else None,
+                                      transport="torch" if wire_cpu else args.transport)
             el5, t5 = timed(torch, dist, True, ctx, k5, 1, lambda: sx5.step(lambda b0, b1, out: r5.extract(ctx, b0, b1, out, B)), lambda: fence(sx5))
             ok5 = sx5.verify_transport()
         else:
@@ -549,7 +564,8 @@ def main():
                 " (in its pinned host memory)" if stream_mode else "") + (" -- REHEARSAL on fewer GPUs than ranks" if rehearsal else "")
         elif world > 1:
             sharding = f"index-sharded x{world}, rows gathered to rank 0 " + ("(gloo through host memory: REHEARSAL on fewer GPUs than "
-                                                                             "ranks, not a scaling measurement)" if rehearsal else "(RCCL)")
+                                                                             "ranks, not a scaling measurement)" if rehearsal else
+                                                                             (f"(gloo through host memory: RCCL FAILED to come up -- {rccl_failure})" if rccl_failure else "(RCCL)"))
         line = {
             "metric": "nuclei/sec", "value": round(value, 1), "unit": "nuclei/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
@@ -561,9 +577,10 @@ def main():
                                  "pinned host memory (PCIe-inclusive; NOT the headline metric)",
                        "gen_seconds": round(gen_s, 1), "csrc_stamp": csrc_stamp(),
                        "gather": ("none" if (stream_mode or args.gather == "none") else "rank0") if world > 1 else None,
-                       "transport": (("torch.distributed.gather" if (rehearsal or args.transport == "torch") else "nfx_gather_rows (grouped ncclSend/ncclRecv)")
+                       "transport": (("torch.distributed.gather" if (wire_cpu or args.transport == "torch") else "nfx_gather_rows (grouped ncclSend/ncclRecv)")
                                      if use_dist and not stream_mode and args.gather == "rank0" else None),
-                       "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") if use_dist else None},
+                       "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") if use_dist else None,
+                       "rccl_failure": rccl_failure},
             "roofline": roofline, "cpu_baseline": cpu, "also": also or None,
         }
         if cpu_torch is not None:
