@@ -191,10 +191,9 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
     if (tr) __syncthreads();
     if (g_begin >= g_end) continue;
     const GaborView &V = s_view[view];
-    const int rmin = __builtin_amdgcn_readfirstlane(V.rmin), rmax = __builtin_amdgcn_readfirstlane(V.rmax);
     const int cmin = __builtin_amdgcn_readfirstlane(V.cmin), cmax = __builtin_amdgcn_readfirstlane(V.cmax);
     const int rlo = __builtin_amdgcn_readfirstlane(V.rlo), nrow_rp = __builtin_amdgcn_readfirstlane(V.nrow_rp);
-    const int ncol = cmax - cmin + 1, nrow = rmax - rmin + 1;
+    const int ncol = cmax - cmin + 1;
     // the wave's strip: TSR columns from c0; the strips of the four waves tile [cs, cs + 4 TSR) inside the plane's 64 columns
     int tsr = (ncol + GB_WAVES - 1) / GB_WAVES;
     tsr = tsr < 3 ? 3 : tsr; // 3 .. 16
@@ -205,16 +204,29 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
     const int rr = rlo + (lane < nrow_rp ? lane : nrow_rp - 1);
     const float *src = tr ? &S.g[rr + GB_PAD] : &S.g[rr * GB_GW + c0]; // gray column c-15 sits at apron index c; transposed: column rr
     f2 *du = &S.UW[(rr + GB_PAD) * GB_UW + c0];
-    // column pass geometry: item = (row strip, column of the wave's strip)
+    // column pass geometry: item = (row strip, column of the wave's strip).  The strips are cut from the rows that hold a mask pixel in
+    // THIS WAVE'S columns, not from the bounding box: a round nucleus's outer strips are shorter than its box, and CT -- the rows per
+    // lane, i.e. the wave's cost per pass -- follows the wave's own extent (0.84 of the box-cut strips' rows per lane by a count over the
+    // synthetic nuclei; -1.7 % time).  The row pass keeps the box's rows.  (Cutting every QUARTER of the wave's columns from its own
+    // extent -- 0.70 by the same count -- was built and measured: +4 % time: the items' start rows then differ inside a wave, the window
+    // loads collide in the LDS banks, and the geometry no longer fits the registers.)
+    int rmin_w, nrow_w;
+    {
+        const uint64_t stripmask = ((tsr >= 64 ? ~0ull : ((1ull << tsr) - 1ull)) << c0);
+        const uint64_t rows_w = __ballot((V.wrow[lane] & stripmask) != 0ull);
+        if (rows_w == 0ull) continue; // wave-uniform: no mask pixel in the strip
+        rmin_w = __ffsll((long long)rows_w) - 1;
+        nrow_w = 64 - __clzll((long long)rows_w) - rmin_w;
+    }
     const int nstrip_max = 64 / tsr;                             // 4 .. 21
-    int ct = (nrow + nstrip_max - 1) / nstrip_max;               // 1 .. 16
+    int ct = (nrow_w + nstrip_max - 1) / nstrip_max;             // 1 .. 16
     ct = ct < 2 ? 2 : ct;
-    const int nstrip = (nrow + ct - 1) / ct;
+    const int nstrip = (nrow_w + ct - 1) / ct;
     const int items = nstrip * tsr;                              // <= 64
     const bool item = lane < items;
     const int li = item ? lane : items - 1;
     const int strip = li / tsr, cj = li - strip * tsr;
-    const int r0 = rmin + strip * ct;
+    const int r0 = rmin_w + strip * ct;
     const int c = c0 + cj;                                       // <= 63
     int r0c = r0 < ps - ct ? r0 : ps - ct; // clamped strips overlap: rows below r0 are masked out
     r0c = r0c > 0 ? r0c : 0;
