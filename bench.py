@@ -1,35 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py -- nuclei/sec of the per-nucleus feature path on MI355X (BASELINE.json metric).
+"""bench.py -- nuclei/sec of the per-nucleus feature path on MI355X (BASELINE.json metric: "nuclei/sec (full feature set)").
 
-    python bench.py --gpus N --steps K --warmup W [--workload config3|config2|config5]
+    python bench.py --gpus N --steps K --warmup W [--workload config5|config3|config2] [--inputs streamed|resident]
 
-A "step" is one pass of the hot path (polygon preprocessing + rasterisation + every selected feature
-set, rows gathered on rank 0) over one resident batch of synthetic nuclei.  Inputs are generated
-directly in HBM before the timed region (SURVEY.md §8d generator).
+DEFAULT = the configuration the metric is quoted on, BASELINE.json configs[4]'s per-GPU shard: 1.25 M nuclei, 64 x 64 patches, the full
+feature set (`all`, F = 418), batch 100, THE SLIDE STREAMED -- the nuclei's slide (47 703^2 pixels, 6.83 GB) and their rings start in
+pinned host memory and every step streams them in band by band, overlapped with compute (nfx_extract_tile_streamed); a step is timed
+from the first H2D byte to the last feature row in host memory (SURVEY.md §8d's wall-time definition).  `--inputs resident` (the
+default of config3 / config2) times the same hot path with packed patches and rings resident in HBM.
 
-Default workload = BASELINE.json configs[2], the largest single-GPU configuration:
-1M nuclei, 48x48 patches, geometry+color+glcm (F=254), batch 100.
+A "step" is one pass of the hot path (polygon preprocessing + rasterisation + every selected feature set) over one rank's nuclei.
+Synthetic inputs are generated on the GPU before the timed region (SURVEY.md §8d generator).
 
-N > 1 (`--gpus N`): started bare, this script launches its own N ranks as child processes
-(torch.distributed.run, one per GPU) before it touches a GPU itself; started by torch.distributed.run it is
-one of those ranks.  The headline is WEAK scaling -- every rank holds its own index shard of `--nuclei`
-nuclei (shard boundaries are multiples of the reference batch size), extracts it with no
-data-path collective and its rows are gathered to rank 0 over RCCL (the reference's vstack under a mutex,
-main.rs:96-108) through `distributed.ShardedExtraction`, the class the CPU gloo test drives.  The same run
-then times BASELINE.json configs[3] (the 1M nuclei of configs[2] cut into N shards: strong scaling) and rank 0
-checks that the gathered matrix is bit-identical to its own single-GPU extraction of the same nuclei; both
-go into the line's `also` object.
+N > 1 (`--gpus N`): started bare, this script launches its own N ranks as child processes (torch.distributed.run, one per GPU) before
+it touches a GPU itself; started by torch.distributed.run it is one of those ranks.  Nuclei are index-sharded on reference-batch
+boundaries, no data-path collective during extraction.  Top line = WEAK scaling of the streamed shard: every rank
+streams its own 1.25 M-nucleus slide over its own host link and its kernels write its rows into ONE host matrix shared by the
+ranks (the reference's vstack under a mutex, main.rs:96-108, as N parallel PCIe streams: no gather step is left when the
+destination is host memory).  The RCCL gather over xGMI (rows resident in HBM, gathered to rank 0: distributed.ShardedExtraction)
+is measured in the same run: `also.weak_config3_rccl_gather`, `also.strong_scaling_config4` (BASELINE configs[3], gathered matrix
+checked bit for bit against rank 0's own single-GPU rows) and `also.full_feature_set_resident`.
 
 The one JSON line also carries
-  roofline     -- the dominant kernel's algorithmic bytes / its average launch time (HIP events on the
-                  engine's stream, measured live in this process) against the HBM peak, plus the VALU issue
-                  rate of the same kernel from the committed SQ counter summary (if taken on this csrc/);
-  cpu_baseline -- the CPU oracle (oracle/nfx_oracle.c, a C/OpenMP port of the reference's arithmetic)
-                  timed on this host on a bounded sample of the same workload;
-  also         -- N = 1: the full-feature-set rate of the configs[4] per-GPU shard (the metric's "full feature
-                  set") with its own roofline, and the PCIe-inclusive rate of the headline workload (patches
-                  streamed from pinned host memory, rows copied back to pinned host memory, all inside the
-                  timed region: SURVEY.md §8d's wall-time definition).
+  roofline     -- the dominant kernel's algorithmic bytes / its average launch time (HIP events on the streams the kernels run on,
+                  measured live in this process) against the HBM peak (`hbm`), the unit that really limits it from the committed
+                  counter summary when that was taken on this csrc/ (`lds` incl. conflict_free_frac / `issue`), the dominant
+                  kernel's HBM traffic and `traffic_step`: the whole step's traffic against its algorithmic bytes;
+  cpu_baseline -- kind "aten-twin": the reference's libtorch-CPU tensor programs restated op for op on torch-CPU (tests/_torch_twin.py,
+                  one process per core, batch 100; a bounded prefix, extrapolated); `cpu_baseline_port`: the C/OpenMP oracle port
+                  (oracle/nfx_oracle.c) on a bounded sample -- both on this host's cores, rank 0 at N = 1 only;
+  also         -- N = 1: configs[2] resident (the previous rounds' headline) with its own roofline, configs[2] with its slide
+                  streamed, the full feature set resident with its own roofline.
 """
 import argparse
 import hashlib
@@ -46,10 +47,10 @@ sys.path.insert(0, ROOT)
 PKG = "nuclei-feature-extraction_amd"
 
 WORKLOADS = {
-    # name: (nuclei per GPU, patch size, feature sets, BASELINE.json config it is, seed index)
-    "config2": (100_000, 32, ["geometry"], "configs[1]: 100k nuclei, 32x32, geometry", 1),
-    "config3": (1_000_000, 48, ["geometry", "color", "glcm"], "configs[2]: 1M nuclei, 48x48, geometry+color+glcm", 2),
-    "config5": (1_250_000, 64, ["all"], "configs[4] per-GPU shard: 1.25M nuclei, 64x64, all", 4),
+    # name: (nuclei per GPU, patch size, feature sets, BASELINE.json config it is, seed index, default inputs)
+    "config2": (100_000, 32, ["geometry"], "configs[1]: 100k nuclei, 32x32, geometry", 1, "resident"),
+    "config3": (1_000_000, 48, ["geometry", "color", "glcm"], "configs[2]: 1M nuclei, 48x48, geometry+color+glcm", 2, "resident"),
+    "config5": (1_250_000, 64, ["all"], "configs[4] per-GPU shard: 1.25M nuclei, 64x64, all", 4, "streamed"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles, 2.4 GHz
@@ -60,6 +61,7 @@ VALU_ISSUE_PROBE = 6.7e11
 LDS_CU_CYCLES_PEAK = 256 * 2.4e9          # CU-cycles per second: one LDS pipe per CU
 # which unit limits a kernel when its counters are at hand; everything else on this path is VALU-issue-bound
 LDS_BOUND_KERNELS = ("k_glcm",)
+PMC_NUCLEI = {"config2": 100_000, "config3": 1_000_000, "config5": 1_250_000}   # what scripts/profile_round.sh profiles (one launch per step)
 
 
 def csrc_stamp():
@@ -74,9 +76,9 @@ def csrc_stamp():
     return h.hexdigest()[:16]
 
 
-def committed_counters(workload, kernel):
-    """(counter summary of the workload's dominant kernel, source) from profiles/pmc_current.json when it was taken on this build
-    of csrc/ for this workload and kernel, else (None, why)."""
+def committed_counters(workload):
+    """(every timing slot's counter summary of the workload, source) from profiles/pmc_current.json when it was taken on this build of
+    csrc/, else (None, why)."""
     path = os.path.join(ROOT, "profiles", "pmc_current.json")
     try:
         with open(path) as fh:
@@ -85,10 +87,10 @@ def committed_counters(workload, kernel):
         return None, "no profiles/pmc_current.json"
     if doc.get("csrc_stamp") != csrc_stamp():
         return None, f"profiles/pmc_current.json was taken on csrc {doc.get('csrc_stamp')}, this is {csrc_stamp()}"
-    t = (doc.get(workload) or {}).get("slots", {}).get(kernel)
-    if not t:
-        return None, f"profiles/pmc_current.json holds no counters for {workload}/{kernel}"
-    return t, doc.get("source", "profiles/pmc_current.json")
+    slots = (doc.get(workload) or {}).get("slots")
+    if not slots:
+        return None, f"profiles/pmc_current.json holds no counters for {workload}"
+    return slots, doc.get("source", "profiles/pmc_current.json")
 
 
 def parse_args():
@@ -96,38 +98,38 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="config5", choices=sorted(WORKLOADS))
+    ap.add_argument("--inputs", default="auto", choices=["auto", "streamed", "resident"],
+                    help="streamed (default of config5, the metric's configuration): slide and rings start in pinned host memory, every step streams "
+                         "the slide in band by band and leaves the rows in host memory (first H2D byte -> last row on the host); resident "
+                         "(default of config3 / config2): packed patches + rings in HBM before the timed region, rows left in HBM")
     ap.add_argument("--nuclei", type=int, default=0, help="nuclei per GPU (default: the workload's)")
     ap.add_argument("--batch-size", type=int, default=100)
     ap.add_argument("--sets", default="", help="override the workload's feature sets (comma separated; experiments only)")
-    ap.add_argument("--h2d", default="resident", choices=["resident", "stream"],
-                    help="resident (default, the metric): inputs in HBM before the timed region; stream: patches start in pinned "
-                         "host memory, every step streams them in and the rows back out (PCIe-inclusive rate, DESIGN.md)")
-    ap.add_argument("--gather-slices", type=int, default=4, help="N>1: slices per step whose row gather overlaps the next slice's compute")
-    ap.add_argument("--chunk", type=int, default=100_000, help="nuclei per streamed chunk (--h2d stream)")
+    ap.add_argument("--gather-slices", type=int, default=4, help="N>1, resident legs: slices per step whose row gather overlaps the next slice's compute")
+    ap.add_argument("--chunk", type=int, default=0, help="nuclei per streamed chunk (0: the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements of the `also` object")
     ap.add_argument("--strong-nuclei", type=int, default=0,
-                    help="N>1: total nuclei of the strong-scaling (configs[3]) measurement; default: the workload's size when the headline "
-                         "runs at full size, else skipped")
-    ap.add_argument("--full-set-nuclei", type=int, default=0,
-                    help="nuclei per GPU of the full-feature-set (configs[4] shard) measurement; default: 1.25M when the headline runs at "
-                         "full size, else skipped")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+                    help="N>1: total nuclei of the strong-scaling (configs[3]) measurement; default: 1M when the top line runs at full size, else skipped")
+    ap.add_argument("--also-nuclei", type=int, default=0,
+                    help="nuclei per GPU of the secondary legs (config3 resident / streamed, full set resident); default: each workload's own "
+                         "size when the top line runs at full size, else skipped")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of each CPU baseline's sample")
     ap.add_argument("--gather", default="rank0", choices=["rank0", "none"],
-                    help="N>1: rank0 (default) = every rank's rows are gathered to rank 0 inside the timed region (the reference's vstack, "
-                         "main.rs:96-108); none = rows stay on the rank that computed them (compute-only scaling).  With rank0 the line also "
-                         "carries `also.weak_scaling_compute_only`, measured in the same run")
+                    help="N>1, resident legs: rank0 (default) = every rank's rows are gathered to rank 0 inside the timed region (the reference's "
+                         "vstack, main.rs:96-108); none = rows stay on the rank that computed them")
     ap.add_argument("--transport", default="torch", choices=["torch", "nfx"],
-                    help="N>1: what carries the rows to rank 0 -- torch.distributed.gather (c10d over RCCL; default) or the engine's own "
-                         "nfx_gather_rows (include/nfx.h: grouped ncclSend / ncclRecv below any framework; torch.distributed only hands out the "
-                         "communicator id; has only ever run with one rank -- tests/test_comm_gpu.py needs two GPUs for more -- so unverified for N>1)")
+                    help="N>1, resident legs: what carries the rows to rank 0 -- torch.distributed.gather (c10d over RCCL; default) or the engine's "
+                         "own nfx_gather_rows (include/nfx.h: grouped ncclSend / ncclRecv below any framework; has only ever run with one rank -- "
+                         "tests/test_comm_gpu.py needs two GPUs for more -- so unverified for N>1)")
     ap.add_argument("--ipc-legacy", default="env", choices=["env", "0", "1"],
                     help="N>1: HSA_ENABLE_IPC_MODE_LEGACY for the ranks (RCCL peer access across processes).  env (default) = whatever the "
                          "environment holds, 0 if it holds nothing (dmabuf IPC: what this pool's host driver supports); recorded in the line")
     return ap.parse_args()
 
 
+# ---- inputs -------------------------------------------------------------------------------------------------------------------------
 class Resident:
     """One workload's synthetic inputs resident in HBM (nuclei [i0, i0+n) of the workload's seed stream)."""
 
@@ -161,7 +163,63 @@ class Resident:
                     batch_size=batch_size, out=out, want_centroids=False)
 
 
-def timed(torch, dist, use_dist, ctx, steps, warmup, step, fence):
+class StreamedSlide:
+    """BASELINE configs[4]'s input path for one rank: nuclei [i0, i0+n) and THEIR slide (side ceil(sqrt(n (ps/1.5)^2)); nuclei in
+    slide order, as segmentation tools emit them) in pinned host memory, plus the rows of the same slide RESIDENT in HBM
+    (nfx_extract_tile) that every streamed step has to reproduce bit for bit."""
+
+    def __init__(self, nfx, synth, torch, ctx, dev, workload, n, i0, B, set_names=None):
+        _, self.ps, names, self.desc, sidx, _ = WORKLOADS[workload]
+        self.sets = nfx.parse_feature_sets(set_names or names)
+        self.F = sum(nfx.num_columns(s) for s in self.sets)
+        self.n, self.B = n, B
+        ps = self.ps
+        seed = synth.SEED_BASE + sidx
+        self.T = T = synth.tile_side(n, ps)
+        t0 = time.time()
+        cx, cy = synth.centres_slide_order(seed, i0, n, n, ps, T, T, slide_i0=i0)
+        self.off, self.xy = synth.polygons(seed, i0, n, ps, cx, cy)
+        d_off = torch.from_numpy(self.off.astype(np.int32)).to(dev)
+        d_xy = torch.from_numpy(self.xy).to(dev)
+        cen, _ = ctx.preprocess_polygons(d_off, d_xy)          # the centroids the engine will address the windows with
+        cen = cen.cpu().numpy()
+        d_p = synth.patches(seed, i0, n, ps, xp=torch, device=dev)
+        tile = synth.tile_from_patches(torch, d_p, cen[:, 0], cen[:, 1], T, T, ps, seed, dev)
+        del d_p
+        torch.cuda.empty_cache()
+        ctx.reserve(self.sets, n, len(self.xy), ps, batch_size=B)
+        ref, _ = ctx.extract_tile(self.sets, d_off, d_xy, tile, ps, batch_size=B)     # the slide resident in HBM: the rows to reproduce
+        torch.cuda.synchronize()
+        self.ref = ref.cpu().numpy()
+        del ref
+        self.h_tile = nfx.pinned_empty((3, T, T), np.uint8)
+        for r0 in range(0, T, 2048):
+            self.h_tile[:, r0:r0 + 2048] = tile[:, r0:r0 + 2048].cpu().numpy()
+        del tile, d_off, d_xy
+        torch.cuda.empty_cache()
+        self.gen_s = time.time() - t0
+        self.bytes_per_nucleus = 3 * ps * ps + 8.0 * len(self.xy) / max(1, n) + 8 + 4 * self.F   # SURVEY.md §8d (the packed-patch unit)
+        self.stats = {}
+
+    def step(self, ctx, rows, chunk=0):
+        self.stats = ctx.extract_tile_streamed(self.sets, self.off, self.xy, self.h_tile, self.ps, batch_size=self.B, chunk_nuclei=chunk, out=rows)[2]
+
+    def describe(self, el, steps, rows):
+        st, n, ps, T = self.stats, self.n, self.ps, self.T
+        wire = st["image_bytes_h2d"] + st["other_bytes_h2d"] + st["rows_bytes_d2h"]
+        packed = 3 * ps * ps + 8.0 * len(self.xy) / n + 4 + 4 * self.F + 8          # what a packed-patch stream would move per nucleus
+        return {"slide": f"{T} x {T} pixels, {3 * T * T / 1e9:.2f} GB, nuclei in slide order, pinned host memory; streamed every step in bands of 2048 rows "
+                         "(contiguous copies overlapped with compute, nfx_extract_tile_streamed); timed from the first H2D byte to the last row on the host "
+                         "(SURVEY.md §8d)",
+                "rows_equal_resident_tile_rows": bool(np.array_equal(np.asarray(rows).view(np.uint32), self.ref.view(np.uint32))),
+                "rows_written_by_the_kernels_into_host_memory": bool(st.get("rows_direct", 0)),
+                "pcie_bytes_per_nucleus": round(wire / n, 1), "pcie_bytes_per_nucleus_packed_patch_stream": round(packed, 1),
+                "link_GBps": round(wire * steps / el / 1e9, 2), "bands_copied": st["blocks_copied"], "bands_total": st["blocks_total"],
+                "chunks": st["chunks"], "image_pinned": bool(st["image_pinned"])}
+
+
+# ---- timing and the roofline object ----------------------------------------------------------------------------------------------------
+def timed(torch, ctl, ctx, steps, warmup, step, fence):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.
     Returns (seconds, per-kernel HIP-event timing of rank-local launches)."""
     for _ in range(warmup):
@@ -177,49 +235,61 @@ def timed(torch, dist, use_dist, ctx, steps, warmup, step, fence):
     elapsed = time.perf_counter() - t0
     timing = ctx.kernel_timing()
     ctx.enable_timing(False)
-    if use_dist:
-        el = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
-        if dist.get_backend() == "gloo":
-            el = el.cpu()
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    if ctl is not None:
+        el = torch.tensor([elapsed], dtype=torch.float64)
+        ctl.all_reduce(el, op=ctl.ReduceOp.MAX)     # the control group is gloo: a host tensor
         elapsed = float(el.item())
     return elapsed, timing
 
 
-def roofline_of(timing, steps, res, workload, full_size):
-    """The dominant kernel against the unit that limits it.  `hbm` (always present) is the figure the metric asks for: algorithmic
-    bytes per launch / average launch time / 8 TB/s.  When the committed counter summary was taken on this very csrc/, the top-level
-    bound / achieved / peak / frac describe the unit that really saturates first -- the LDS pipe for k_glcm, VALU issue for the
-    rest -- else they fall back to the HBM figure and say so."""
-    dom_name, dom_t = max(timing.items(), key=lambda kv: kv[1]["total_ms"])
-    dom_avg_ms = dom_t["total_ms"] / max(1, dom_t["launches"])
+def roofline_of(timing, steps, n, bytes_per_nucleus, workload, full_size):
+    """The dominant kernel against the unit that limits it.  `hbm` (always present) is the figure the metric asks for: algorithmic bytes
+    per launch / average launch time / 8 TB/s.  When the committed counter summary was taken on this very csrc/, the top-level bound /
+    achieved / peak / frac describe the unit that really saturates first -- the LDS pipe for k_glcm, VALU issue for the rest -- else they
+    fall back to the HBM figure and say so.  `traffic` is the dominant kernel's counted HBM traffic per launch, `traffic_step` every
+    kernel's of one step against the step's algorithmic bytes (every pixel kernel re-reads the packed patch: DESIGN.md §6)."""
+    live = {k: v for k, v in timing.items() if v["launches"]}
+    dom_name, dom_t = max(live.items(), key=lambda kv: kv[1]["total_ms"])
+    dom_avg_ms = dom_t["total_ms"] / dom_t["launches"]
     launches_per_step = max(1, dom_t["launches"] // max(1, steps))
-    nuclei_per_launch = res.n / launches_per_step    # a kernel launched once per step processes the rank's nuclei
+    nuclei_per_launch = n / launches_per_step        # a kernel launched once per step (or once per streamed chunk) processes that many of the rank's nuclei
     sec = dom_avg_ms * 1e-3
-    achieved = res.bytes_per_nucleus * nuclei_per_launch / sec / 1e9
+    achieved = bytes_per_nucleus * nuclei_per_launch / sec / 1e9
     hbm = {"achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-           "algorithmic_bytes_per_nucleus": round(res.bytes_per_nucleus, 1)}
-    ctr, src = (None, "not the full-size workload") if not full_size else committed_counters(workload, dom_name)
-    issue = lds = None
-    traffic = None
-    if ctr is not None:
-        traffic = ctr.get("traffic_bytes_per_launch")
-        valu = ctr.get("valu_insts_per_nucleus")
-        if valu is not None:
-            rate = valu * nuclei_per_launch / sec
-            issue = {"unit": "valu", "insts_per_nucleus": valu, "achieved": round(rate / 1e9, 2), "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
-                     "rate_unit": "G wave-instructions/s", "frac": round(rate / VALU_ISSUE_PEAK, 4),
-                     "basis": "nominal: 256 CUs x 4 SIMDs x one wave64 instruction per 2 cycles x 2.4 GHz",
-                     "frac_of_probe": round(rate / VALU_ISSUE_PROBE, 4),
-                     "probe_basis": "6.7e11 wave-instructions/s: what scripts/valu_probe.hip reaches with back-to-back independent plain FMAs "
-                                    "(~4 cycles per wave64 instruction and SIMD)"}
-        lds_cyc = ctr.get("lds_idx_active_cycles_per_nucleus")
-        if lds_cyc is not None:
-            busy = lds_cyc * nuclei_per_launch / sec
-            lds = {"unit": "lds", "active_cycles_per_nucleus": lds_cyc, "achieved": round(busy / 1e9, 2), "peak": round(LDS_CU_CYCLES_PEAK / 1e9, 1),
-                   "rate_unit": "G CU-cycles/s with the LDS pipe active (SQ_LDS_IDX_ACTIVE)", "frac": round(busy / LDS_CU_CYCLES_PEAK, 4),
-                   "same_address_conflict_share": ctr.get("lds_addr_conflict_over_idx_active"),
-                   "bank_conflict_share": ctr.get("lds_bank_conflict_over_idx_active")}
+           "algorithmic_bytes_per_nucleus": round(bytes_per_nucleus, 1), "nuclei_per_launch": round(nuclei_per_launch, 1),
+           "launches_per_step": launches_per_step}
+    slots, src = (None, "not the full-size workload") if not full_size else committed_counters(workload)
+    issue = lds = traffic = traffic_step = None
+    if slots is not None:
+        per_nucleus = 1.0 / PMC_NUCLEI[workload]
+        ctr = slots.get(dom_name)
+        if ctr is not None:
+            if ctr.get("traffic_bytes_per_launch") is not None:
+                traffic = int(ctr["traffic_bytes_per_launch"] * per_nucleus * nuclei_per_launch)
+            valu = ctr.get("valu_insts_per_nucleus")
+            if valu is not None:
+                rate = valu * nuclei_per_launch / sec
+                issue = {"unit": "valu", "insts_per_nucleus": valu, "achieved": round(rate / 1e9, 2), "peak": round(VALU_ISSUE_PEAK / 1e9, 1),
+                         "rate_unit": "G wave-instructions/s", "frac": round(rate / VALU_ISSUE_PEAK, 4),
+                         "basis": "nominal: 256 CUs x 4 SIMDs x one wave64 instruction per 2 cycles x 2.4 GHz",
+                         "frac_of_probe": round(rate / VALU_ISSUE_PROBE, 4),
+                         "probe_basis": "6.7e11 wave-instructions/s: what scripts/valu_probe.hip reaches with back-to-back independent plain FMAs "
+                                        "(~4 cycles per wave64 instruction and SIMD)"}
+            lds_cyc = ctr.get("lds_idx_active_cycles_per_nucleus")
+            if lds_cyc is not None:
+                busy = lds_cyc * nuclei_per_launch / sec
+                same = ctr.get("lds_addr_conflict_over_idx_active")
+                lds = {"unit": "lds", "active_cycles_per_nucleus": lds_cyc, "achieved": round(busy / 1e9, 2), "peak": round(LDS_CU_CYCLES_PEAK / 1e9, 1),
+                       "rate_unit": "G CU-cycles/s with the LDS pipe active (SQ_LDS_IDX_ACTIVE)", "frac": round(busy / LDS_CU_CYCLES_PEAK, 4),
+                       "same_address_conflict_share": same, "bank_conflict_share": ctr.get("lds_bank_conflict_over_idx_active"),
+                       # the pipe's busy cycles that move data: busy x (1 - the share spent serialising lanes of one instruction on one address)
+                       "conflict_free_frac": None if same is None else round(busy / LDS_CU_CYCLES_PEAK * (1.0 - same), 4)}
+        tot = sum(s.get("traffic_bytes_per_launch") or 0 for s in slots.values()) * per_nucleus * n
+        alg = bytes_per_nucleus * n
+        traffic_step = {"bytes": int(tot), "algorithmic_bytes": int(alg), "ratio": round(tot / alg, 3),
+                        "what": "HBM bytes of EVERY kernel of one step (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, the resident-input profile of this "
+                                "workload scaled to this step's nuclei) against the step's algorithmic bytes: every pixel-consuming kernel reads the packed "
+                                "patch again (k_hue_batch, k_color, k_glcm, k_glrlm, k_gabor)"}
     top = dict(hbm, bound="hbm")
     if dom_name in LDS_BOUND_KERNELS and lds is not None:
         top = {"bound": "lds", "achieved": lds["achieved"], "peak": lds["peak"], "unit": lds["rate_unit"], "frac": lds["frac"]}
@@ -230,73 +300,152 @@ def roofline_of(timing, steps, res, workload, full_size):
     if top["bound"] == "hbm":
         note += "; bound says hbm only because no counter summary of this csrc/ is committed (counters_source)"
     return {"bound": top["bound"], "kernel": dom_name, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
-            "frac": top["frac"], "traffic": traffic, "hbm": hbm, "issue": issue, "lds": lds, "counters_source": src, "limiter": note,
-            "avg_launch_ms": round(dom_avg_ms, 4),
-            "kernels_ms_per_step": {k: round(v["total_ms"] / steps, 4) for k, v in timing.items() if v["launches"]}}
+            "frac": top["frac"], "traffic": traffic, "traffic_step": traffic_step, "hbm": hbm, "issue": issue, "lds": lds,
+            "counters_source": src, "limiter": note, "avg_launch_ms": round(dom_avg_ms, 4),
+            "kernels_ms_per_step": {k: round(v["total_ms"] / steps, 4) for k, v in live.items()}}
 
 
-def streamed_tile_leg(nfx, synth, torch, dist, ctx, dev, workload, n, i0, B, steps, fence):
-    """BASELINE configs[4]'s input path on one GPU: this rank's nuclei [i0, i0+n) and THEIR slide (side ceil(sqrt(n (ps/1.5)^2)),
-    SURVEY.md §8d; nuclei in slide order, as segmentation tools emit them) start in pinned host memory; every step streams the
-    slide block by block through nfx_extract_tile_streamed -- copies overlapped with compute, rows copied back -- and is timed from the
-    first H2D byte to the last row on the host.  Checked bit for bit against nfx_extract_tile on the same slide resident in HBM."""
-    n_def, ps, set_names, desc, sidx = WORKLOADS[workload]
-    sets = nfx.parse_feature_sets(set_names)
-    F = sum(nfx.num_columns(s) for s in sets)
-    seed = synth.SEED_BASE + sidx
-    T = synth.tile_side(n, ps)
-    t0 = time.time()
-    cx, cy = synth.centres_slide_order(seed, i0, n, n, ps, T, T, slide_i0=i0)
-    off, xy = synth.polygons(seed, i0, n, ps, cx, cy)
-    d_off = torch.from_numpy(off.astype(np.int32)).to(dev)
-    d_xy = torch.from_numpy(xy).to(dev)
-    cen, _ = ctx.preprocess_polygons(d_off, d_xy)          # the centroids the engine will address the windows with
-    cen = cen.cpu().numpy()
-    d_p = synth.patches(seed, i0, n, ps, xp=torch, device=dev)
-    tile = synth.tile_from_patches(torch, d_p, cen[:, 0], cen[:, 1], T, T, ps, seed, dev)
-    del d_p
-    torch.cuda.empty_cache()
-    ctx.reserve(sets, n, len(xy), ps, batch_size=B)
-    ref, _ = ctx.extract_tile(sets, d_off, d_xy, tile, ps, batch_size=B)     # the slide resident in HBM: the rows to reproduce
-    torch.cuda.synchronize()
-    ref = ref.cpu().numpy()
-    h_tile = nfx.pinned_empty((3, T, T), np.uint8)         # pinned for libnfx's own HIP runtime (torch's pinned memory is not)
-    for r0 in range(0, T, 2048):
-        h_tile[:, r0:r0 + 2048] = tile[:, r0:r0 + 2048].cpu().numpy()
-    del tile
-    torch.cuda.empty_cache()
-    h_rows = nfx.pinned_empty((n, F), np.float32)
-    gen_s = time.time() - t0
-    stats = {}
-
-    def step():
-        stats.update(ctx.extract_tile_streamed(sets, off, xy, h_tile, ps, batch_size=B, out=h_rows)[2])
-    el, _ = timed(torch, dist, False, ctx, steps, 1, step, fence)
-    same = bool(np.array_equal(h_rows.view(np.uint32), ref.view(np.uint32)))
-    wire = stats["image_bytes_h2d"] + stats["other_bytes_h2d"] + stats["rows_bytes_d2h"]
-    packed = 3 * ps * ps + 8.0 * len(xy) / n + 4 + 4 * F + 8          # what the packed-patch stream moves per nucleus
-    return {"value": round(n * steps / el, 1), "unit": "nuclei/s", "ms_per_step": round(el / steps * 1e3, 3),
-            "what": f"{desc}: the nuclei's slide ({T} x {T} pixels, {3 * T * T / 1e9:.2f} GB, nuclei in slide order) starts in pinned host memory and is "
-                    "streamed every step in bands of 2048 rows (contiguous copies overlapped with compute, nfx_extract_tile_streamed), rows copied back; timed from the "
-                    "first H2D byte to the last row on the host (SURVEY.md §8d); never the headline value",
-            "rows_equal_resident_tile_rows": same, "pcie_bytes_per_nucleus": round(wire / n, 1),
-            "pcie_bytes_per_nucleus_packed_patch_stream": round(packed, 1), "link_GBps": round(wire * steps / el / 1e9, 2),
-            "blocks_copied": stats["blocks_copied"], "blocks_total": stats["blocks_total"], "chunks": stats["chunks"], "gen_seconds": round(gen_s, 1)}
-
-
-def aten_twin_baseline(args, ps, n):
-    """BASELINE.md §3's "restatement of the libtorch-CPU path" for the geometry workload: tests/_twin_baseline.py as a child
-    process, run to completion BEFORE this process touches a GPU (its workers are forked CPU processes)."""
+# ---- CPU baselines --------------------------------------------------------------------------------------------------------------------
+def aten_twin_baseline(args, workload, set_names):
+    """BASELINE.md §3's "restatement of the libtorch-CPU path": tests/_twin_baseline.py as a child process, run to completion BEFORE this
+    process touches a GPU (its workers are forked CPU processes)."""
     import subprocess
+    _, ps, _, _, sidx, _ = WORKLOADS[workload]
     cores = int(os.environ.get("NFX_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
-    cmd = [sys.executable, os.path.join(ROOT, "tests", "_twin_baseline.py"), "--ps", str(ps), "--nuclei", str(n), "--batch", str(args.batch_size),
-           "--procs", str(cores), "--seconds", str(min(args.cpu_seconds, 12.0))]
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "_twin_baseline.py"), "--ps", str(ps), "--nuclei", str(args.nuclei or WORKLOADS[workload][0]),
+           "--batch", str(args.batch_size), "--procs", str(cores), "--seconds", str(min(args.cpu_seconds, 15.0)), "--seed-index", str(sidx),
+           "--sets", ",".join(set_names)]
     try:
-        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180)
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-        return json.loads(line[-1]) if out.returncode == 0 and line else {"error": (out.stderr or "no output")[-300:]}
+        d = json.loads(line[-1]) if out.returncode == 0 and line else {"error": (out.stderr or "no output")[-300:]}
     except Exception as e:   # a reported baseline, never a reason for the bench to fail
-        return {"error": repr(e)[:300]}
+        d = {"error": repr(e)[:300]}
+    if "value" in d:
+        d["sample"] += " -- a prefix of the workload, the rate extrapolated to the whole of it"
+    return d
+
+
+def oracle_port_baseline(args, nfx, sets, off, xy, patches_u8_of, ps, n_local, got_rows):
+    """The C/OpenMP oracle port on a bounded sample of the same workload; doubles as an end-of-bench parity spot check.
+    patches_u8_of(m) -> numpy u8 [m,3,ps,ps] of the first m nuclei; got_rows(m) -> the GPU's rows of the first m nuclei (numpy)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as orc      # checker / baseline only -- never on the product path
+    import _parity as par
+    B = args.batch_size
+    cores = int(os.environ.get("NFX_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))   # the GPU box grants 16 host cores per GPU
+
+    def run_sample(m):
+        m = min(max(B, (m // B) * B), n_local)
+        pu = patches_u8_of(m)
+        t = time.perf_counter()
+        rows, _ = orc.extract(sets, off[:m + 1], xy[:off[m]], pu, ps, batch_size=B, threads=cores)
+        return m, time.perf_counter() - t, rows
+
+    m0, dt0, _ = run_sample(max(B, cores * B))
+    m1, dt1, rows = run_sample(int(m0 / dt0 * args.cpu_seconds))
+    worst = par.assert_rows_close(got_rows(m1), rows, par.column_scales(nfx, sets, ps), what="bench sample vs oracle")
+    return {"value": round(m1 / dt1, 1), "unit": "nuclei/s", "cores": cores, "kind": "port",
+            "what": "C/OpenMP oracle port of the reference's arithmetic (oracle/nfx_oracle.c): a stronger (faster) CPU baseline than the reference's "
+                    "libtorch-CPU path, whose tensor programs `cpu_baseline` (kind aten-twin) restates",
+            "sample": f"first {m1} nuclei of the same workload, OpenMP over reference batches ({cores} threads), {dt1:.1f} s",
+            "parity_spot_check_worst_scaled_err": float(f"{worst:.3g}")}
+
+
+# ---- ranks ----------------------------------------------------------------------------------------------------------------------------
+class Ranks:
+    """The process group(s) of an N > 1 run.  The CONTROL group is always gloo (barriers, timing reductions, checksums, agreement on
+    failures: host memory, cannot be taken down by a GPU transport problem); the DATA group carries the row gathers: RCCL (backend
+    "nccl") when every rank has a GPU of its own and RCCL came up on ALL ranks, else the gloo group through host memory (a rehearsal
+    on fewer GPUs than ranks, or a degraded run that says so in the line)."""
+
+    def __init__(self, torch, dist, dev, world, rank, rehearsal):
+        import datetime
+        self.dist, self.world, self.rank = dist, world, rank
+        self.rccl_failure = None
+        self.wire_cpu = rehearsal
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+        self.data = None            # None = the default (gloo) group
+        if not rehearsal:
+            ok, why = 1, ""
+            try:
+                grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180), device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe, group=grp)               # the first collective brings the communicator up: a failure shows here
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
+            except Exception as e:
+                ok, why = 0, repr(e)[:300]
+                print(f"bench.py: RCCL failed on rank {rank} ({why})", file=sys.stderr, flush=True)
+            # every rank learns whether ALL ranks have a working communicator, over the control group: nobody switches on its own
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                self.data = grp
+            else:
+                whys = [None] * world
+                dist.all_gather_object(whys, why)
+                self.rccl_failure = next((w for w in whys if w), "a rank failed")
+                self.wire_cpu = True
+                if ok:
+                    try:
+                        dist.destroy_process_group(grp)
+                    except Exception as e:   # a half-built communicator may refuse: the run goes on over gloo
+                        print(f"bench.py: destroying the RCCL group failed on rank {rank}: {e!r}", file=sys.stderr, flush=True)
+                if rank == 0:
+                    print(f"bench.py: RCCL did not come up on every rank ({self.rccl_failure}); the row gathers fall back to gloo through host memory "
+                          "(the line says degraded: true)", file=sys.stderr, flush=True)
+        dist.barrier()
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def close(self):
+        try:
+            self.dist.destroy_process_group()
+        except Exception:
+            pass
+
+
+class SharedRows:
+    """ONE [world * n, F] f32 matrix in host memory that every rank maps (a file in /dev/shm named after the rendezvous port) and whose
+    own slice every rank registers with its HIP runtime: the kernels of rank r write rank r's rows straight into rows [r n, (r+1) n)
+    over rank r's own host link.  The reference's row merge (vstack_mut under a mutex, main.rs:96-108) without a gather step."""
+
+    def __init__(self, nfx, ranks, n, F):
+        self.nfx, self.ranks = nfx, ranks
+        self.path = f"/dev/shm/nfx_rows_{os.environ.get('MASTER_PORT', '0')}_{ranks.world}"
+        shape = (ranks.world * n, F)
+        err = ""
+        if ranks.rank == 0:
+            try:
+                np.lib.format.open_memmap(self.path, mode="w+", dtype=np.float32, shape=shape).flush()
+            except OSError as e:
+                err = repr(e)
+        errs = [None] * ranks.world
+        ranks.dist.all_gather_object(errs, err)
+        self.full = self.mine = None
+        self.registered = False
+        if any(errs):
+            self.why_not = next(e for e in errs if e)
+            return
+        self.full = np.load(self.path, mmap_mode="r+")
+        self.mine = self.full[ranks.rank * n:(ranks.rank + 1) * n]
+        self.registered = nfx.lib().nfx_host_register(self.mine.ctypes.data, self.mine.nbytes) == 0
+        self.why_not = None if self.registered else "hipHostRegister refused the shared mapping (rows staged on the device and copied home instead)"
+
+    def close(self):
+        if self.mine is not None and self.registered:
+            self.nfx.lib().nfx_host_unregister(self.mine.ctypes.data)
+        self.mine = self.full = None
+        self.ranks.barrier()
+        if self.ranks.rank == 0:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
 
 
 def main():
@@ -310,10 +459,15 @@ def main():
         # bare `python bench.py --gpus N`: start the N ranks as children BEFORE this process touches a GPU
         D = importlib.import_module(PKG + ".distributed")
         sys.exit(D.launch_ranks(os.path.abspath(__file__), args.gpus, sys.argv[1:]))
-    # the libtorch-shaped CPU data point of the geometry workload: a child process, finished before any GPU call here
-    cpu_torch = None
-    if args.workload == "config2" and int(world_env or "1") == 1 and not args.no_cpu_baseline and not args.sets:
-        cpu_torch = aten_twin_baseline(args, WORKLOADS["config2"][1], args.nuclei or WORKLOADS["config2"][0])
+    n_def, ps, set_names, wl_desc, _, default_inputs = WORKLOADS[args.workload]
+    if args.sets:
+        set_names = args.sets.split(",")
+        wl_desc += f" [feature sets overridden: {args.sets}]"
+    inputs = default_inputs if args.inputs == "auto" else args.inputs
+    # the libtorch-shaped CPU baseline: a child process, finished before any GPU call here
+    cpu_twin = None
+    if int(world_env or "1") == 1 and not args.no_cpu_baseline:
+        cpu_twin = aten_twin_baseline(args, args.workload, set_names)
 
     import torch
     import torch.distributed as dist
@@ -338,62 +492,44 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     n_dev = torch.cuda.device_count()
-    # fewer GPUs than ranks (a one-GPU box rehearsing the N>1 path): ranks share devices and the collective runs over gloo
+    # fewer GPUs than ranks (a one-GPU box rehearsing the N>1 path): ranks share devices and the collectives run over gloo
     # through host memory -- same sharding, slicing and verification code, NOT a scaling measurement (flagged in the line)
     rehearsal = world > max(1, n_dev)
     torch.cuda.set_device(local_rank % max(1, n_dev))
     dev = torch.device("cuda", local_rank % max(1, n_dev))
+    torch.cuda.init()
     # the collective path is taken for N > 1 (or when forced, to rehearse RCCL itself with one rank)
     use_dist = world > 1 or (os.environ.get("NFX_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
-    wire_cpu = rehearsal          # the gathers travel through host memory (gloo): a rehearsal, or RCCL failed to come up
-    rccl_failure = None
+    ranks = None
     if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL announces itself on stdout ("Librccl path : ...") when its first communicator comes up; stdout carries the
         # one JSON line of the contract, so the process's fd 1 points at stderr until the communicator exists
         sys.stdout.flush()
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            if rehearsal:
-                dist.init_process_group("gloo")
-            else:
-                try:
-                    dist.init_process_group("nccl", device_id=dev)
-                    probe = torch.ones(1, device=dev)
-                    dist.all_reduce(probe)                      # the first collective brings the communicator up: a failure shows here
-                    torch.cuda.synchronize()
-                    if int(probe.item()) != world:
-                        raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
-                except Exception as e:                          # RCCL did not come up (every rank sees the same environment): the scaling run
-                    rccl_failure = repr(e)[:300]                # still measures sharding and compute, with the rows gathered over gloo through host
-                    print(f"bench.py: RCCL failed on rank {rank} ({rccl_failure}); falling back to gloo through host memory", file=sys.stderr, flush=True)
-                    if dist.is_initialized():
-                        dist.destroy_process_group()
-                    dist.init_process_group("gloo")
-                    wire_cpu = True
-            dist.barrier()
+            ranks = Ranks(torch, dist, dev, world, rank, rehearsal)
             torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
+    ctl = dist if use_dist else None
+    wire_cpu = ranks.wire_cpu if ranks else False
+    rccl_failure = ranks.rccl_failure if ranks else None
+    data_group = ranks.data if ranks else None
 
-    n_def, ps, set_names, wl_desc, _ = WORKLOADS[args.workload]
-    if args.sets:
-        set_names = args.sets.split(",")
-        wl_desc += f" [feature sets overridden: {args.sets}]"
     B = args.batch_size
     n_local = max(B, ((args.nuclei or n_def) // B) * B)          # shard boundary on a reference-batch boundary
     full_size = n_local == n_def and not args.sets
-
-    res = Resident(nfx, synth, torch, dev, args.workload, n_local, rank * n_local, set_names)
-    sets, F, gen_s = res.sets, res.F, res.gen_s
+    sets = nfx.parse_feature_sets(set_names)
+    F = sum(nfx.num_columns(s) for s in sets)
+    pixel_sets = any(s != nfx.GEOMETRY for s in sets)
+    if inputs == "streamed" and not pixel_sets:
+        inputs = "resident"          # geometry needs no pixels: nothing to stream
     ctx = nfx.Context(dev.index)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
-    ctx.reserve(sets, n_local, len(res.xy), ps, batch_size=B)   # device-memory calls never allocate after this
-    d_out = torch.empty((n_local, F), dtype=torch.float32, device=dev)
 
     def fence(sx=None):
         if sx is not None:
@@ -402,192 +538,195 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- the headline: resident inputs; N > 1 weak scaling through ShardedExtraction ----------------------------------
-    stream_mode = args.h2d == "stream" and res.pixel_sets
-    sx = None
-    h_patches = h_rows = None
-    if stream_mode:
-        pipeline = importlib.import_module(PKG + ".pipeline")
-        h_patches = torch.empty(res.d_patches.shape, dtype=torch.uint8, pin_memory=True)
-        h_patches.copy_(res.d_patches)
-        h_rows = torch.empty((n_local, F), dtype=torch.float32, pin_memory=True)
-        torch.cuda.synchronize()
+    def sharded(n_total, Fx):
+        return D.ShardedExtraction(n_total, Fx, B, n_slices=args.gather_slices, device=dev, group=data_group,
+                                   wire_device="cpu" if wire_cpu else None, transport="torch" if wire_cpu else args.transport)
 
-        def step():
-            pipeline.extract_streamed(ctx, sets, res.off, res.xy, h_patches, ps, batch_size=B, chunk_nuclei=args.chunk, out=d_out,
-                                      host_rows=h_rows, want_centroids=False)
-    elif use_dist and args.gather == "rank0":
-        transport = "torch" if wire_cpu else args.transport       # (the native gather needs one GPU per rank and a working RCCL)
-        sx = D.ShardedExtraction(world * n_local, F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if wire_cpu else None,
-                                 transport=transport)
-        assert (sx.i0, sx.i1) == (rank * n_local, (rank + 1) * n_local)
-
-        def step():
-            sx.step(lambda b0, b1, out: res.extract(ctx, b0, b1, out, B))
-    else:
-        def step():
-            res.extract(ctx, 0, n_local, d_out, B)
-
-    elapsed, timing = timed(torch, dist, use_dist, ctx, args.steps, args.warmup, step, lambda: fence(sx))
-    total_nuclei = n_local * world
-    value = total_nuclei * args.steps / elapsed
-    roofline = roofline_of(timing, args.steps, res, args.workload, full_size)
     also = {}
-    if sx is not None:
-        ok = sx.verify_transport()
-        if rank == 0:
-            also["gather_checksums_match"] = bool(all(ok))
-        d_out = sx.local_rows()
-
-    if sx is not None and not args.no_also:
-        # the same shards with the rows left where they were computed: if the incast into rank 0 (world-1 streams of n_local x F
-        # x 4 B per step over its xGMI links) does not hide behind compute, this figure says what the extraction alone scales to
-        el_c, _ = timed(torch, dist, True, ctx, args.steps, 1, lambda: res.extract(ctx, 0, n_local, d_out, B), fence)
-        if rank == 0:
-            also["weak_scaling_compute_only"] = {
-                "value": round(total_nuclei * args.steps / el_c, 1), "unit": "nuclei/s", "ms_per_step": round(el_c / args.steps * 1e3, 3),
-                "scaling": "weak", "what": "the headline's shards extracted with NO gather (rows stay on the rank that computed them): "
-                "compute-only scaling, beside the gathered headline measured in the same run",
-                "gather_cost_ms_per_step": round((elapsed - el_c) / args.steps * 1e3, 3)}
-
-    # ---- CPU baseline: the oracle port on a bounded sample, rank 0 at N=1 only ------------------------------------------
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import _oracle as orc      # checker / baseline only -- never on the product path
-        import _parity as par
-        # the GPU box grants 16 host cores per GPU (use NFX_CPU_THREADS to override)
-        cores = int(os.environ.get("NFX_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
-
-        def run_sample(m):
-            m = min(max(B, (m // B) * B), n_local)
-            pu = res.d_patches[:m].cpu().numpy() if res.pixel_sets else np.zeros((m, 3, ps, ps), np.uint8)
-            so, sxy = res.off[:m + 1], res.xy[:res.off[m]]
-            t = time.perf_counter()
-            rows, _ = orc.extract(sets, so, sxy, pu, ps, batch_size=B, threads=cores)
-            return m, time.perf_counter() - t, rows
-
-        m0, dt0, _ = run_sample(max(B, cores * B))
-        m1, dt1, rows = run_sample(int(m0 / dt0 * args.cpu_seconds))
-        # the sample doubles as an end-of-bench parity spot check of the resident result
-        got = (h_rows[:m1].numpy() if stream_mode else d_out[:m1].cpu().numpy())
-        worst = par.assert_rows_close(got, rows, par.column_scales(nfx, sets, ps), what="bench sample vs oracle")
-        cpu = {"value": round(m1 / dt1, 1), "unit": "nuclei/s", "cores": cores, "kind": "port",
-               "what": "C/OpenMP oracle port of the reference's arithmetic (oracle/nfx_oracle.c), not the torch-CPU twin BASELINE.md §3 "
-                       "describes: a stronger (faster) CPU baseline than the reference's libtorch-CPU path would be",
-               "sample": f"first {m1} nuclei of the same workload, OpenMP over reference batches ({cores} threads), {dt1:.1f} s",
-               "parity_spot_check_worst_scaled_err": float(f"{worst:.3g}")}
-
-    # ---- also: the figures the metric names, under the same clock --------------------------------------------------------
-    n_strong = args.strong_nuclei or (n_def if full_size else 0)
-    n_strong = (n_strong // B) * B
-    if not args.no_also and not stream_mode and world > 1 and use_dist and 0 < n_strong <= n_local:
-        # configs[3]: the SAME n_strong nuclei cut into `world` batch-aligned shards (strong scaling); rank 0's weak-scaling
-        # inputs start with exactly those nuclei, so it can check the gathered matrix against its own single-GPU result
-        ssx = D.ShardedExtraction(n_strong, F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if wire_cpu else None,
-                                  transport="torch" if wire_cpu else args.transport)
-        rs = Resident(nfx, synth, torch, dev, args.workload, ssx.n_local, ssx.i0, set_names)
-        el_s, _ = timed(torch, dist, True, ctx, args.steps, 1, lambda: ssx.step(lambda b0, b1, out: rs.extract(ctx, b0, b1, out, B)),
-                        lambda: fence(ssx))
-        ok = ssx.verify_transport()
-        full = ssx.result()
-        if rank == 0:
-            single = torch.empty((n_strong, F), dtype=torch.float32, device=dev)
-            res.extract(ctx, 0, n_strong, single, B)
-            torch.cuda.synchronize()
-            same = bool(torch.equal(full.to(dev).view(torch.int32), single.view(torch.int32)))
-            also["strong_scaling_config4"] = {
-                "value": round(n_strong * args.steps / el_s, 1), "unit": "nuclei/s", "ms_per_step": round(el_s / args.steps * 1e3, 3),
-                "scaling": "strong", "what": f"BASELINE.json configs[3]: the first {n_strong} nuclei of {wl_desc} index-sharded x{world} "
-                "(batch-aligned shards), rows gathered to rank 0",
-                "shard_nuclei": ssx.counts, "gather_checksums_match": bool(all(ok)), "gathered_equals_single_gpu": same,
-                "gathered_checksum": D.row_checksum(full)}
-            single = None
-        dist.barrier()
-        ssx = rs = full = None
-    n5 = ((args.full_set_nuclei or (WORKLOADS["config5"][0] if full_size else 0)) // B) * B
-    if not args.no_also and args.workload == "config3" and not args.sets and not stream_mode and (full_size or n5 > 0):
-        if world == 1 and full_size:
-            # (ii) PCIe-inclusive rate of the headline workload: first H2D byte to last row in pinned host memory
-            pipeline = importlib.import_module(PKG + ".pipeline")
-            hp = torch.empty(res.d_patches.shape, dtype=torch.uint8, pin_memory=True)
-            hp.copy_(res.d_patches)
-            hr = torch.empty((n_local, F), dtype=torch.float32, pin_memory=True)
-            torch.cuda.synchronize()
-            el_s, _ = timed(torch, dist, False, ctx, args.steps, 1,
-                            lambda: pipeline.extract_streamed(ctx, sets, res.off, res.xy, hp, ps, batch_size=B, chunk_nuclei=args.chunk,
-                                                              out=d_out, host_rows=hr, want_centroids=False), fence)
-            same = bool(torch.equal(hr.view(torch.int32), d_out.cpu().view(torch.int32)))
-            also["streamed_pcie_inclusive"] = {
-                "value": round(n_local * args.steps / el_s, 1), "unit": "nuclei/s", "ms_per_step": round(el_s / args.steps * 1e3, 3),
-                "what": f"{wl_desc}; patches start in pinned host memory and stream in every step in chunks of {args.chunk} nuclei "
-                        "(double-buffered), rows are copied back to pinned host memory chunk by chunk; timed from the first H2D "
-                        "byte to the last row on the host (SURVEY.md §8d); never the headline value",
-                "host_rows_equal_resident_rows": same}
-            del hp, hr
-            # (iii) the same workload fed the way configs[4] asks: the TILE streamed block by block, not packed patches
-            also["streamed_tile"] = streamed_tile_leg(nfx, synth, torch, dist, ctx, dev, "config3", n_local, 0, B, max(2, args.steps // 2), fence)
-        # (i) the metric's "full feature set": configs[4] per-GPU shard on every rank (weak scaling, rows gathered to rank 0 for N > 1)
-        res = d_out = sx = None
-        torch.cuda.empty_cache()
-        r5 = Resident(nfx, synth, torch, dev, "config5", n5, rank * n5, WORKLOADS["config5"][2])
-        ctx.reserve(r5.sets, r5.n, len(r5.xy), r5.ps, batch_size=B)
-        k5 = max(2, args.steps // 2)
+    cfg_extra = {}
+    cpu_port = None
+    # ---- the top line ----------------------------------------------------------------------------------------------------------------
+    if inputs == "streamed":
+        slide = StreamedSlide(nfx, synth, torch, ctx, dev, args.workload, n_local, rank * n_local, B, set_names)
+        gen_s, bytes_per_nucleus = slide.gen_s, slide.bytes_per_nucleus
+        shared = None
         if use_dist:
-            sx5 = D.ShardedExtraction(world * n5, r5.F, B, n_slices=args.gather_slices, device=dev, wire_device="cpu" if wire_cpu else None,
-                                      transport="torch" if wire_cpu else args.transport)
-            el5, t5 = timed(torch, dist, True, ctx, k5, 1, lambda: sx5.step(lambda b0, b1, out: r5.extract(ctx, b0, b1, out, B)), lambda: fence(sx5))
-            ok5 = sx5.verify_transport()
-        else:
-            o5 = torch.empty((r5.n, r5.F), dtype=torch.float32, device=dev)
-            el5, t5 = timed(torch, dist, False, ctx, k5, 1, lambda: r5.extract(ctx, 0, r5.n, o5, B), fence)
-            ok5 = None
-        if rank == 0:
-            also["full_feature_set"] = {
-                "value": round(world * r5.n * k5 / el5, 1), "unit": "nuclei/s", "n_gpus": world, "steps": k5, "ms_per_step": round(el5 / k5 * 1e3, 3),
-                "scaling": "weak",
-                "config": {"workload": WORKLOADS["config5"][3], "nuclei_per_gpu": r5.n, "patch_size": r5.ps, "feature_sets": ["all"],
-                           "columns": r5.F, "batch_size": B, "gen_seconds": round(r5.gen_s, 1)},
-                "roofline": roofline_of(t5, k5, r5, "config5", n5 == WORKLOADS["config5"][0])}
-            if ok5 is not None:
-                also["full_feature_set"]["gather_checksums_match"] = bool(all(ok5))
-        r5 = o5 = None
+            shared = SharedRows(nfx, ranks, n_local, F)
+        rows = shared.mine if (shared is not None and shared.mine is not None) else nfx.pinned_empty((n_local, F), np.float32)
+        elapsed, timing = timed(torch, ctl, ctx, args.steps, args.warmup, lambda: slide.step(ctx, rows, args.chunk), fence)
+        cfg_extra = slide.describe(elapsed, args.steps, rows)
+        if use_dist:
+            # every rank's streamed rows, as they lie in the ONE host matrix, against the rows of that rank's slide resident in HBM
+            mine = torch.tensor([D.row_checksum(torch.from_numpy(slide.ref))], dtype=torch.int64)
+            got = [torch.zeros(1, dtype=torch.int64) for _ in range(world)] if rank == 0 else None
+            dist.gather(mine, got, dst=0)
+            fence()
+            if rank == 0:
+                src = shared.full if shared.full is not None else None
+                cfg_extra["rows_destination"] = (f"one [{world * n_local}, {F}] f32 matrix in host memory shared by the ranks ({shared.path}): every rank's kernels write "
+                                                 "its shard over its own host link" if src is not None else
+                                                 f"per-rank pinned host buffers (no shared matrix: {shared.why_not})")
+                if src is not None:
+                    cfg_extra["shared_matrix_registered_for_direct_writes"] = shared.registered
+                    cfg_extra["every_ranks_rows_in_the_shared_matrix_equal_its_resident_rows"] = bool(all(
+                        D.row_checksum(torch.from_numpy(np.ascontiguousarray(src[r * n_local:(r + 1) * n_local]))) == int(got[r].item()) for r in range(world)))
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            h = slide
+            # the oracle port on the patches the engine itself gathers for the first nuclei (nfx_gather_patches: utils.rs:159-191)
+            cen = ctx.preprocess_polygons(h.off, h.xy)[0]
+
+            def patches_of(m):
+                out = np.empty((m, 3, ps, ps), np.uint8)
+                for i0 in range(0, m, 2000):      # windows of the first m nuclei lie in the slide's first bands
+                    i1 = min(m, i0 + 2000)
+                    rmax = int(np.ceil(cen[i0:i1, 1].max())) + ps
+                    out[i0:i1] = ctx.gather_patches(cen[i0:i1], np.ascontiguousarray(h.h_tile[:, :rmax]), ps)
+                return out
+            cpu_port = oracle_port_baseline(args, nfx, sets, h.off, h.xy, patches_of, ps, n_local, lambda m: np.asarray(rows[:m]))
+        if shared is not None:
+            rows = None
+            shared.close()
+        del slide
         torch.cuda.empty_cache()
-        if world == 1 and n5 == WORKLOADS["config5"][0]:
-            # BASELINE configs[4] as it says: one GPU's shard of the 10 M-nucleus slide, full feature set, tile streamed over the host link
-            also["streamed_tile_full_set"] = streamed_tile_leg(nfx, synth, torch, dist, ctx, dev, "config5", n5, 0, B, 2, fence)
+        res = None
+    else:
+        res = Resident(nfx, synth, torch, dev, args.workload, n_local, rank * n_local, set_names)
+        gen_s, bytes_per_nucleus = res.gen_s, res.bytes_per_nucleus
+        ctx.reserve(sets, n_local, len(res.xy), ps, batch_size=B)   # device-memory calls never allocate after this
+        d_out = torch.empty((n_local, F), dtype=torch.float32, device=dev)
+        sx = None
+        if use_dist and args.gather == "rank0":
+            sx = sharded(world * n_local, F)
+            assert (sx.i0, sx.i1) == (rank * n_local, (rank + 1) * n_local)
+
+            def step():
+                sx.step(lambda b0, b1, out: res.extract(ctx, b0, b1, out, B))
+        else:
+            def step():
+                res.extract(ctx, 0, n_local, d_out, B)
+        elapsed, timing = timed(torch, ctl, ctx, args.steps, args.warmup, step, lambda: fence(sx))
+        if sx is not None:
+            ok = sx.verify_transport()
+            if rank == 0:
+                also["gather_checksums_match"] = bool(all(ok))
+            d_out = sx.local_rows()
+            if not args.no_also:
+                # the same shards with the rows left where they were computed: what the extraction alone scales to
+                el_c, _ = timed(torch, ctl, ctx, args.steps, 1, lambda: res.extract(ctx, 0, n_local, d_out, B), fence)
+                if rank == 0:
+                    also["weak_scaling_compute_only"] = {
+                        "value": round(world * n_local * args.steps / el_c, 1), "unit": "nuclei/s", "ms_per_step": round(el_c / args.steps * 1e3, 3),
+                        "scaling": "weak", "what": "the top line's shards extracted with NO gather (rows stay on the rank that computed them)",
+                        "gather_cost_ms_per_step": round((elapsed - el_c) / args.steps * 1e3, 3)}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            cpu_port = oracle_port_baseline(args, nfx, sets, res.off, res.xy,
+                                            lambda m: res.d_patches[:m].cpu().numpy() if res.pixel_sets else np.zeros((m, 3, ps, ps), np.uint8),
+                                            ps, n_local, lambda m: d_out[:m].cpu().numpy())
+        cfg_extra = {"inputs": "packed u8 patches + polygons resident in HBM, rows left in HBM"}
+    value = world * n_local * args.steps / elapsed
+    roofline = roofline_of(timing, args.steps, n_local, bytes_per_nucleus, args.workload, full_size)
+
+    # ---- also: the other figures, under the same clock ------------------------------------------------------------------------------------
+    def resident_leg(workload, n, k, with_gather):
+        """one workload with resident inputs on every rank (rows gathered to rank 0 over the data group for N > 1): (entry, Resident)"""
+        names = WORKLOADS[workload][2]
+        r = Resident(nfx, synth, torch, dev, workload, n, rank * n, names)
+        ctx.reserve(r.sets, r.n, len(r.xy), r.ps, batch_size=B)
+        if use_dist and with_gather:
+            sxl = sharded(world * n, r.F)
+            el, t = timed(torch, ctl, ctx, k, 1, lambda: sxl.step(lambda b0, b1, out: r.extract(ctx, b0, b1, out, B)), lambda: fence(sxl))
+            okl = sxl.verify_transport()
+        else:
+            o = torch.empty((r.n, r.F), dtype=torch.float32, device=dev)
+            el, t = timed(torch, ctl, ctx, k, 1, lambda: r.extract(ctx, 0, r.n, o, B), fence)
+            okl = None
+        e = {"value": round(world * r.n * k / el, 1), "unit": "nuclei/s", "n_gpus": world, "steps": k, "ms_per_step": round(el / k * 1e3, 3), "scaling": "weak",
+             "config": {"workload": WORKLOADS[workload][3], "nuclei_per_gpu": r.n, "patch_size": r.ps, "feature_sets": names, "columns": r.F, "batch_size": B,
+                        "inputs": "packed u8 patches + polygons resident in HBM" + (", rows gathered to rank 0 " + ("(gloo through host memory)" if wire_cpu else "(RCCL)")
+                                                                                    if okl is not None else ", rows left in HBM"),
+                        "gen_seconds": round(r.gen_s, 1)},
+             "roofline": roofline_of(t, k, r.n, r.bytes_per_nucleus, workload, n == WORKLOADS[workload][0])}
+        if okl is not None:
+            e["gather_checksums_match"] = bool(all(okl)) if rank == 0 else None
+        return e, r
+
+    na = lambda wl: ((args.also_nuclei or (WORKLOADS[wl][0] if full_size else 0)) // B) * B
+    if not args.no_also and not args.sets and args.workload == "config5" and inputs == "streamed":
+        k2 = max(2, args.steps // 2)
+        if na("config3") > 0:
+            e, r3 = resident_leg("config3", na("config3"), args.steps, True)
+            if rank == 0:
+                also["config3_resident" if world == 1 else "weak_config3_rccl_gather"] = e
+            # BASELINE configs[3]: the SAME nuclei cut into `world` batch-aligned shards (strong scaling); rank 0's weak-scaling inputs start with
+            # exactly those nuclei, so it can check the gathered matrix against its own single-GPU result
+            n_strong = ((args.strong_nuclei or (WORKLOADS["config3"][0] if full_size else 0)) // B) * B
+            if world > 1 and use_dist and 0 < n_strong <= r3.n:
+                ssx = sharded(n_strong, r3.F)
+                rs = Resident(nfx, synth, torch, dev, "config3", ssx.n_local, ssx.i0, WORKLOADS["config3"][2])
+                el_s, _ = timed(torch, ctl, ctx, args.steps, 1, lambda: ssx.step(lambda b0, b1, out: rs.extract(ctx, b0, b1, out, B)), lambda: fence(ssx))
+                oks = ssx.verify_transport()
+                full = ssx.result()
+                if rank == 0:
+                    single = torch.empty((n_strong, r3.F), dtype=torch.float32, device=dev)
+                    r3.extract(ctx, 0, n_strong, single, B)
+                    torch.cuda.synchronize()
+                    also["strong_scaling_config4"] = {
+                        "value": round(n_strong * args.steps / el_s, 1), "unit": "nuclei/s", "ms_per_step": round(el_s / args.steps * 1e3, 3), "scaling": "strong",
+                        "what": f"BASELINE.json configs[3]: the first {n_strong} nuclei of {WORKLOADS['config3'][3]} index-sharded x{world} (batch-aligned shards), "
+                                "rows gathered to rank 0", "shard_nuclei": ssx.counts, "gather_checksums_match": bool(all(oks)),
+                        "gathered_equals_single_gpu": bool(torch.equal(full.to(dev).view(torch.int32), single.view(torch.int32))),
+                        "gathered_checksum": D.row_checksum(full)}
+                    single = None
+                dist.barrier()
+                ssx = rs = full = None
+            r3 = None
+            torch.cuda.empty_cache()
+            if world == 1:
+                s3 = StreamedSlide(nfx, synth, torch, ctx, dev, "config3", na("config3"), 0, B)
+                hr = nfx.pinned_empty((s3.n, s3.F), np.float32)
+                el3, _ = timed(torch, None, ctx, k2, 1, lambda: s3.step(ctx, hr, args.chunk), fence)
+                also["config3_streamed"] = dict({"value": round(s3.n * k2 / el3, 1), "unit": "nuclei/s", "ms_per_step": round(el3 / k2 * 1e3, 3),
+                                                 "workload": WORKLOADS["config3"][3]}, **s3.describe(el3, k2, hr))
+                del s3, hr
+                torch.cuda.empty_cache()
+        if na("config5") > 0:
+            e, r5 = resident_leg("config5", na("config5"), k2, True)
+            r5 = None
+            torch.cuda.empty_cache()
+            if rank == 0:
+                also["full_feature_set_resident"] = e
 
     if rank == 0:
         sharding = "single GPU"
-        if world > 1 and (stream_mode or args.gather == "none"):
-            sharding = f"index-sharded x{world}, NO gather: rows stay on the rank that computed them" + (
-                " (in its pinned host memory)" if stream_mode else "") + (" -- REHEARSAL on fewer GPUs than ranks" if rehearsal else "")
-        elif world > 1:
-            sharding = f"index-sharded x{world}, rows gathered to rank 0 " + ("(gloo through host memory: REHEARSAL on fewer GPUs than "
-                                                                             "ranks, not a scaling measurement)" if rehearsal else
-                                                                             (f"(gloo through host memory: RCCL FAILED to come up -- {rccl_failure})" if rccl_failure else "(RCCL)"))
+        if world > 1:
+            how = "REHEARSAL on fewer GPUs than ranks, not a scaling measurement" if rehearsal else ("RCCL FAILED to come up: " + str(rccl_failure) if rccl_failure else "")
+            if inputs == "streamed":
+                sharding = f"index-sharded x{world} on reference-batch boundaries; every rank streams its own slide and leaves its rows in host memory" + (f" ({how})" if how else "")
+            elif args.gather == "none":
+                sharding = f"index-sharded x{world}, NO gather: rows stay on the rank that computed them" + (f" ({how})" if how else "")
+            else:
+                sharding = f"index-sharded x{world}, rows gathered to rank 0 (" + ("gloo through host memory: " + how if wire_cpu else "RCCL") + ")"
         line = {
             "metric": "nuclei/sec", "value": round(value, 1), "unit": "nuclei/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64 (u8 pixels, integer counts)", "data": "synthetic",
-            "config": {"workload": wl_desc, "nuclei_per_gpu": n_local, "patch_size": ps, "feature_sets": set_names,
-                       "columns": F, "batch_size": B, "sharding": sharding,
-                       "inputs": "packed u8 patches + polygons resident in HBM" if not stream_mode else
-                                 f"patches streamed from pinned host memory every step in chunks of {args.chunk}, rows copied back to "
-                                 "pinned host memory (PCIe-inclusive; NOT the headline metric)",
-                       "gen_seconds": round(gen_s, 1), "csrc_stamp": csrc_stamp(),
-                       "gather": ("none" if (stream_mode or args.gather == "none") else "rank0") if world > 1 else None,
-                       "transport": (("torch.distributed.gather" if (wire_cpu or args.transport == "torch") else "nfx_gather_rows (grouped ncclSend/ncclRecv)")
-                                     if use_dist and not stream_mode and args.gather == "rank0" else None),
-                       "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") if use_dist else None,
-                       "rccl_failure": rccl_failure},
-            "roofline": roofline, "cpu_baseline": cpu, "also": also or None,
+            "config": dict({"workload": wl_desc + (", slide streamed from pinned host memory, rows to host memory" if inputs == "streamed" else ""),
+                            "nuclei_per_gpu": n_local, "patch_size": ps, "feature_sets": set_names, "columns": F, "batch_size": B,
+                            "inputs_mode": inputs, "sharding": sharding, "gen_seconds": round(gen_s, 1), "csrc_stamp": csrc_stamp(),
+                            "hip_runtimes_mapped": nfx.hip_runtimes_mapped(),
+                            "gather": (None if world == 1 else ("none needed: rows land in host memory" if inputs == "streamed" else args.gather)),
+                            "transport": (("torch.distributed.gather" if (wire_cpu or args.transport == "torch") else "nfx_gather_rows (grouped ncclSend/ncclRecv)")
+                                          if use_dist and inputs != "streamed" and args.gather == "rank0" else None),
+                            "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") if use_dist else None,
+                            "rccl_failure": rccl_failure}, **cfg_extra),
+            "roofline": roofline, "cpu_baseline": cpu_twin if cpu_twin is not None else cpu_port,
+            "cpu_baseline_port": cpu_port if cpu_twin is not None else None, "also": also or None,
         }
-        if cpu_torch is not None:
-            line["cpu_baseline_torch"] = cpu_torch
+        if rccl_failure:
+            line["degraded"] = True     # a multi-GPU figure whose rows travelled through host memory over gloo: not an xGMI measurement
         print(json.dumps(line), flush=True)
-    if use_dist:
-        dist.destroy_process_group()
+    if ranks:
+        ranks.close()
     ctx.close()
 
 

@@ -58,7 +58,10 @@
 extern "C" {
 #endif
 
-#define NFX_VERSION 300 /* 0.3.0 */
+/* 0.4.0 -- ABI break against 0.3.0: nfx_stream_stats now starts with `struct_size` (set by the caller) and the library never
+   writes past it, so the struct can grow without corrupting callers built against an older header (0.3.0 grew it from 8 to 9
+   fields under an unchanged version number).  Everything else is unchanged. */
+#define NFX_VERSION 400
 
 typedef struct nfx_ctx nfx_ctx;
 
@@ -223,14 +226,20 @@ nfx_status nfx_extract_tile(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n
    at a time, only the extraction needs all of a batch's patches -- so no cache size makes a call fail, a small one only re-copies.  For the link's full rate and for copies that overlap compute, image_u8 and out_rows should be pinned
    for THIS library's HIP runtime (nfx_host_alloc, or nfx_host_register on memory of the caller's own; memory pinned by another
    runtime in the process, e.g. PyTorch's, counts as pageable and is staged by the runtime).
-   stats (may be NULL): what travelled ("blocks" = bands). */
+   When out_rows is pinned the kernels write the rows straight into it over the link (NFX_STREAM_ROWS=copy in the environment keeps the
+   staged form: a device buffer per chunk and a copy behind it).
+   stats (may be NULL; set stats->struct_size = sizeof(nfx_stream_stats) before the call): what travelled ("blocks" = bands). */
 typedef struct {
+    int64_t struct_size;      /* IN: sizeof(nfx_stream_stats) as the caller was compiled; the library fills at most that many bytes
+                                 (a value below 16 or not a multiple of 8 is NFX_ERR_INVALID_ARGUMENT) and leaves it as it was */
     int64_t image_bytes_h2d;  /* block windows copied to the device (3 bytes per pixel, halos and re-copies included) */
     int64_t other_bytes_h2d;  /* ring offsets and vertices, per-chunk selection lists and rebased offsets */
     int64_t rows_bytes_d2h;   /* feature rows + centroids */
     int64_t blocks_copied, blocks_total, block_slots, chunks;
     int64_t image_pinned;     /* 1: the image is pinned for this runtime (asynchronous copies); 0: pageable */
     int64_t split_gather_passes; /* band passes made by chunks whose bands did not fit the cache at once (0: one pass per chunk) */
+    int64_t rows_direct;      /* 1: out_rows is pinned and the feature kernels wrote the rows into it themselves (no staging buffer, no
+                                 device -> host copy); 0: rows staged on the device and copied home chunk by chunk */
 } nfx_stream_stats;
 nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t n_vertices,
                                      const uint32_t *ring_offsets, const float *ring_xy, const uint8_t *image_u8, int64_t H, int64_t W,

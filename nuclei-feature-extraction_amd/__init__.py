@@ -45,6 +45,11 @@ ABI_SYMBOLS = (
 )
 
 
+# nfx_stream_stats after its leading struct_size (include/nfx.h; tests/test_abi.py compiles the header and compares)
+STREAM_STATS_FIELDS = ("image_bytes_h2d", "other_bytes_h2d", "rows_bytes_d2h", "blocks_copied", "blocks_total", "block_slots", "chunks",
+                       "image_pinned", "split_gather_passes", "rows_direct")
+
+
 class NfxError(RuntimeError):
     pass
 
@@ -107,6 +112,25 @@ def lib() -> C.CDLL:
     L.nfx_gather_rows.argtypes = [vp, vp, f32p, C.c_int, C.POINTER(C.c_int64), f32p, C.c_int]
     _lib = L
     return L
+
+
+def hip_runtimes_mapped() -> List[str]:
+    """Every libamdhip64 mapped into this process (real paths, from /proc/self/maps).
+
+    libnfx.so needs `libamdhip64.so.7` (RUNPATH /opt/rocm/lib).  PyTorch's wheel bundles a runtime of its own under the same
+    SONAME.  Loaded AFTER `import torch`, libnfx binds the one torch already mapped: ONE runtime in the process (torch's), pinned
+    memory and streams are shared.  Loaded BEFORE torch, libnfx maps /opt/rocm's and a later `import torch` maps its own beside it:
+    TWO runtimes, and torch is left with "No HIP GPUs are available".  A torch-free process (the C++ command line, a Rust host)
+    holds /opt/rocm's alone."""
+    libs = set()
+    try:
+        with open("/proc/self/maps") as fh:
+            for ln in fh:
+                if "libamdhip64" in ln:
+                    libs.add(os.path.realpath(ln.split()[-1]))
+    except OSError:
+        pass
+    return sorted(libs)
 
 
 # ---- registry (no GPU needed) ---------------------------------------------------------------
@@ -195,8 +219,16 @@ class Context:
     ``torch.cuda.current_stream().cuda_stream``; device-memory calls are enqueued on it."""
 
     def __init__(self, device: int = 0, stream: Optional[int] = None):
-        # A process that also uses torch holds two HIP runtimes (torch ships its own): torch's has to come up first, the
-        # other order leaves torch with "No HIP GPUs are available".  Only when the caller has imported torch already.
+        # One HIP runtime per process (hip_runtimes_mapped): libnfx loaded after `import torch` shares torch's; loaded before it, a
+        # later `import torch` maps a second one and torch finds no GPU.  That order is refused here with its cure, not left to
+        # surface as "No HIP GPUs are available" somewhere in torch.
+        lib()
+        mapped = hip_runtimes_mapped()
+        if len(mapped) > 1:
+            raise NfxError("two HIP runtimes are mapped into this process (" + ", ".join(mapped) + "): libnfx.so was loaded before "
+                           "`import torch`, which then brought its own.  Import torch BEFORE the first call into this package (libnfx "
+                           "then binds torch's bundled runtime: one runtime, shared streams and pinned memory), or do not import torch "
+                           "in this process at all (libnfx then runs on /opt/rocm's)")
         torch = sys.modules.get("torch")
         if torch is not None and torch.cuda.is_available():
             torch.cuda.init()
@@ -401,12 +433,11 @@ class Context:
             out = np.empty((n, F), np.float32)
         assert out.shape == (n, F) and out.dtype == np.float32 and out.flags.c_contiguous
         cen = np.empty((n, 2), np.float32)
-        st = (C.c_int64 * 9)()
+        st = (C.c_int64 * (1 + len(STREAM_STATS_FIELDS)))()
+        st[0] = C.sizeof(st)                                          # nfx_stream_stats.struct_size: the library writes no further
         self._check(lib().nfx_extract_tile_streamed(self._h, sets_arr, len(sets), n, nv, _ptr(off), _ptr(xy), _ptr(image_u8), int(image_u8.shape[1]),
                                                     int(image_u8.shape[2]), ps, batch_size, block, chunk_nuclei, cache_bytes, _ptr(out), _ptr(cen), st))
-        names = ("image_bytes_h2d", "other_bytes_h2d", "rows_bytes_d2h", "blocks_copied", "blocks_total", "block_slots", "chunks", "image_pinned",
-                 "split_gather_passes")
-        return out, cen, {k: int(st[j]) for j, k in enumerate(names)}
+        return out, cen, {k: int(st[1 + j]) for j, k in enumerate(STREAM_STATS_FIELDS)}
 
     def gather_patches(self, centroids, image_u8, ps: int):
         dev = _is_torch(image_u8) and image_u8.is_cuda
@@ -422,7 +453,8 @@ class Context:
         return out
 
 
-# ---- pinned host memory of libnfx's own HIP runtime (PyTorch's pinned tensors belong to ITS runtime and count as pageable here) ----
+# ---- pinned host memory (nfx_host_alloc = hipHostMalloc of the runtime libnfx is bound to; in a torch-first process that is torch's own
+# runtime, so torch's pinned tensors are pinned for libnfx as well -- hip_runtimes_mapped) ----
 class _PinnedBuffer:
     def __init__(self, nbytes):
         self.ptr = lib().nfx_host_alloc(max(1, nbytes))
@@ -441,6 +473,7 @@ class _PinnedBuffer:
 
 def pinned_empty(shape, dtype) -> np.ndarray:
     """An uninitialised numpy array in memory pinned by nfx_host_alloc (freed with the array's last reference)."""
+    # (works without torch: the C++ command line and torch-free hosts pin their slide and rows the same way)
     dtype = np.dtype(dtype)
     n = int(np.prod(shape)) * dtype.itemsize
     owner = _PinnedBuffer(n)

@@ -1086,14 +1086,17 @@ hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
     // the BASELINE patch sizes it holds a percent of the nuclei or less, on patches smaller than the filter nearly all of them)
     const unsigned grid2 = (unsigned)(job.n < 256 * 2 * 4 ? job.n : 256 * 2 * 4);
     const GaborTileArgs none{nullptr, nullptr, nullptr, nullptr};
+    // EXPERIMENT (NFX_GABOR_PAD = bytes of dynamic LDS nobody uses): 8192 leaves room for ONE workgroup per CU instead of two, so that the
+    // waves of another stream's kernels (k_glcm: LDS-bound) share the CU with it -- DESIGN.md §8
+    static const unsigned pad = [] { const char *e = getenv("NFX_GABOR_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
     if (job.patches_f32) {
         const float *pf = reinterpret_cast<const float *>(job.patches);
-        hipLaunchKernelGGL((k_gabor<float, GB_MAIN>), dim3(grid), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps, pf, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none);
-        hipLaunchKernelGGL((k_gabor<float, GB_REFINED>), dim3(grid2), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps, pf, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none);
+        hipLaunchKernelGGL((k_gabor<float, GB_MAIN>), dim3(grid), dim3(GB_THREADS), pad, ctx->stream, job.n, job.ps, pf, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none);
+        hipLaunchKernelGGL((k_gabor<float, GB_REFINED>), dim3(grid2), dim3(GB_THREADS), pad, ctx->stream, job.n, job.ps, pf, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none);
     } else {
         const uint8_t *pb = reinterpret_cast<const uint8_t *>(job.patches);
-        hipLaunchKernelGGL((k_gabor<uint8_t, GB_MAIN>), dim3(grid), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps, pb, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none);
-        hipLaunchKernelGGL((k_gabor<uint8_t, GB_REFINED>), dim3(grid2), dim3(GB_THREADS), 0, ctx->stream, job.n, job.ps, pb, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none);
+        hipLaunchKernelGGL((k_gabor<uint8_t, GB_MAIN>), dim3(grid), dim3(GB_THREADS), pad, ctx->stream, job.n, job.ps, pb, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none);
+        hipLaunchKernelGGL((k_gabor<uint8_t, GB_REFINED>), dim3(grid2), dim3(GB_THREADS), pad, ctx->stream, job.n, job.ps, pb, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none);
     }
     return hipGetLastError();
 }

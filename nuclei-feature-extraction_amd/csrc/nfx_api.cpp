@@ -290,7 +290,10 @@ nfx_status nfx_ctx_create(int device, nfx_ctx **out)
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->gabor_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_gfork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_gjoin, hipEventDisableTiming) != hipSuccess) {
         nfx_ctx_destroy(c);
         return NFX_ERR_DEVICE;
     }
@@ -305,6 +308,9 @@ void nfx_ctx_destroy(nfx_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    if (ctx->gabor_stream) { (void)hipStreamSynchronize(ctx->gabor_stream); (void)hipStreamDestroy(ctx->gabor_stream); }
+    if (ctx->ev_gfork) (void)hipEventDestroy(ctx->ev_gfork);
+    if (ctx->ev_gjoin) (void)hipEventDestroy(ctx->ev_gjoin);
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->alt_stream) { (void)hipStreamSynchronize(ctx->alt_stream); (void)hipStreamDestroy(ctx->alt_stream); }
     if (ctx->d2h_stream) { (void)hipStreamSynchronize(ctx->d2h_stream); (void)hipStreamDestroy(ctx->d2h_stream); }
@@ -313,7 +319,10 @@ void nfx_ctx_destroy(nfx_ctx *ctx)
         for (hipEvent_t e : {ctx->ev_ready[b], ctx->ev_done[b], ctx->ev_rows[b], ctx->ev_bands[b]})
             if (e) (void)hipEventDestroy(e);
     if (ctx->ev_pass) (void)hipEventDestroy(ctx->ev_pass);
+    for (hipEvent_t e : {ctx->ev_front, ctx->ev_front_up, ctx->ev_front_cen})
+        if (e) (void)hipEventDestroy(e);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->pin_cen) (void)hipHostFree(ctx->pin_cen);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (auto &t : ctx->pending) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
@@ -461,7 +470,7 @@ nfx_status prepare_sets(nfx_ctx *ctx, const int *sets, int n_sets)
 // everything on the device; ws already reserved.  `forked` tells the caller that the side stream holds work to be joined.
 static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_off,
                                       const float *ring_xy, const uint8_t *patches_u8, const uint8_t *image, int64_t H, int64_t W,
-                                      int ps, int batch_size, float *out_rows, float *out_centroids, bool &forked)
+                                      int ps, int batch_size, float *out_rows, float *out_centroids, bool &forked, bool &gforked)
 {
     const int F = sets_total_columns(sets, n_sets);
     float *centred = (float *)ws_alloc(ctx, sizeof(float) * 2 * (size_t)nv);
@@ -503,6 +512,12 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
         }
     }
     NFX_HIP(ctx, launch_raster_shape(ctx, n, ring_off, centred, ps, rows, geo_col >= 0 ? out_rows : nullptr, F, geo_col >= 0 ? geo_col : 0, areas));
+    // k_gabor (VALU-bound, 76 KB of LDS per workgroup) beside the LDS-bound k_glcm and k_glrlm of the same call, on a stream of its own: only
+    // when both kinds are selected and the patches are of the row-word family.  Off by default (NFX_GABOR_SIDE=1 turns it on)
+    static const bool gabor_side_env = [] { const char *e = getenv("NFX_GABOR_SIDE"); return e && atoi(e) == 1; }();
+    const bool gabor_beside = gabor_side_env && ps <= NFX_ROW_WORD_PS && count_set(sets, n_sets, NFX_SET_GABOR) &&
+                              (count_set(sets, n_sets, NFX_SET_GLCM) || count_set(sets, n_sets, NFX_SET_GLRLM));
+    if (gabor_beside) NFX_HIP(ctx, hipEventRecord(ctx->ev_gfork, main_stream));
     Job job;
     job.n = n; job.ps = ps; job.batch_size = batch_size; job.poly_off = ring_off; job.poly_xy = centred;
     job.patches = patches_u8; job.patches_f32 = false; job.mask_rows = rows; job.areas = areas; job.out = out_rows; job.F = F;
@@ -546,7 +561,16 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
         case NFX_SET_GABOR: {
             if (!gabor_scr) gabor_scr = ws_alloc(ctx, gabor_scratch_bytes(job)); // (a repeated "gabor" runs after the first on the same stream: shared)
             if (!gabor_scr && gabor_scratch_bytes(job)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
-            NFX_HIP(ctx, launch_gabor(ctx, job, col, gabor_scr));
+            if (gabor_beside) { // fork (once): everything k_gabor reads -- patches, mask rows -- exists when the rasteriser has run
+                if (!gforked) {
+                    NFX_HIP(ctx, hipStreamWaitEvent(ctx->gabor_stream, ctx->ev_gfork, 0));
+                    gforked = true;
+                }
+                ctx->stream = ctx->gabor_stream;
+            }
+            const hipError_t ge = launch_gabor(ctx, job, col, gabor_scr);
+            ctx->stream = main_stream;
+            NFX_HIP(ctx, ge);
             break;
         }
         }
@@ -559,11 +583,16 @@ nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, 
                           const float *ring_xy, const uint8_t *patches_u8, const uint8_t *image, int64_t H, int64_t W,
                                  int ps, int batch_size, float *out_rows, float *out_centroids)
 {
-    bool forked = false;
+    bool forked = false, gforked = false;
     hipStream_t const main_stream = ctx->stream;
-    const nfx_status st = extract_device_body(ctx, sets, n_sets, n, nv, ring_off, ring_xy, patches_u8, image, H, W, ps, batch_size,
-                                              out_rows, out_centroids, forked);
+    nfx_status st = extract_device_body(ctx, sets, n_sets, n, nv, ring_off, ring_xy, patches_u8, image, H, W, ps, batch_size,
+                                        out_rows, out_centroids, forked, gforked);
     ctx->stream = main_stream;
+    if (gforked) { // joined on every path, like the polygon kernel's stream below
+        const hipError_t e1 = hipEventRecord(ctx->ev_gjoin, ctx->gabor_stream);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(main_stream, ctx->ev_gjoin, 0) : e1;
+        if (st == NFX_OK && e2 != hipSuccess) st = fail(ctx, NFX_ERR_DEVICE, std::string("joining the gabor stream: ") + hipGetErrorString(e2));
+    }
     if (forked) { // join on every path: an error return must not leave the side stream dangling off the caller's stream (or capture)
         const hipError_t e1 = hipEventRecord(ctx->ev_join, ctx->side_stream);
         const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(main_stream, ctx->ev_join, 0) : e1;

@@ -54,11 +54,16 @@ struct nfx_ctx {
                                       // different host threads overlap on the GPU instead of queueing on the default stream
     hipStream_t side_stream = nullptr; // the polygon kernel (64 serial programs per wave: latency-bound, hardly any issue slots) runs
     hipEvent_t ev_fork = nullptr, ev_join = nullptr; // here, beside the rasteriser and the pixel kernels of the same call
+    hipStream_t gabor_stream = nullptr;                // k_gabor beside k_glcm / k_glrlm of the same call (NFX_GABOR_SIDE; nfx_api.cpp: extract_device_body)
+    hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
     // nfx_extract_tile_streamed (nfx_stream.cpp): block copies + window gathers | rows back to the host, created on first use
     hipStream_t copy_stream = nullptr, rows_stream = nullptr, d2h_stream = nullptr, alt_stream = nullptr;
     hipEvent_t ev_ready[3] = {}, ev_done[3] = {}, ev_rows[3] = {}, ev_bands[3] = {}, ev_pass = nullptr;
-    void *pin = nullptr;      // grow-only pinned host staging (selection lists, rebased offsets of two chunks)
+    hipEvent_t ev_front = nullptr, ev_front_up = nullptr, ev_front_cen = nullptr; // the centroid frontier: centroids home | rings up | centroids made
+    void *pin = nullptr;      // grow-only pinned host staging (selection lists, rebased offsets of the chunks in flight)
     size_t pin_cap = 0;
+    void *pin_cen = nullptr;  // grow-only pinned host staging: the centroids of a streamed call
+    size_t pin_cen_cap = 0;
     nfx_addressing addressing = NFX_ADDR_IMAGE;
     std::string err;
     // Two grow-only device workspaces with a bump pointer each, rewound at the start of every API call:

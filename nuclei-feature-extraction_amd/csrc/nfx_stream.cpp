@@ -28,6 +28,7 @@
 // same extraction runs on the same batches.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -59,15 +60,17 @@ bool is_pinned(const void *p)
     return a.type == hipMemoryTypeHost;
 }
 
-struct Pinned { // grow-only pinned staging kept by the context
-    static void *get(nfx_ctx *ctx, size_t bytes)
+struct Pinned { // grow-only pinned staging kept by the context: region 0 = centroids of the call, region 1 = per-chunk lists
+    static void *get(nfx_ctx *ctx, int region, size_t bytes)
     {
-        if (bytes <= ctx->pin_cap) return ctx->pin;
-        if (ctx->pin) (void)hipHostFree(ctx->pin);
-        ctx->pin = nullptr; ctx->pin_cap = 0;
-        if (hipHostMalloc(&ctx->pin, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->pin = nullptr; return nullptr; }
-        ctx->pin_cap = bytes;
-        return ctx->pin;
+        void *&p = region == 0 ? ctx->pin_cen : ctx->pin;
+        size_t &cap = region == 0 ? ctx->pin_cen_cap : ctx->pin_cap;
+        if (bytes <= cap) return p;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return nullptr; }
+        cap = bytes;
+        return p;
     }
 };
 
@@ -103,9 +106,16 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
                                      const float *ring_xy, const uint8_t *image_u8, int64_t H, int64_t W, int ps, int batch_size, int block,
                                      int64_t chunk_nuclei, int64_t cache_bytes, float *out_rows, float *out_centroids_xy, nfx_stream_stats *stats)
 {
-    if (stats) memset(stats, 0, sizeof(*stats));
     nfx_status st = check_common(ctx, n, nv, ps);
     if (st != NFX_OK) return st;
+    // the caller says how large ITS nfx_stream_stats is: nothing is written past that (include/nfx.h)
+    const int64_t stats_size = stats ? stats->struct_size : 0;
+    if (stats && (stats_size < 16 || (stats_size & 7))) return api_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "stats->struct_size must be sizeof(nfx_stream_stats) of the caller's header");
+    auto put_stats = [&](const nfx_stream_stats &full) {
+        if (!stats) return;
+        memcpy((char *)stats + 8, (const char *)&full + 8, (size_t)std::min<int64_t>(stats_size, (int64_t)sizeof(full)) - 8);
+    };
+    put_stats(nfx_stream_stats{});
     if (!sets || n_sets <= 0) return api_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "no feature set selected");
     const int F = sets_total_columns(sets, n_sets);
     if (F < 0) return api_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "unknown feature set");
@@ -143,9 +153,26 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     if (!ctx->ev_pass) NFX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pass, hipEventDisableTiming));
     if (!ctx->alt_stream) NFX_HIP(ctx, hipStreamCreateWithFlags(&ctx->alt_stream, hipStreamNonBlocking));
     hipStream_t const compute = ctx->stream, copy = ctx->copy_stream, rows_s = ctx->rows_stream, d2h = ctx->d2h_stream;
-    hipStream_t const cs[2] = {compute, ctx->alt_stream};
+    // chunks alternate between two compute streams (NFX_STREAM_NCS=1: one stream, chunk after chunk -- experiments)
+    const bool one_cs = [] { const char *e = getenv("NFX_STREAM_NCS"); return e && atoi(e) == 1; }();
+    hipStream_t const cs[2] = {compute, one_cs ? compute : ctx->alt_stream};
     constexpr int NB = 3; // buffer sets (patches, rows, selection lists): one being filled, two being extracted
     const bool slide = ctx->addressing == NFX_ADDR_SLIDE;
+    // Rows straight home.  When out_rows is pinned for this runtime the feature kernels write their columns into it themselves (the
+    // mapped host pointer goes in as the rows' address): posted writes over the link, spread over the whole extraction, instead of a
+    // device buffer per chunk and a copy behind it -- which the runtime carries with a copy KERNEL of one workgroup per CU while the
+    // bands hold the DMA engine (profiles/r03_stream_d2h.txt).  Same kernels, same rows.  NFX_STREAM_ROWS=copy keeps the staged form.
+    float *rows_direct = nullptr;
+    {
+        const char *rm = getenv("NFX_STREAM_ROWS");
+        const bool want = !(rm && !strcmp(rm, "copy"));
+        const size_t rows_bytes = 4 * (size_t)n * F;
+        if (want && rows_bytes && is_pinned(out_rows) && is_pinned((const char *)out_rows + rows_bytes - 1)) {
+            void *dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, out_rows, 0) == hipSuccess && dp) rows_direct = (float *)dp;
+            else (void)hipGetLastError();
+        }
+    }
 
     // ---- geometry of the plan: "block" b is the band of rows [b B, b B + B + ps) (clipped to the image), all W columns -----------
     const int64_t B = block > 0 ? (block < 64 ? 64 : block) : 2048;
@@ -176,7 +203,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     }
     const size_t scratch = extract_ws_bytes(sets, n_sets, chunk_cap, (int64_t)max_chunk_nv, ps, batch_size, false, false);
     size_t need = al(4 * ((size_t)n + 1)) + al(8 * (size_t)nv + 8) + al(8 * (size_t)n + 8) + (size_t)n_slots * slot_bytes +
-                  NB * al((size_t)chunk_cap * P3) + NB * al(4 * (size_t)chunk_cap * F + 8) + NB * al(4 * (size_t)chunk_cap + 8) +
+                  NB * al((size_t)chunk_cap * P3) + (rows_direct ? 0 : NB * al(4 * (size_t)chunk_cap * F + 8)) + NB * al(4 * (size_t)chunk_cap + 8) +
                   NB * al(4 * ((size_t)chunk_cap + 1)) + 2 * al(scratch) + 8192;
     if ((st = ws_reserve(ctx, need, NFX_MEM_HOST)) != NFX_OK) return st;
     uint32_t *d_off_all = (uint32_t *)ws_alloc(ctx, 4 * ((size_t)n + 1));
@@ -186,7 +213,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     uint8_t *d_patches[NB]; float *d_rows[NB]; uint32_t *d_sel[NB], *d_off[NB];
     for (int b = 0; b < NB; ++b) {
         d_patches[b] = (uint8_t *)ws_alloc(ctx, (size_t)chunk_cap * P3);
-        d_rows[b] = (float *)ws_alloc(ctx, 4 * (size_t)chunk_cap * F + 8);
+        d_rows[b] = rows_direct ? rows_direct : (float *)ws_alloc(ctx, 4 * (size_t)chunk_cap * F + 8);
         d_sel[b] = (uint32_t *)ws_alloc(ctx, 4 * (size_t)chunk_cap + 8);
         d_off[b] = (uint32_t *)ws_alloc(ctx, 4 * ((size_t)chunk_cap + 1));
     }
@@ -196,14 +223,37 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     const size_t ws_mark[2] = {ctx->ws->off, ctx->ws->off + al(scratch)};
     if (ctx->ws->cap - ws_mark[0] < 2 * al(scratch)) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
     if ((st = prepare_sets(ctx, sets, n_sets)) != NFX_OK) return st;
-    NFX_HIP(ctx, hipMemcpyAsync(d_off_all, ring_offsets, 4 * ((size_t)n + 1), hipMemcpyHostToDevice, compute));
-    if (nv) NFX_HIP(ctx, hipMemcpyAsync(d_xy, ring_xy, 8 * (size_t)nv, hipMemcpyHostToDevice, compute));
-    NFX_HIP(ctx, launch_preprocess(ctx, n, d_off_all, d_xy, d_cen, nullptr));
-    std::vector<float> cen(2 * (size_t)n);
-    NFX_HIP(ctx, hipMemcpyAsync(cen.data(), d_cen, 8 * (size_t)n, hipMemcpyDeviceToHost, compute));
-    NFX_HIP(ctx, hipStreamSynchronize(compute));
-    if (out_centroids_xy) memcpy(out_centroids_xy, cen.data(), 8 * (size_t)n);
-    int64_t other_h2d = 4 * (n + 1) + 8 * nv;
+    if (!ctx->ev_front) NFX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_front, hipEventDisableTiming));
+    if (!ctx->ev_front_up) NFX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_front_up, hipEventDisableTiming));
+    if (!ctx->ev_front_cen) NFX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_front_cen, hipEventDisableTiming));
+    // The centroids address the windows (k_preprocess: the loader's own arithmetic), so the host needs them before it can plan a chunk.
+    // They are made a FRONTIER at a time, a chunk or two ahead of the plan, not all up front: the rings of nuclei [front, upto) travel on the
+    // copy stream (ahead of the bands that will be planned from them), are centred on the rows stream and their centroids come home on
+    // the d2h stream -- so the first band leaves a millisecond into the call instead of behind 310 MB of vertices (1.25 M nuclei), and
+    // the rest of the rings travel in the link's spare time (it outruns the extraction).
+    float *const cen = (float *)Pinned::get(ctx, 0, 8 * (size_t)n + 64); // pinned: the copy home is asynchronous
+    if (!cen) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "pinned staging (centroids)");
+    NFX_HIP(ctx, hipMemcpyAsync(d_off_all, ring_offsets, 4 * ((size_t)n + 1), hipMemcpyHostToDevice, copy));
+    int64_t front = 0, other_h2d = 4 * (n + 1) + 8 * nv;
+    auto advance_front = [&](int64_t upto) -> hipError_t { // enqueue only; ev_front fires when the centroids of [0, upto) are on the host
+        upto = std::min<int64_t>(upto, n);
+        if (upto <= front) return hipSuccess;
+        const size_t v0 = ring_offsets[front], v1 = ring_offsets[upto];
+        hipError_t e = hipSuccess;
+        if (v1 > v0) e = hipMemcpyAsync(d_xy + 2 * v0, ring_xy + 2 * v0, 8 * (v1 - v0), hipMemcpyHostToDevice, copy);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_front_up, copy);
+        if (e == hipSuccess) e = hipStreamWaitEvent(rows_s, ctx->ev_front_up, 0);
+        if (e != hipSuccess) return e;
+        ctx->stream = rows_s;
+        e = launch_preprocess(ctx, upto - front, d_off_all + front, d_xy, d_cen + 2 * front, nullptr); // (offsets are absolute: d_xy is the base)
+        ctx->stream = compute;
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_front_cen, rows_s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(d2h, ctx->ev_front_cen, 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(cen + 2 * front, d_cen + 2 * front, 8 * (size_t)(upto - front), hipMemcpyDeviceToHost, d2h);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_front, d2h);
+        front = upto;
+        return e;
+    };
 
     // ---- the plan, made chunk by chunk while the device works on the chunks before: the band of every nucleus's window, chunks of
     // whole batches whose bands fit the cache, the chunk's nuclei grouped by band (a counting sort: bands are few) -----------------
@@ -217,25 +267,35 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     std::vector<uint32_t> band_count((size_t)nblocks, 0);
     std::vector<int64_t> blk_buf((size_t)chunk_cap);
     int64_t plan_next = 0, plan_index = 0;             // first nucleus / index of the chunk the next plan() call makes
+    std::vector<int64_t> block_slot((size_t)nblocks, -1); // band -> cache slot (-1: not resident); kept by enqueue_copy
+    // RAMP-UP.  The call's first chunks end where their nuclei would need a SECOND band that is not on the device yet: the first chunk
+    // then waits for one band (302 MB at 47 703 pixels across: 5 ms) instead of two, and while it is extracted the link delivers exactly
+    // the one band the next chunk needs.  After `ramp` chunks the link is ahead for good (it outruns the extraction) and chunks take
+    // their full size -- fewer launches, fewer tails.  NFX_STREAM_RAMP overrides (0: none).
+    int64_t ramp = 2;
+    if (const char *e = getenv("NFX_STREAM_RAMP")) ramp = atoll(e);
+    const int64_t ramp_min = std::min<int64_t>(chunk_cap, std::max<int64_t>(batch_size, (chunk_cap / 8 / batch_size) * batch_size)); // (never slivers)
     auto plan = [&](Chunk &c) {                        // a single batch that needs more bands than the cache holds is a chunk of its own
         c.i0 = plan_next; c.blocks.clear(); c.sel.clear(); c.sel_off.clear();
         const int64_t ck = plan_index++;
-        int64_t i = c.i0, distinct = 0;
+        int64_t i = c.i0, distinct = 0, fresh = 0;    // bands of the chunk | those among them that still have to travel
         while (i < n && i - c.i0 < chunk_cap) {
             const int64_t e = std::min<int64_t>(n, i + batch_size);
-            int64_t add = 0;
+            int64_t add = 0, add_fresh = 0;
             for (int64_t j = i; j < e; ++j) {
                 const int64_t bnd = band_of(j);
                 blk_buf[(size_t)(j - c.i0)] = bnd;
-                if (stamp[bnd] != ck && stamp[bnd] != -2 - ck) { stamp[bnd] = -2 - ck; ++add; }
+                if (stamp[bnd] != ck && stamp[bnd] != -2 - ck) { stamp[bnd] = -2 - ck; ++add; add_fresh += block_slot[bnd] < 0; }
             }
-            const bool fits = distinct + add <= n_slots;
+            bool fits = distinct + add <= n_slots;
+            if (fits && ck < ramp && fresh + add_fresh > 1 && i - c.i0 >= ramp_min) fits = false; // ramp-up: one travelling band per chunk
             for (int64_t j = i; j < e; ++j) { // settle the tentative marks: counted (the batch joins the chunk) or forgotten
                 int64_t &m = stamp[blk_buf[(size_t)(j - c.i0)]];
                 if (m == -2 - ck) m = (fits || i == c.i0) ? ck : -1;
             }
             if (!fits && i > c.i0) break;      // this batch opens the next chunk
             distinct += add;
+            fresh += add_fresh;
             i = e;
             if (!fits) break;                  // ... one batch wider than the cache: gathered in several passes (enqueue_copy)
         }
@@ -258,7 +318,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     // ---- pinned staging: selection lists and rebased offsets of two chunks -------------------------------------------------------
     const bool img_pinned = is_pinned(image_u8); // (a pageable image is copied by the runtime through its own staging: correct, not overlapped)
     const size_t stage_bytes = NB * (4 * (size_t)chunk_cap + 4 * ((size_t)chunk_cap + 1) + 128) + 512;
-    uint8_t *pin = (uint8_t *)Pinned::get(ctx, stage_bytes);
+    uint8_t *pin = (uint8_t *)Pinned::get(ctx, 1, stage_bytes);
     if (!pin) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "pinned staging");
     uint32_t *h_sel[NB], *h_off[NB];
     {
@@ -267,7 +327,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     }
 
     // ---- block cache ---------------------------------------------------------------------------------------------------------
-    std::vector<int64_t> slot_block((size_t)n_slots, -1), slot_use((size_t)n_slots, -1), block_slot((size_t)nblocks, -1);
+    std::vector<int64_t> slot_block((size_t)n_slots, -1), slot_use((size_t)n_slots, -1);
     int64_t img_h2d = 0, blocks_copied = 0, rows_d2h = 0, use_tick = 0, gather_passes = 0;
 
     auto fail_sync = [&](nfx_status s) { // an error mid-way: nothing may still be in flight on the private streams when the call returns
@@ -355,10 +415,16 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     // Order of the host's work per chunk k: enqueue extract(k) -- its windows were gathered while chunk k-1 ran --, THEN plan chunk
     // k+1 and send its bands on their way (the host first waits for extract(k-2), whose buffers chunk k+1 takes over: two
     // extractions are queued on the device at that moment, so it never runs dry while the host sleeps), and the rows of chunk k home.
+    // The centroid frontier runs two chunks ahead of the plan: plan(j) reads the centroids of [plan_next, plan_next + chunk_cap); right
+    // after it the frontier is pushed to plan_next + 2 chunk_cap -- enqueued AHEAD of chunk j's bands on the copy stream (25 MB of rings
+    // before 300-600 MB of bands), so that by the time the host comes to plan(j + 1) it waits for nothing that lies behind those bands.
     int64_t nchunks = 0;
     bool have = plan_next < n, have_next = false;
     if (have) {
+        NFX_HIP_S(advance_front(chunk_cap));
+        NFX_HIP_S(hipEventSynchronize(ctx->ev_front));
         plan(plans[0]);
+        NFX_HIP_S(advance_front(plan_next + 2 * chunk_cap));
         if ((st = enqueue_copy(0)) != NFX_OK) return st;
     }
     for (int64_t k = 0; have; ++k, have = have_next) {
@@ -367,34 +433,43 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         const int64_t i0 = plans[k & 1].i0, i1 = plans[k & 1].i1, m = i1 - i0;
         ++nchunks;
         NFX_HIP_S(hipStreamWaitEvent(cstream, ctx->ev_ready[b], 0));
-        if (k >= NB) NFX_HIP_S(hipStreamWaitEvent(cstream, ctx->ev_rows[b], 0)); // rows[b] of chunk k-3 have left for the host
+        if (k >= NB && !rows_direct) NFX_HIP_S(hipStreamWaitEvent(cstream, ctx->ev_rows[b], 0)); // rows[b] of chunk k-3 have left for the host
         ctx->ws->off = ws_mark[k & 1];
         ctx->stream = cstream;
         const uint32_t v0 = ring_offsets[i0], v1 = ring_offsets[i1];
-        st = extract_device(ctx, sets, n_sets, m, (int64_t)(v1 - v0), d_off[b], d_xy + 2 * (size_t)v0, d_patches[b], nullptr, 0, 0, ps, batch_size, d_rows[b], nullptr);
+        st = extract_device(ctx, sets, n_sets, m, (int64_t)(v1 - v0), d_off[b], d_xy + 2 * (size_t)v0, d_patches[b], nullptr, 0, 0, ps, batch_size,
+                            rows_direct ? rows_direct + (size_t)i0 * F : d_rows[b], nullptr);
         ctx->stream = compute;
         if (st != NFX_OK) return fail_sync(st);
         NFX_HIP_S(hipEventRecord(ctx->ev_done[b], cstream));
-        NFX_HIP_S(hipStreamWaitEvent(d2h, ctx->ev_done[b], 0));
-        NFX_HIP_S(hipMemcpyAsync(out_rows + (size_t)i0 * F, d_rows[b], 4 * (size_t)m * F, hipMemcpyDeviceToHost, d2h));
-        NFX_HIP_S(hipEventRecord(ctx->ev_rows[b], d2h));
+        if (!rows_direct) {
+            NFX_HIP_S(hipStreamWaitEvent(d2h, ctx->ev_done[b], 0));
+            NFX_HIP_S(hipMemcpyAsync(out_rows + (size_t)i0 * F, d_rows[b], 4 * (size_t)m * F, hipMemcpyDeviceToHost, d2h));
+            NFX_HIP_S(hipEventRecord(ctx->ev_rows[b], d2h));
+        }
         rows_d2h += 4 * m * F;
         have_next = plan_next < n;
         if (have_next) {
+            NFX_HIP_S(hipEventSynchronize(ctx->ev_front)); // centroids of [0, plan_next + chunk_cap) and beyond are home
             plan(plans[(k + 1) & 1]);
+            NFX_HIP_S(advance_front(plan_next + 2 * chunk_cap));
             if ((st = enqueue_copy(k + 1)) != NFX_OK) return st;
         }
     }
+    NFX_HIP_S(advance_front(n)); // (nuclei behind the last chunk's end: none -- every nucleus belongs to a chunk; kept for the invariant front == n)
 #undef NFX_HIP_S
     NFX_HIP(ctx, hipStreamSynchronize(copy));
     NFX_HIP(ctx, hipStreamSynchronize(cs[0]));
     NFX_HIP(ctx, hipStreamSynchronize(cs[1]));
     NFX_HIP(ctx, hipStreamSynchronize(rows_s));
     NFX_HIP(ctx, hipStreamSynchronize(d2h));
-    if (stats) {
-        stats->image_bytes_h2d = img_h2d; stats->other_bytes_h2d = other_h2d; stats->rows_bytes_d2h = rows_d2h + 8 * n;
-        stats->blocks_copied = blocks_copied; stats->blocks_total = nblocks; stats->chunks = nchunks; stats->block_slots = n_slots;
-        stats->image_pinned = img_pinned ? 1 : 0; stats->split_gather_passes = gather_passes;
+    if (out_centroids_xy) memcpy(out_centroids_xy, cen, 8 * (size_t)n);
+    {
+        nfx_stream_stats full{};
+        full.image_bytes_h2d = img_h2d; full.other_bytes_h2d = other_h2d; full.rows_bytes_d2h = rows_d2h + 8 * n;
+        full.blocks_copied = blocks_copied; full.blocks_total = nblocks; full.chunks = nchunks; full.block_slots = n_slots;
+        full.image_pinned = img_pinned ? 1 : 0; full.split_gather_passes = gather_passes; full.rows_direct = rows_direct ? 1 : 0;
+        put_stats(full);
     }
     return NFX_OK;
 }

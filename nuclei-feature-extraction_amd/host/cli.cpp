@@ -264,7 +264,8 @@ int main(int argc, char **argv)
                 std::vector<uint32_t> off((size_t)(i1 - i0 + 1));
                 const uint32_t base = poly.ring_offsets[(size_t)i0];
                 for (int64_t i = i0; i <= i1; ++i) off[(size_t)(i - i0)] = poly.ring_offsets[(size_t)i] - base;
-                nfx_stream_stats ss;
+                nfx_stream_stats ss{};
+                ss.struct_size = sizeof ss;
                 const nfx_status st = nfx_extract_tile_streamed(ctxs[(size_t)r], sets.data(), n_sets, i1 - i0, off.back(), off.data(),
                                                                 poly.ring_xy.data() + 2 * (size_t)base, img.data.data(), img.H, img.W, args.patch_size,
                                                                 args.batch_size, 0, 0, 0, rows.data() + (size_t)i0 * F, cen.data() + 2 * (size_t)i0, &ss);

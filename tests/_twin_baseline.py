@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A libtorch-shaped CPU data point for the geometry path (test / bench infrastructure, never on the product path).
+"""A libtorch-shaped CPU data point for every feature set (test / bench infrastructure, never on the product path).
 
 The reference runs `geometry` as rayon `par_chunks(batch_size)` over the nuclei, one batch per worker thread, and inside a batch a
 serial per-nucleus loop of ~25 small ATen calls, one LAPACK `geev`, one ellipse rasterisation and >= 10 scalar reads
@@ -10,7 +10,15 @@ are absent) are stood in for by the C oracle -- polygon and ellipse rasterisatio
 CHEAPER than the tensor programs tch-utils runs for them, so the figure flatters the reference.  It is "a restatement of the
 reference's libtorch-CPU path", not the reference.
 
+The other sets (`--sets`, round 5) run as the batched tensor programs their call sites fix: ColorFeatureSet op for op (color.rs:43-99, the
+accidental [N,N,ps,ps] broadcast of circular_mean included), GlcmFeatureSet as 16 dense [N,L,L] co-occurrence tensors built with
+index_put_(accumulate) and reduced fourteen times each with one host copy per column (texture.rs:38-79), GLRLMFeatureSet as four dense
+[N,24,16] tensors (texture.rs:191-215), GaborFilterFeatureSet as one conv2d to 48 channels + masked mean / variance (texture.rs:332-344) --
+tests/_torch_twin.py, whose dependency-resident pieces (hsv / hed transforms, what glcm / glrlm / the filter bank compute) follow the
+oracle's definitions.
+
     python tests/_twin_baseline.py --ps 32 --nuclei 100000 --batch 100 --procs 16 --seconds 12   -> one JSON line
+    python tests/_twin_baseline.py --ps 64 --sets all --seed-index 4 --nuclei 2000 --procs 16      (the full feature set)
 Must be started BEFORE the calling process touches a GPU, or as an ordinary child process (it never touches one itself).
 """
 import argparse
@@ -40,15 +48,33 @@ def _init():
 
 def _batch(job):
     """one reference batch: loader stand-in (preprocess + rasterise) + ShapeFeatureSet::compute_features_batched"""
-    seed, i0, m, ps = job
+    seed, i0, m, ps, sets = job
     torch, orc, tw, synth = _state["torch"], _state["orc"], _state["tw"], _state["synth"]
     off, xy = synth.polygons(seed, i0, m, ps)
+    pu8 = synth.patches(seed, i0, m, ps) if any(s != 0 for s in sets) else None
     t0 = time.perf_counter()
     half = np.float32(ps) / np.float32(2.0)
     rows = np.empty((m, 12), np.float64)
-    for i in range(m):
-        _, ctr = orc.preprocess_polygon(xy[off[i]:off[i + 1]])           # utils.rs:54-74
-        mask = torch.from_numpy(orc.raster_polygon(ctr, ps)).unsqueeze(0)  # tch_utils::shapes::polygon stand-in
+    # the loader's part (utils.rs:141-206): centred ring, mask, u8 / 255 -- per nucleus, then stacked into the batch's two tensors
+    ctrs = [orc.preprocess_polygon(xy[off[i]:off[i + 1]])[1] for i in range(m)]                     # utils.rs:54-74
+    masks = torch.stack([torch.from_numpy(orc.raster_polygon(c, ps)).unsqueeze(0) for c in ctrs])   # tch_utils::shapes::polygon stand-in
+    patchs = torch.from_numpy(pu8).to(torch.float32) / 255.0 if pu8 is not None else None           # utils.rs:172
+    check = 0.0
+    with torch.no_grad():
+        for s in sets:
+            if s == 1:
+                check += float(tw.color_features(patchs, masks, tw.hsv_from_rgb_spec(patchs), tw.hed_from_rgb_spec(patchs)).nansum())
+            elif s == 2:
+                check += float(tw.glcm_set(patchs, masks).nansum())
+            elif s == 3:
+                check += float(tw.glrlm_set(patchs, masks).nansum())
+            elif s == 4:
+                if "bank" not in _state:
+                    _state["bank"] = torch.from_numpy(orc.gabor_bank()).unsqueeze(1)
+                check += float(tw.gabor_set(patchs, masks, _state["bank"]).nansum())
+    for i in range(m if 0 in sets else 0):
+        ctr = ctrs[i]
+        mask = masks[i]
         com = tw.center_of_mass(mask)                                    # shape.rs:71
         res = tw.major_minor_axes_w_angle(mask)                          # shape.rs:76
         major, minor, angle = res[0], res[1], res[2]
@@ -57,7 +83,7 @@ def _batch(job):
         ed = tw.eliptic_deviation(mask, torch.from_numpy(ell).unsqueeze(0))  # shape.rs:105
         p = orc.polygon_features_f64(ctr)                                # geometric_features::* stand-in (shape.rs:89-97)
         rows[i] = (p[0], major, minor, ecc, angle, p[1], p[2], p[3], ed, p[4], p[5], p[6])
-    return m, time.perf_counter() - t0, float(np.nansum(rows[:, 1]))
+    return m, time.perf_counter() - t0, check + (float(np.nansum(rows[:, 1])) if 0 in sets else 0.0)
 
 
 def main():
@@ -68,28 +94,37 @@ def main():
     ap.add_argument("--procs", type=int, default=min(len(os.sched_getaffinity(0)), 16))
     ap.add_argument("--seconds", type=float, default=12.0)
     ap.add_argument("--seed-index", type=int, default=1)
+    ap.add_argument("--sets", default="geometry", help="comma separated CLI names (args.rs:18-49): geometry color glcm glrlm gabor texture all")
     a = ap.parse_args()
+    nfx = importlib.import_module("nuclei-feature-extraction_amd")
+    sets = nfx.parse_feature_sets(a.sets.split(","))
+    sets_t = tuple(sets)
     synth = importlib.import_module("nuclei-feature-extraction_amd.synth")
     seed = synth.SEED_BASE + a.seed_index
     with mp.get_context("fork").Pool(a.procs, initializer=_init) as pool:
-        pool.map(_batch, [(seed, 0, 2, a.ps)] * a.procs)   # workers up (torch imported, oracle loaded) before anything is timed
+        pool.map(_batch, [(seed, 0, 2, a.ps, sets_t)] * a.procs)   # workers up (torch imported, oracle loaded) before anything is timed
         # calibrate on one batch per worker, then size the sample for the asked wall time
         t0 = time.perf_counter()
-        cal = pool.map(_batch, [(seed, k * a.batch, a.batch, a.ps) for k in range(a.procs)])
+        cal = pool.map(_batch, [(seed, k * a.batch, a.batch, a.ps, sets_t) for k in range(a.procs)])
         dt = time.perf_counter() - t0
         rate = sum(c[0] for c in cal) / dt
         nb = int(max(a.procs, min(a.nuclei // a.batch, rate * a.seconds / a.batch)))
+        nb = (nb // a.procs) * a.procs or a.procs          # whole rounds of the pool: no core idles while the last batches run
         t0 = time.perf_counter()
-        res = pool.map(_batch, [(seed, k * a.batch, a.batch, a.ps) for k in range(nb)], chunksize=1)
+        res = pool.map(_batch, [(seed, k * a.batch, a.batch, a.ps, sets_t) for k in range(nb)], chunksize=1)
         wall = time.perf_counter() - t0
     n = sum(r[0] for r in res)
     print(json.dumps({"value": round(n / wall, 1), "unit": "nuclei/s", "cores": a.procs, "kind": "aten-twin",
                       "sample": f"first {n} nuclei of the workload in {nb} reference batches of {a.batch}, one process per core "
                                 f"(torch.set_num_threads(1)), {wall:.1f} s",
-                      "what": "tests/_torch_twin.py: the reference's per-nucleus ATen op sequence for ShapeFeatureSet (shape.rs:66-111; "
-                              "center_of_mass, covariance mm, linalg_eig, eliptic_deviation) on torch-CPU, batch-per-worker like rayon "
-                              "(main.rs:146-151); rasterisers and geometric_features stood in for by the C oracle (cheaper than "
-                              "tch-utils' tensor programs): a restatement of the reference's libtorch-CPU path, not the reference",
+                      "feature_sets": [nfx.feature_set_cli_name(x) for x in sets], "patch_size": a.ps,
+                      "what": "tests/_torch_twin.py on torch-CPU, batch-per-worker like rayon (main.rs:146-151): the reference's per-nucleus ATen op "
+                              "sequence for ShapeFeatureSet (shape.rs:66-111; center_of_mass, covariance mm, linalg_eig, eliptic_deviation), "
+                              "ColorFeatureSet op for op (color.rs:43-99, the [N,N,ps,ps] broadcast included), the texture sets as the dense "
+                              "tensor programs their call sites fix (16 x [N,L,L] GLCM by index_put_(accumulate) + 14 reductions each, 4 x "
+                              "[N,24,16] GLRLM, conv2d to 48 channels: texture.rs:38-79,191-215,332-344); rasterisers, geometric_features, "
+                              "hsv / hed and the filter bank stood in for by the oracle's definitions: a restatement of the reference's "
+                              "libtorch-CPU path, not the reference",
                       "per_nucleus_us_single_core": round(1e6 * sum(r[1] for r in res) / n, 1)}), flush=True)
 
 

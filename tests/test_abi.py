@@ -18,7 +18,23 @@ def test_library_exports_every_declared_symbol(nfx):
     L = nfx.lib()
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.nfx_version() == 300
+    assert L.nfx_version() == 400
+
+
+def test_stream_stats_mirror_matches_the_header(nfx, tmp_path):
+    """nfx_stream_stats as the C compiler lays it out == the Python mirror (struct_size first, then STREAM_STATS_FIELDS in order):
+    a field added to one and not the other is caught here, not as memory written past a caller's struct."""
+    import subprocess
+    fields = ("struct_size",) + tuple(nfx.STREAM_STATS_FIELDS)
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nfx.h"\nint main(void){printf("%zu", sizeof(nfx_stream_stats));'
+                   + "".join(f'printf(" %zu", offsetof(nfx_stream_stats, {f}));' for f in fields) + 'printf(" %d", NFX_VERSION);return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got[0] == 8 * len(fields)
+    assert got[1:-1] == [8 * j for j in range(len(fields))]
+    assert got[-1] == nfx.lib().nfx_version()
 
 
 def test_registry_names_and_counts(nfx):
@@ -101,3 +117,23 @@ def test_a_host_without_rccl_gets_unsupported_not_a_crash():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stderr[-400:])
     assert "status [2, 2]" in r.stdout, r.stdout
+
+
+def test_one_hip_runtime_per_process_and_the_bad_order_is_refused():
+    """torch first: libnfx binds the runtime torch already mapped (ONE libamdhip64 in /proc/self/maps).  libnfx first: a later `import torch`
+    maps a second one -- Context() refuses that order with the cure in the message instead of leaving torch with "No HIP GPUs"."""
+    import subprocess
+    import sys
+    pre = "import sys, importlib; sys.path.insert(0, %r); " % ROOT
+    good = pre + ("import torch; nfx = importlib.import_module('nuclei-feature-extraction_amd'); nfx.lib(); m = nfx.hip_runtimes_mapped(); "
+                  "print(len(m), 'torch' in m[0])")
+    r = subprocess.run([sys.executable, "-c", good], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.split() == ["1", "True"], r.stdout + r.stderr[-500:]
+    bad = pre + ("nfx = importlib.import_module('nuclei-feature-extraction_amd'); nfx.lib(); m0 = nfx.hip_runtimes_mapped(); import torch\n"
+                 "m = nfx.hip_runtimes_mapped(); print(len(m0), 'rocm' in m0[0], len(m))\n"
+                 "try:\n    nfx.Context(0)\n    print('no error')\nexcept nfx.NfxError as e:\n    print('refused' if 'two HIP runtimes' in str(e) and 'Import torch BEFORE' in str(e) else str(e))")
+    r = subprocess.run([sys.executable, "-c", bad], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.split() == ["1", "True", "2", "refused"], r.stdout + r.stderr[-500:]
+    free = pre + "nfx = importlib.import_module('nuclei-feature-extraction_amd'); nfx.lib(); print(len(nfx.hip_runtimes_mapped()), 'torch' in sys.modules)"
+    r = subprocess.run([sys.executable, "-c", free], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.split() == ["1", "False"], r.stdout + r.stderr[-500:]

@@ -81,6 +81,30 @@ def test_equal_shards_single_slice():
     assert np.array_equal(got, want, equal_nan=True)
 
 
+def test_eight_ranks_ragged_and_empty_shards():
+    """The target world size (8 ranks, gloo on the CPU): 181 nuclei in batches of 16 are 12 batches, two per rank -- ranks 0..4 hold 32
+    nuclei, rank 5 holds the ragged tail (16 + 5), ranks 6 and 7 hold NOTHING; every rank still takes part in every gather, over
+    several steps (both row buffers in use), and the gathered matrix is the single-process one row for row."""
+    got, want, ok, counts, bounds = _run(n=181, world=8, n_slices=2, steps=3)
+    assert counts == [32, 32, 32, 32, 32, 21, 0, 0] and bounds == [0, 16, 32]
+    assert ok == [True] * 8
+    assert got.shape == want.shape and np.array_equal(got, want, equal_nan=True)
+
+
+def test_eight_ranks_fewer_batches_than_ranks():
+    """n < 8 batches: 40 nuclei are three batches of 16, so ranks 3..7 have no shard at all (main.rs:146-148 with fewer chunks than workers)."""
+    got, want, ok, counts, bounds = _run(n=40, world=8, n_slices=4, steps=2)
+    assert counts == [16, 16, 8, 0, 0, 0, 0, 0] and bounds == [0, 16]       # one batch per rank: the four slices collapse to one
+    assert ok == [True] * 8
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_eight_ranks_equal_shards():
+    got, want, ok, counts, _ = _run(n=8 * 32, world=8, n_slices=2, steps=2)
+    assert counts == [32] * 8 and ok == [True] * 8
+    assert np.array_equal(got, want, equal_nan=True)
+
+
 def test_shard_cut_inside_a_batch_changes_mean_h():
     """Why shard boundaries must be multiples of the reference batch: mean_h (column 12+6) couples a batch.
     Shards aligned to 20 nuclei cut the reference batches of 16."""

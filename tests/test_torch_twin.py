@@ -156,3 +156,26 @@ def test_gray_is_f32_sum_then_div(synth):
     x = p.numpy()
     mine = ((x[:, 0] + x[:, 1]) + x[:, 2]) / np.float32(3.0)
     assert np.array_equal(g, mine)
+
+
+@pytest.mark.parametrize("n,ps", [(5, 32), (3, 64)])
+def test_dense_texture_programs_follow_the_oracles_definitions(synth, n, ps):
+    """The libtorch-shaped baseline's tensor programs (dense [N,L,L] GLCM + 14 reductions, dense [N,24,16] GLRLM, conv2d Gabor) compute
+    what the oracle defines: counts `==`, features to f32-dense-arithmetic accuracy."""
+    off, xy, patches, masks = _color_batch(synth, n, ps, seed=17)
+    p = torch.from_numpy(patches)
+    m = torch.from_numpy(masks).unsqueeze(1)
+    gs = tw.gray(p)
+    for L, (dy, dx) in ((32, (0, 1)), (254, (1, -1)), (128, (1, 1))):
+        P = tw.glcm_dense(gs, (dy, dx), L, m, True)
+        for i in range(n):
+            G = orc.glcm_counts(patches[i], masks[i], L, dy, dx)
+            np.testing.assert_allclose(P[i].numpy() * G.sum(), G, atol=1e-3)
+    for d, (dx, dy) in enumerate(tw.GLRLM_DIRECTIONS):
+        R = tw.glrlm_dense(gs, 24, 16, (dx, dy), m)
+        for i in range(n):
+            assert np.array_equal(R[i].numpy(), orc.glrlm_counts(patches[i], masks[i], dx, dy))
+    for set_id, got in ((2, tw.glcm_set(p, m)), (3, tw.glrlm_set(p, m))):
+        want = orc.compute_features_batched(set_id, off, xy, patches, masks)
+        err = np.abs(got.numpy() - want) / (np.abs(want) + 1e-3 * np.abs(want).max(axis=0, keepdims=True) + 1e-6)
+        assert np.nanmax(err) <= 5e-3, (set_id, np.nanmax(err), np.unravel_index(np.nanargmax(err), err.shape))
