@@ -534,8 +534,9 @@ def main():
     def fence(sx=None):
         if sx is not None:
             sx.finish()
+        torch.cuda.synchronize()      # this rank's device work is done ...
         if use_dist:
-            dist.barrier()
+            dist.barrier()            # ... and so is every other rank's (the control group's barrier is a host barrier)
         torch.cuda.synchronize()
 
     def sharded(n_total, Fx):
@@ -659,16 +660,18 @@ def main():
                 also["config3_resident" if world == 1 else "weak_config3_rccl_gather"] = e
             # BASELINE configs[3]: the SAME nuclei cut into `world` batch-aligned shards (strong scaling); rank 0's weak-scaling inputs start with
             # exactly those nuclei, so it can check the gathered matrix against its own single-GPU result
-            n_strong = ((args.strong_nuclei or (WORKLOADS["config3"][0] if full_size else 0)) // B) * B
-            if world > 1 and use_dist and 0 < n_strong <= r3.n:
+            n_strong = args.strong_nuclei or (WORKLOADS["config3"][0] if full_size else 0)     # (any number: the last shard may be ragged, later ones empty)
+            if world > 1 and use_dist and n_strong > 0:
                 ssx = sharded(n_strong, r3.F)
                 rs = Resident(nfx, synth, torch, dev, "config3", ssx.n_local, ssx.i0, WORKLOADS["config3"][2])
+                ctx.reserve(rs.sets, max(rs.n, n_strong if rank == 0 else 0), max(len(rs.xy), len(r3.xy)) + 64 * n_strong, rs.ps, batch_size=B)
                 el_s, _ = timed(torch, ctl, ctx, args.steps, 1, lambda: ssx.step(lambda b0, b1, out: rs.extract(ctx, b0, b1, out, B)), lambda: fence(ssx))
                 oks = ssx.verify_transport()
                 full = ssx.result()
                 if rank == 0:
+                    whole = r3 if n_strong <= r3.n else Resident(nfx, synth, torch, dev, "config3", n_strong, 0, WORKLOADS["config3"][2])
                     single = torch.empty((n_strong, r3.F), dtype=torch.float32, device=dev)
-                    r3.extract(ctx, 0, n_strong, single, B)
+                    whole.extract(ctx, 0, n_strong, single, B)
                     torch.cuda.synchronize()
                     also["strong_scaling_config4"] = {
                         "value": round(n_strong * args.steps / el_s, 1), "unit": "nuclei/s", "ms_per_step": round(el_s / args.steps * 1e3, 3), "scaling": "strong",
@@ -676,7 +679,7 @@ def main():
                                 "rows gathered to rank 0", "shard_nuclei": ssx.counts, "gather_checksums_match": bool(all(oks)),
                         "gathered_equals_single_gpu": bool(torch.equal(full.to(dev).view(torch.int32), single.view(torch.int32))),
                         "gathered_checksum": D.row_checksum(full)}
-                    single = None
+                    single = whole = None
                 dist.barrier()
                 ssx = rs = full = None
             r3 = None

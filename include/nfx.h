@@ -224,8 +224,10 @@ nfx_status nfx_extract_tile(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n
    two bands; any other order only costs copies).  `cache_bytes` is honoured down to ONE band (a smaller value keeps one): a batch
    whose windows start in more bands than the cache holds is gathered in several passes over its bands -- the gather needs one band
    at a time, only the extraction needs all of a batch's patches -- so no cache size makes a call fail, a small one only re-copies.  For the link's full rate and for copies that overlap compute, image_u8 and out_rows should be pinned
-   for THIS library's HIP runtime (nfx_host_alloc, or nfx_host_register on memory of the caller's own; memory pinned by another
-   runtime in the process, e.g. PyTorch's, counts as pageable and is staged by the runtime).
+   for the HIP runtime this library is bound to (nfx_host_alloc, or nfx_host_register on memory of the caller's own).  A process holds ONE
+   HIP runtime: /opt/rocm's when nothing else brought one, PyTorch's bundled one when torch was imported before this library was loaded --
+   its pinned tensors are then pinned for this library too; the other load order maps two runtimes and leaves torch without a GPU
+   (the Python binding refuses it).
    When out_rows is pinned the kernels write the rows straight into it over the link (NFX_STREAM_ROWS=copy in the environment keeps the
    staged form: a device buffer per chunk and a copy behind it).
    stats (may be NULL; set stats->struct_size = sizeof(nfx_stream_stats) before the call): what travelled ("blocks" = bands). */

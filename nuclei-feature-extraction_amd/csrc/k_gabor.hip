@@ -245,9 +245,10 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
     for (int g = g_begin; g < g_end; ++g) {
         const float *__restrict__ img = tab->groups[g].image; // wave-uniform: the taps arrive through the scalar cache
         // ---- row pass ---------------------------------------------------------------------------------------------
-        const bool envelope = __float_as_int(img[GB_META + 1]) != 0; // both row kernels are the bare envelope (90 / 0 degree groups)
+        const int env_flag = __float_as_int(img[GB_META + 1]);       // 0: a genuine kernel pair; 1: envelope group whose column taps are mirror-symmetric; 2: envelope group, taps not bit-symmetric
+        const bool envelope = env_flag != 0; // both row kernels are the bare envelope (90 / 0 degree groups)
         const int n_pass = __float_as_int(img[GB_META]);
-        const bool fused = NFX_GB_ENV_FUSED && envelope && n_pass == GB_MAX_PASSES && ct <= NFX_GB_ENV_MAX_CT; // wave-uniform
+        const bool fused = NFX_GB_ENV_FUSED && env_flag == 1 && n_pass == GB_MAX_PASSES && ct <= NFX_GB_ENV_MAX_CT; // wave-uniform
         auto load_window = [&](auto win_tag, float (&x)[decltype(win_tag)::value]) {
             constexpr int WIN = decltype(win_tag)::value;
             if (tr) { // window element j is gray row c0 + j - 15 (wave-uniform): outside the patch it is the apron's zero
@@ -943,7 +944,6 @@ static void build_tables(GaborTables &T)
             GaborGroup *G = new_group();
             if (!G) { ok = false; break; }
             for (int j = 0; j < GB_SIZE; ++j) set_row(*G, j, env(tk(j)), env(tk(j)));
-            { const int one = 1; memcpy(&G->image[GB_META + 1], &one, sizeof(int)); } // the row pass pairs output positions
             for (int p = 0; p < GB_MAX_PASSES && i + 2 * p < col.size(); ++p) {
                 Uniq *u = col[i + 2 * p], *v = i + 2 * p + 1 < col.size() ? col[i + 2 * p + 1] : nullptr;
                 for (int j = 0; j < GB_SIZE; ++j)
@@ -953,6 +953,15 @@ static void build_tables(GaborTables &T)
                 if (v) v->placed = true;
                 G->n_pass = p + 1;
             }
+            // the row pass pairs output positions (flag != 0); the column passes may share a FOLDED window (column_passes_env multiplies taps j and
+            // 29 - j by ONE weight) only if the f32 taps really are mirror images of each other -- tk(j) and tk(29 - j) are computed independently in
+            // f64 and rounded, so this is checked, not assumed: flag 1 = symmetric bit for bit, 2 = not (the generic passes run)
+            int flag = 1;
+            for (int p = 0; p < G->n_pass; ++p)
+                for (int j = 0; j < GB_SIZE / 2; ++j)
+                    for (int h = 0; h < 2; ++h)
+                        if (memcmp(&G->image[(1 + p) * GB_WSLOT + 2 * j + h], &G->image[(1 + p) * GB_WSLOT + 2 * (GB_SIZE - 1 - j) + h], sizeof(float)) != 0) flag = 2;
+            memcpy(&G->image[GB_META + 1], &flag, sizeof(int));
         }
     }
     for (auto &u : uniq) ok = ok && u.placed;

@@ -316,8 +316,10 @@ void nfx_ctx_destroy(nfx_ctx *ctx)
     if (ctx->d2h_stream) { (void)hipStreamSynchronize(ctx->d2h_stream); (void)hipStreamDestroy(ctx->d2h_stream); }
     if (ctx->rows_stream) { (void)hipStreamSynchronize(ctx->rows_stream); (void)hipStreamDestroy(ctx->rows_stream); }
     for (int b = 0; b < 3; ++b)
-        for (hipEvent_t e : {ctx->ev_ready[b], ctx->ev_done[b], ctx->ev_rows[b], ctx->ev_bands[b]})
+        for (hipEvent_t e : {ctx->ev_ready[b], ctx->ev_done[b], ctx->ev_rows[b]})
             if (e) (void)hipEventDestroy(e);
+    for (int b = 0; b < 4; ++b)
+        if (ctx->ev_bands[b]) (void)hipEventDestroy(ctx->ev_bands[b]);
     if (ctx->ev_pass) (void)hipEventDestroy(ctx->ev_pass);
     for (hipEvent_t e : {ctx->ev_front, ctx->ev_front_up, ctx->ev_front_cen})
         if (e) (void)hipEventDestroy(e);

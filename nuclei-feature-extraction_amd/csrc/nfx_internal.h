@@ -58,7 +58,7 @@ struct nfx_ctx {
     hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
     // nfx_extract_tile_streamed (nfx_stream.cpp): block copies + window gathers | rows back to the host, created on first use
     hipStream_t copy_stream = nullptr, rows_stream = nullptr, d2h_stream = nullptr, alt_stream = nullptr;
-    hipEvent_t ev_ready[3] = {}, ev_done[3] = {}, ev_rows[3] = {}, ev_bands[3] = {}, ev_pass = nullptr;
+    hipEvent_t ev_ready[3] = {}, ev_done[3] = {}, ev_rows[3] = {}, ev_bands[4] = {}, ev_pass = nullptr;
     hipEvent_t ev_front = nullptr, ev_front_up = nullptr, ev_front_cen = nullptr; // the centroid frontier: centroids home | rings up | centroids made
     void *pin = nullptr;      // grow-only pinned host staging (selection lists, rebased offsets of the chunks in flight)
     size_t pin_cap = 0;

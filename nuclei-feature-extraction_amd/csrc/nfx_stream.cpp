@@ -148,8 +148,10 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         NFX_HIP(ctx, hipStreamCreateWithPriority(&ctx->d2h_stream, hipStreamNonBlocking, hi));
     }
     for (int b = 0; b < 3; ++b)
-        for (hipEvent_t *e : {&ctx->ev_ready[b], &ctx->ev_done[b], &ctx->ev_rows[b], &ctx->ev_bands[b]})
+        for (hipEvent_t *e : {&ctx->ev_ready[b], &ctx->ev_done[b], &ctx->ev_rows[b]})
             if (!*e) NFX_HIP(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (int b = 0; b < 4; ++b)
+        if (!ctx->ev_bands[b]) NFX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_bands[b], hipEventDisableTiming));
     if (!ctx->ev_pass) NFX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pass, hipEventDisableTiming));
     if (!ctx->alt_stream) NFX_HIP(ctx, hipStreamCreateWithFlags(&ctx->alt_stream, hipStreamNonBlocking));
     hipStream_t const compute = ctx->stream, copy = ctx->copy_stream, rows_s = ctx->rows_stream, d2h = ctx->d2h_stream;
@@ -163,6 +165,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     // device buffer per chunk and a copy behind it -- which the runtime carries with a copy KERNEL of one workgroup per CU while the
     // bands hold the DMA engine (profiles/r03_stream_d2h.txt).  Same kernels, same rows.  NFX_STREAM_ROWS=copy keeps the staged form.
     float *rows_direct = nullptr;
+    const bool exp_rows_dev = [] { const char *e = getenv("NFX_EXP_STREAM_ROWS_DEVICE"); return e && atoi(e) == 1; }(); // MEASUREMENT ONLY: rows stay on the device
     {
         const char *rm = getenv("NFX_STREAM_ROWS");
         const bool want = !(rm && !strcmp(rm, "copy"));
@@ -204,7 +207,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     const size_t scratch = extract_ws_bytes(sets, n_sets, chunk_cap, (int64_t)max_chunk_nv, ps, batch_size, false, false);
     size_t need = al(4 * ((size_t)n + 1)) + al(8 * (size_t)nv + 8) + al(8 * (size_t)n + 8) + (size_t)n_slots * slot_bytes +
                   NB * al((size_t)chunk_cap * P3) + (rows_direct ? 0 : NB * al(4 * (size_t)chunk_cap * F + 8)) + NB * al(4 * (size_t)chunk_cap + 8) +
-                  NB * al(4 * ((size_t)chunk_cap + 1)) + 2 * al(scratch) + 8192;
+                  NB * al(4 * ((size_t)chunk_cap + 1)) + 2 * al(scratch) + 8192 + (exp_rows_dev ? al(4 * (size_t)n * F + 8) : 0);
     if ((st = ws_reserve(ctx, need, NFX_MEM_HOST)) != NFX_OK) return st;
     uint32_t *d_off_all = (uint32_t *)ws_alloc(ctx, 4 * ((size_t)n + 1));
     float *d_xy = (float *)ws_alloc(ctx, 8 * (size_t)nv + 8);
@@ -216,6 +219,11 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         d_rows[b] = rows_direct ? rows_direct : (float *)ws_alloc(ctx, 4 * (size_t)chunk_cap * F + 8);
         d_sel[b] = (uint32_t *)ws_alloc(ctx, 4 * (size_t)chunk_cap + 8);
         d_off[b] = (uint32_t *)ws_alloc(ctx, 4 * ((size_t)chunk_cap + 1));
+    }
+    if (exp_rows_dev) { // (a whole [n, F] device matrix takes the host matrix's place: what the kernels' writes over the link cost)
+        rows_direct = (float *)ws_alloc(ctx, 4 * (size_t)n * F + 8);
+        if (!rows_direct) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
+        for (int b = 0; b < NB; ++b) d_rows[b] = rows_direct;
     }
     if (!d_off_all || !d_xy || !d_cen || !d_slots || !d_patches[NB - 1] || !d_rows[NB - 1] || !d_sel[NB - 1] || !d_off[NB - 1])
         return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
@@ -274,12 +282,27 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     // their full size -- fewer launches, fewer tails.  NFX_STREAM_RAMP overrides (0: none).
     int64_t ramp = 2;
     if (const char *e = getenv("NFX_STREAM_RAMP")) ramp = atoll(e);
+    // GROWING CHUNKS (experiment, NFX_STREAM_GROW=g > 1 with NFX_STREAM_FIRST=nuclei): chunk k holds at most FIRST * g^k nuclei, up to
+    // chunk_cap -- few, large extractions (every launch of a chunk has a fixed cost: ramp-up, a tail of one or two nuclei-times per GLCM
+    // class) without a long wait for the first one; the link outruns the extraction by about 1.3, which bounds a useful g
+    double grow = 1.0;
+    int64_t first = 50000;
+    if (const char *e = getenv("NFX_STREAM_GROW")) grow = atof(e);
+    if (const char *e = getenv("NFX_STREAM_FIRST")) first = atoll(e);
+    auto cap_of = [&](int64_t k) -> int64_t {
+        if (!(grow > 1.0)) return chunk_cap;
+        double c = (double)first;
+        for (int64_t j = 0; j < k && c < (double)chunk_cap; ++j) c *= grow;
+        const int64_t r = ((int64_t)c / batch_size) * batch_size;
+        return std::min<int64_t>(chunk_cap, std::max<int64_t>(batch_size, r));
+    };
     const int64_t ramp_min = std::min<int64_t>(chunk_cap, std::max<int64_t>(batch_size, (chunk_cap / 8 / batch_size) * batch_size)); // (never slivers)
     auto plan = [&](Chunk &c) {                        // a single batch that needs more bands than the cache holds is a chunk of its own
         c.i0 = plan_next; c.blocks.clear(); c.sel.clear(); c.sel_off.clear();
         const int64_t ck = plan_index++;
         int64_t i = c.i0, distinct = 0, fresh = 0;    // bands of the chunk | those among them that still have to travel
-        while (i < n && i - c.i0 < chunk_cap) {
+        const int64_t cap = cap_of(ck);
+        while (i < n && i - c.i0 < cap) {
             const int64_t e = std::min<int64_t>(n, i + batch_size);
             int64_t add = 0, add_fresh = 0;
             for (int64_t j = i; j < e; ++j) {
@@ -313,19 +336,29 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
             for (size_t q = 0; q < c.blocks.size(); ++q) at[c.blocks[q]] = 0;
         }
     };
-    Chunk plans[2]; // chunk k lives in plans[k & 1] from its planning to the enqueue of its copies
+    Chunk plans[4]; // chunk k lives in plans[k & 3] from its planning to the enqueue of its extraction (up to `lead` + 1 chunks are alive)
 
     // ---- pinned staging: selection lists and rebased offsets of two chunks -------------------------------------------------------
     const bool img_pinned = is_pinned(image_u8); // (a pageable image is copied by the runtime through its own staging: correct, not overlapped)
-    const size_t stage_bytes = NB * (4 * (size_t)chunk_cap + 4 * ((size_t)chunk_cap + 1) + 128) + 512;
+    // (every chunk's lists have a place of their own: the host enqueues far ahead of the device and must never overwrite a list the device has
+    // not read yet.  sel: one entry per nucleus; off: one per nucleus + one per chunk, and there are no more chunks than batches)
+    const size_t max_chunks = (size_t)((n + batch_size - 1) / batch_size) + 1;
+    const size_t stage_bytes = 4 * (size_t)n + 64 + 4 * ((size_t)n + max_chunks) + 64;
     uint8_t *pin = (uint8_t *)Pinned::get(ctx, 1, stage_bytes);
     if (!pin) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "pinned staging");
-    uint32_t *h_sel[NB], *h_off[NB];
-    {
-        uint8_t *q = pin;
-        for (int b = 0; b < NB; ++b) { h_sel[b] = (uint32_t *)q; q += 4 * (size_t)chunk_cap + 32; h_off[b] = (uint32_t *)q; q += 4 * ((size_t)chunk_cap + 1) + 32; }
-    }
+    uint32_t *const h_sel_all = (uint32_t *)pin, *const h_off_all = (uint32_t *)(pin + ((4 * (size_t)n + 63) & ~(size_t)63));
+    auto stage_lists = [&](int64_t k, const Chunk &c, uint32_t *&hs, uint32_t *&ho) { // fills and returns chunk k's staged lists
+        const int64_t m = c.i1 - c.i0;
+        hs = h_sel_all + c.i0;
+        ho = h_off_all + c.i0 + k;
+        memcpy(hs, c.sel.data(), 4 * (size_t)m);
+        const uint32_t v0 = ring_offsets[c.i0];
+        for (int64_t j = 0; j <= m; ++j) ho[j] = ring_offsets[c.i0 + j] - v0;
+    };
 
+    // MEASUREMENT ONLY (wrong rows unless the call before left the same bands in the same arena): NFX_EXP_STREAM_NOCOPY=1 enqueues no band copy --
+    // what the chunked extraction takes with the link silent (profiles/r05_stream_experiments.txt)
+    const bool exp_nocopy = [] { const char *e = getenv("NFX_EXP_STREAM_NOCOPY"); return e && atoi(e) == 1; }();
     // ---- block cache ---------------------------------------------------------------------------------------------------------
     std::vector<int64_t> slot_block((size_t)n_slots, -1), slot_use((size_t)n_slots, -1);
     int64_t img_h2d = 0, blocks_copied = 0, rows_d2h = 0, use_tick = 0, gather_passes = 0;
@@ -347,15 +380,14 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     // H2D of chunk k's missing bands on the copy stream -- nothing but copies there, so the link never waits for a kernel -- and the
     // gathers of its windows behind them on the rows stream (which also carries the rows home)
     auto enqueue_copy = [&](int64_t k) -> nfx_status {
-        const Chunk &c = plans[k & 1];
+        const Chunk &c = plans[k & 3];
         const int b = (int)(k % NB);
         const int64_t m = c.i1 - c.i0;
         if (k >= NB) NFX_HIP_S(hipEventSynchronize(ctx->ev_done[b])); // extract(k-3) has finished: patches[b], sel[b], off[b] and their staging are free
-        memcpy(h_sel[b], c.sel.data(), 4 * (size_t)m);
-        const uint32_t v0 = ring_offsets[c.i0];
-        for (int64_t j = 0; j <= m; ++j) h_off[b][j] = ring_offsets[c.i0 + j] - v0;
-        NFX_HIP_S(hipMemcpyAsync(d_sel[b], h_sel[b], 4 * (size_t)m, hipMemcpyHostToDevice, copy));
-        NFX_HIP_S(hipMemcpyAsync(d_off[b], h_off[b], 4 * ((size_t)m + 1), hipMemcpyHostToDevice, copy));
+        uint32_t *hs, *ho;
+        stage_lists(k, c, hs, ho);
+        NFX_HIP_S(hipMemcpyAsync(d_sel[b], hs, 4 * (size_t)m, hipMemcpyHostToDevice, copy));
+        NFX_HIP_S(hipMemcpyAsync(d_off[b], ho, 4 * ((size_t)m + 1), hipMemcpyHostToDevice, copy));
         other_h2d += 8 * m + 4;
         // The chunk's bands in PASSES of at most n_slots (one pass unless a single batch is wider than the cache): the bands of a pass
         // that are not resident take the slots that have gone unused longest, their copies go out back to back, the windows that start
@@ -387,7 +419,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
                     }
                     slot_block[s] = bid; block_slot[bid] = s; slot_use[s] = use_tick;
                     uint8_t *dst = d_slots + (size_t)s * slot_bytes;
-                    for (int ch = 0; ch < 3; ++ch) // rows [wy0, wy0 + wh) of a channel are contiguous in the planar image
+                    for (int ch = 0; ch < 3 && !exp_nocopy; ++ch) // rows [wy0, wy0 + wh) of a channel are contiguous in the planar image
                         NFX_HIP_S(hipMemcpyAsync(dst + (size_t)ch * wh * ww, image_u8 + ((size_t)ch * H + wy0) * W, (size_t)wh * ww, hipMemcpyHostToDevice, copy));
                     img_h2d += 3 * wh * ww;
                     ++blocks_copied;
@@ -412,25 +444,80 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         return NFX_OK;
     };
 
+    // BANDS AHEAD (round 5).  When every band keeps a cache slot of its own (the whole slide fits: the default on 288 GB) nothing is ever evicted,
+    // so a chunk's bands depend on nothing but the plan -- they are sent `lead` chunks ahead of the extraction, back to back, and the link
+    // never waits for the compute side (before: chunk k+1's bands left only once extract(k-2) had finished, because the same host step
+    // also reused that chunk's patch buffer; the link then ran one chunk ahead at best and the next extraction often started behind its
+    // bands).  The gathers still wait for their patch buffer, but on the DEVICE (an event of extract(k-3)), not on the host, and the
+    // chunk's lists travel on the rows stream right in front of them.  A smaller cache keeps the fused form below (lead 1, enqueue_copy).
+    const bool all_resident = n_slots >= nblocks;
+    int64_t lead = all_resident ? 2 : 1;
+    if (const char *e = getenv("NFX_STREAM_LEAD")) lead = std::max<int64_t>(1, std::min<int64_t>(3, atoll(e)));
+    if (!all_resident) lead = 1;
+    const bool split = lead > 1;
+    auto send_bands = [&](int64_t k) -> nfx_status { // chunk k's bands that are not on the device yet: slot = band (nothing is evicted)
+        const Chunk &c = plans[k & 3];
+        for (size_t q = 0; q < c.blocks.size(); ++q) {
+            const int64_t bid = c.blocks[q];
+            if (block_slot[bid] >= 0) continue;
+            const int64_t wy0 = bid * B, wh = std::min<int64_t>(H - wy0, B + ps), ww = W;
+            block_slot[bid] = bid; slot_block[bid] = bid;
+            uint8_t *dst = d_slots + (size_t)bid * slot_bytes;
+            for (int ch = 0; ch < 3 && !exp_nocopy; ++ch)
+                NFX_HIP_S(hipMemcpyAsync(dst + (size_t)ch * wh * ww, image_u8 + ((size_t)ch * H + wy0) * W, (size_t)wh * ww, hipMemcpyHostToDevice, copy));
+            img_h2d += 3 * wh * ww;
+            ++blocks_copied;
+        }
+        NFX_HIP_S(hipEventRecord(ctx->ev_bands[k & 3], copy));
+        return NFX_OK;
+    };
+    auto gather_chunk = [&](int64_t k) -> nfx_status { // (split form) lists up, windows gathered: all on the rows stream, behind the chunk's bands and its buffer's last reader
+        const Chunk &c = plans[k & 3];
+        const int b = (int)(k % NB);
+        const int64_t m = c.i1 - c.i0;
+        uint32_t *hs, *ho;
+        stage_lists(k, c, hs, ho);
+        NFX_HIP_S(hipStreamWaitEvent(rows_s, ctx->ev_bands[k & 3], 0));
+        if (k >= NB) NFX_HIP_S(hipStreamWaitEvent(rows_s, ctx->ev_done[b], 0)); // extract(k-3) read patches[b], sel[b], off[b]
+        NFX_HIP_S(hipMemcpyAsync(d_sel[b], hs, 4 * (size_t)m, hipMemcpyHostToDevice, rows_s));
+        NFX_HIP_S(hipMemcpyAsync(d_off[b], ho, 4 * ((size_t)m + 1), hipMemcpyHostToDevice, rows_s));
+        other_h2d += 8 * m + 4;
+        for (size_t q = 0; q < c.blocks.size(); ++q) {
+            const int64_t bid = c.blocks[q];
+            const int64_t wy0 = bid * B, wh = std::min<int64_t>(H - wy0, B + ps);
+            ctx->stream = rows_s;
+            const hipError_t ge = launch_gather_patches_window(ctx, c.sel_off[q + 1] - c.sel_off[q], d_sel[b] + c.sel_off[q], d_cen + 2 * c.i0,
+                                                               d_slots + (size_t)block_slot[bid] * slot_bytes, H, W, wy0, 0, wh, W, ps, d_patches[b]);
+            ctx->stream = compute;
+            NFX_HIP_S(ge);
+        }
+        NFX_HIP_S(hipEventRecord(ctx->ev_ready[b], rows_s));
+        return NFX_OK;
+    };
+
     // Order of the host's work per chunk k: enqueue extract(k) -- its windows were gathered while chunk k-1 ran --, THEN plan chunk
     // k+1 and send its bands on their way (the host first waits for extract(k-2), whose buffers chunk k+1 takes over: two
     // extractions are queued on the device at that moment, so it never runs dry while the host sleeps), and the rows of chunk k home.
-    // The centroid frontier runs two chunks ahead of the plan: plan(j) reads the centroids of [plan_next, plan_next + chunk_cap); right
-    // after it the frontier is pushed to plan_next + 2 chunk_cap -- enqueued AHEAD of chunk j's bands on the copy stream (25 MB of rings
+    // The centroid frontier runs two chunks ahead of the plan: plan(j) reads the centroids of [plan_next, plan_next + cap(j)); right
+    // after it the frontier is pushed to plan_next + cap(j+1) + cap(j+2) -- enqueued AHEAD of chunk j's bands on the copy stream (25 MB of rings
     // before 300-600 MB of bands), so that by the time the host comes to plan(j + 1) it waits for nothing that lies behind those bands.
-    int64_t nchunks = 0;
-    bool have = plan_next < n, have_next = false;
-    if (have) {
-        NFX_HIP_S(advance_front(chunk_cap));
-        NFX_HIP_S(hipEventSynchronize(ctx->ev_front));
-        plan(plans[0]);
-        NFX_HIP_S(advance_front(plan_next + 2 * chunk_cap));
-        if ((st = enqueue_copy(0)) != NFX_OK) return st;
-    }
-    for (int64_t k = 0; have; ++k, have = have_next) {
+    int64_t nchunks = 0, planned = 0;  // chunks whose plan exists (and, in the split form, whose bands are on their way)
+    auto plan_next_chunk = [&]() -> nfx_status {
+        if (planned == 0) NFX_HIP_S(advance_front(cap_of(0)));
+        NFX_HIP_S(hipEventSynchronize(ctx->ev_front)); // centroids of [0, plan_next + this chunk's cap) and beyond are home
+        plan(plans[planned & 3]);
+        NFX_HIP_S(advance_front(plan_next + cap_of(planned + 1) + cap_of(planned + 2)));
+        if (split) { const nfx_status s2 = send_bands(planned); if (s2 != NFX_OK) return s2; }
+        ++planned;
+        return NFX_OK;
+    };
+    while (planned < lead && plan_next < n)
+        if ((st = plan_next_chunk()) != NFX_OK) return st;
+    if (planned > 0 && (st = split ? gather_chunk(0) : enqueue_copy(0)) != NFX_OK) return st;
+    for (int64_t k = 0; k < planned; ++k) {
         const int b = (int)(k % NB);
         hipStream_t const cstream = cs[k & 1];
-        const int64_t i0 = plans[k & 1].i0, i1 = plans[k & 1].i1, m = i1 - i0;
+        const int64_t i0 = plans[k & 3].i0, i1 = plans[k & 3].i1, m = i1 - i0;
         ++nchunks;
         NFX_HIP_S(hipStreamWaitEvent(cstream, ctx->ev_ready[b], 0));
         if (k >= NB && !rows_direct) NFX_HIP_S(hipStreamWaitEvent(cstream, ctx->ev_rows[b], 0)); // rows[b] of chunk k-3 have left for the host
@@ -448,13 +535,8 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
             NFX_HIP_S(hipEventRecord(ctx->ev_rows[b], d2h));
         }
         rows_d2h += 4 * m * F;
-        have_next = plan_next < n;
-        if (have_next) {
-            NFX_HIP_S(hipEventSynchronize(ctx->ev_front)); // centroids of [0, plan_next + chunk_cap) and beyond are home
-            plan(plans[(k + 1) & 1]);
-            NFX_HIP_S(advance_front(plan_next + 2 * chunk_cap));
-            if ((st = enqueue_copy(k + 1)) != NFX_OK) return st;
-        }
+        if (plan_next < n && (st = plan_next_chunk()) != NFX_OK) return st;                                    // chunk k + lead: plan, bands on their way
+        if (k + 1 < planned && (st = split ? gather_chunk(k + 1) : enqueue_copy(k + 1)) != NFX_OK) return st;  // chunk k + 1: windows into its patch buffer
     }
     NFX_HIP_S(advance_front(n)); // (nuclei behind the last chunk's end: none -- every nucleus belongs to a chunk; kept for the invariant front == n)
 #undef NFX_HIP_S

@@ -172,10 +172,23 @@ class GeoJsonReader {
         std::vector<std::vector<FullFeature>> part_full((size_t)T);
         std::vector<char> ok((size_t)T, 0);
         bool give_up = false; // set by thread 0 between two barriers, read by all behind the second one
+        // a pass that throws in one thread (bad_alloc while collecting element starts) must not leave the others waiting at a barrier, nor
+        // end the process in std::terminate: the thread notes its failure and still ARRIVES at every barrier; thread 0 turns any failure
+        // into give_up at the next serial step, and the document is parsed again by the serial reader
+        std::vector<char> failed((size_t)T, 0);
+        auto any_failed = [&] { for (char f : failed) if (f) return true; return false; };
         Barrier bar(T);
+        // the workers start behind a gate: if a thread cannot be created (a pid / memory limit of the cgroup) the ones that exist are
+        // told to leave before any of them waits at a barrier sized for T
+        std::mutex gate_m; std::condition_variable gate_cv; int gate = 0; // 0 wait, 1 go, -1 leave
         auto worker = [&](int k) {
+            if (k != 0) {
+                std::unique_lock<std::mutex> l(gate_m);
+                gate_cv.wait(l, [&] { return gate != 0; });
+                if (gate < 0) return;
+            }
             // pass 1: string quotes per chunk -> string state at every chunk start
-            quotes[(size_t)k] = count_string_quotes(cut[(size_t)k], cut[(size_t)k + 1]);
+            try { quotes[(size_t)k] = count_string_quotes(cut[(size_t)k], cut[(size_t)k + 1]); } catch (...) { failed[(size_t)k] = 1; }
             bar.wait();
             if (k == 0) {
                 size_t q = 0;
@@ -183,9 +196,10 @@ class GeoJsonReader {
             }
             bar.wait();
             // pass 2: bracket depth per chunk -> depth at every chunk start
-            end_state[(size_t)k] = scan_chunk(cut[(size_t)k], cut[(size_t)k + 1], begin_state[(size_t)k], nullptr, nullptr);
+            try { end_state[(size_t)k] = scan_chunk(cut[(size_t)k], cut[(size_t)k + 1], begin_state[(size_t)k], nullptr, nullptr); } catch (...) { failed[(size_t)k] = 1; }
             bar.wait();
             if (k == 0) {
+                if (any_failed()) give_up = true;
                 long long d = 0;
                 for (int j = 0; j < T; ++j) {
                     if (j > 0 && end_state[(size_t)j - 1].in_string != begin_state[(size_t)j].in_string) give_up = true; // (the two passes disagree: not a valid document)
@@ -196,14 +210,16 @@ class GeoJsonReader {
             bar.wait();
             if (give_up) return;
             // pass 3: the elements of the array, chunk by chunk, up to its closing bracket
-            (void)scan_chunk(cut[(size_t)k], cut[(size_t)k + 1], begin_state[(size_t)k], &starts[(size_t)k], &closes[(size_t)k]);
+            try { (void)scan_chunk(cut[(size_t)k], cut[(size_t)k + 1], begin_state[(size_t)k], &starts[(size_t)k], &closes[(size_t)k]); } catch (...) { failed[(size_t)k] = 1; }
             bar.wait();
             if (k == 0) {
-                for (int j = 0; j < T && !array_end; ++j) {
-                    elem.insert(elem.end(), starts[(size_t)j].begin(), starts[(size_t)j].end());
-                    array_end = closes[(size_t)j]; // (a chunk behind the array's end is never consulted)
-                }
-                if (!array_end || elem.empty()) give_up = true; // unbalanced or empty: the serial reader says what is wrong (or returns nothing)
+                try {
+                    for (int j = 0; j < T && !array_end && !any_failed(); ++j) {
+                        elem.insert(elem.end(), starts[(size_t)j].begin(), starts[(size_t)j].end());
+                        array_end = closes[(size_t)j]; // (a chunk behind the array's end is never consulted)
+                    }
+                } catch (...) { failed[0] = 1; }
+                if (any_failed() || !array_end || elem.empty()) give_up = true; // unbalanced, empty or out of memory: the serial reader says what is wrong (or returns nothing)
             }
             bar.wait();
             if (give_up) return;
@@ -223,15 +239,21 @@ class GeoJsonReader {
                 if (b > a && sub.p_ != stop) return;
                 part_full[(size_t)k] = std::move(sub.full);
                 ok[(size_t)k] = 1;
-            } catch (const std::exception &) {
+            } catch (...) { // (a parse error or bad_alloc: ok[k] stays 0 and the document goes to the serial reader)
             }
         };
         {
             std::vector<std::thread> th;
-            th.reserve((size_t)T);
-            for (int k = 1; k < T; ++k) th.emplace_back(worker, k);
-            worker(0);
+            bool started = true;
+            try {
+                th.reserve((size_t)T);
+                for (int k = 1; k < T; ++k) th.emplace_back(worker, k);
+            } catch (...) { started = false; } // std::system_error: no more threads to be had
+            { std::lock_guard<std::mutex> l(gate_m); gate = started ? 1 : -1; }
+            gate_cv.notify_all();
+            if (started) worker(0);
             for (std::thread &t : th) t.join();
+            if (!started) return false;
         }
         if (give_up) return false;
         for (int k = 0; k < T; ++k)
@@ -250,6 +272,8 @@ class GeoJsonReader {
             out.ring_xy.insert(out.ring_xy.end(), pp.ring_xy.begin(), pp.ring_xy.end());
             for (size_t i = 1; i < pp.ring_offsets.size(); ++i) out.ring_offsets.push_back(base + pp.ring_offsets[i]);
             if (keep_all_) for (FullFeature &f : part_full[(size_t)k]) full.push_back(std::move(f));
+            part[(size_t)k] = Polygons(); // appended: give the run's buffers back now (the peak stays near one copy of the rings, not two)
+            part_full[(size_t)k] = std::vector<FullFeature>();
         }
         p_ = array_end + 1;
         threads_used = T;

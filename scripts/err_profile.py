@@ -29,7 +29,8 @@ for seed, ps in ((7, 17), (8, 24), (1, 32), (2, 48), (4, 64)):
     med = np.array([np.median(np.abs(w[ok[:, c], c])) if ok[:, c].any() else 0.0 for c in range(w.shape[1])])
     with np.errstate(divide="ignore", invalid="ignore"):
         rel_to_med = err.max(0) / med
-        pure_rel = np.where(ok & (w != 0), err / np.abs(w), 0.0).max(0)
+        pure_rel_all = np.where(ok & (w != 0), err / np.abs(w), 0.0)
+        pure_rel = pure_rel_all.max(0)
     col = 0
     try:
         scaled = f"{par.assert_rows_close(got, want, par.column_scales(nfx, sets, ps)):.3e}"
@@ -44,6 +45,14 @@ for seed, ps in ((7, 17), (8, 24), (1, 32), (2, 48), (4, 64)):
         for j in order:
             c = col + j
             print(f"     {names[c]:55s} max|err| {err[:, c].max():.3e}  median|v| {med[c]:.3e}  err/median {rel_to_med[c]:.3e}  pure rel {pure_rel[c]:.3e}")
+        # the same by PURE relative error (no floor): the column, the nucleus, both values -- a sign flip or a 0-vs-tiny on a tiny mask shows here
+        for j in np.argsort(-pure_rel[sl])[:3]:
+            c = col + j
+            if pure_rel[c] == 0.0:
+                continue
+            i = int(np.argmax(pure_rel_all[:, c]))
+            print(f"     by pure relative: {names[c]:45s} nucleus {i:5d}  hip {got[i, c]: .9e}  oracle {want[i, c]: .9e}  |err| {err[i, c]:.3e}  pure rel {pure_rel[c]:.3e}  "
+                  f"column median {med[c]:.3e}  mask area {int(round(float(want[i, 0])))}")
         if s == 4:
             for tag, sel in (("mean", slice(col, col + k, 2)), ("variance", slice(col + 1, col + k, 2))):
                 e = err[:, sel].max(0)

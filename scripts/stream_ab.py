@@ -95,6 +95,8 @@ def run(with_torch, rows_mode, chunk, block, reps=3):
         t0 = time.perf_counter()
         _, _, st = ctx.extract_tile_streamed(sets, off, xy, h_tile, ps, chunk_nuclei=chunk, block=block, out=rows)
         times.append(1e3 * (time.perf_counter() - t0))
+        if os.environ.get("AB_NOCOPY_AFTER_FIRST") == "1":   # measurement only: later calls find the bands where the first call left them
+            os.environ["NFX_EXP_STREAM_NOCOPY"] = "1"
         time.sleep(0.2)
     same = bool(np.array_equal(rows.view(np.uint32), np.asarray(ref).view(np.uint32)))
     print(f"run torch={with_torch} rows={rows_mode} chunk={chunk or 100000} block={block or 2048}: streamed calls {', '.join(f'{t:.1f}' for t in times)} ms "

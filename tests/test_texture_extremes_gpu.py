@@ -104,3 +104,32 @@ def test_extreme_textures_through_the_trait_entry(nfx, ctx, ps):
         want = orc.compute_features_batched(set_id, off, ctr, patchs, masks[:, 0])
         got = ctx.compute_features_batched(set_id, off, ctr, patchs, masks)
         par.assert_rows_close(got, want, par.column_scales(nfx, [set_id], ps), what=f"trait {nfx.feature_set_cli_name(set_id)} ps={ps}", labels=names)
+
+
+@pytest.mark.parametrize("seed_idx,ps,i,column,dy,dx", [(7, 17, 1628, "correlation_1_1_32", 1, 1), (8, 24, 2391, "correlation_1_-1_32", 1, -1)])
+def test_an_exactly_uncorrelated_glcm_gives_zero_up_to_f64_noise(nfx, synth, ctx, seed_idx, ps, i, column, dy, dx):
+    """The column behind "worst pure relative 2.0 at ps 17 / 1.0 at ps 24" of the GLCM error profiles (named by scripts/err_profile.py,
+    profiles/r05_err_profile.txt): `correlation` at 32 levels of a small nucleus whose numerator sum(ij P) - mu^2 is ZERO in exact
+    arithmetic (checked here on the integer matrix: T sum(ij G) == (sum(i G))^2).  The oracle evaluates the cancellation to +7.8e-15
+    (resp. -4.4e-15), the kernel to -7.8e-15 (resp. 0): one ulp of mu^2 over the variance either way -- a true 0-vs-epsilon fourteen
+    orders below the column's values (median 0.2), not a sign error.  Every other GLCM column of the nucleus is within 1e-5."""
+    seed = synth.SEED_BASE + seed_idx
+    off, xy = synth.polygons(seed, i, 1, ps)
+    pu8 = synth.patches(seed, i, 1, ps)
+    want, _ = orc.extract([2], off, xy, pu8, ps, batch_size=1)
+    got, _ = ctx.extract([2], off, xy, pu8, ps, batch_size=1)
+    cols = nfx.all_column_names([2])[1:]
+    c = cols.index(column)
+    mask = orc.raster_polygon(orc.preprocess_polygon(xy)[1], ps)
+    G = orc.glcm_counts(pu8[0].astype(np.float32) / np.float32(255.0), mask, 32, dy, dx).astype(object)    # exact integers
+    T = int(G.sum())
+    lv = np.arange(32, dtype=object)
+    s_ij = int((G * np.outer(lv, lv)).sum())
+    s_i = int((G.sum(1) * lv).sum())
+    assert T > 0 and T * s_ij == s_i * s_i, "the numerator of this nucleus's correlation is exactly zero"
+    mu = s_i / T
+    var = float(((lv.astype(np.float64) - mu) ** 2 * G.sum(1).astype(np.float64)).sum() / T)
+    noise = 4 * np.finfo(np.float64).eps * mu * mu / var                # a few ulps of mu^2, scaled as the division scales them
+    assert abs(float(want[0, c])) <= noise and abs(float(got[0, c])) <= noise, (want[0, c], got[0, c], noise)
+    other = [j for j in range(len(cols)) if j != c]
+    par.assert_rows_close(got[:, other], want[:, other], np.asarray(par.column_scales(nfx, [2], ps))[other], what=f"glcm of nucleus {i} at ps {ps}")

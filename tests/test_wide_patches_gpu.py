@@ -133,6 +133,23 @@ def test_huge_sets_match_the_oracle(nfx, ctx, ps, n, sets):
     assert np.array_equal(gs, ws) and np.array_equal(gb, wb)
 
 
+def test_gabor_on_more_than_64_tiles(nfx, ctx):
+    """above 280 pixels a bounding box holds more than 64 candidate Gabor tiles, so k_gabor_plan's tile list is written by
+    several waves (cross-wave prefix over the ballots) and the scratch holds up to 225 tiles per nucleus -- never checked below ps 300.
+    Two nuclei at 300 x 300 (81 candidate tiles), one ring covering the whole patch, one typical: the 96 Gabor columns against the
+    oracle's dense 30 x 30 bank (a few seconds on 16 threads for two nuclei)."""
+    ps = 300
+    off, xy, pu8 = par.make_inputs(63, 1, ps)
+    c = 5000.0
+    full = np.array([[c - 2 * ps, c - 2 * ps], [c + 2 * ps, c - 2 * ps], [c + 2 * ps, c + 2 * ps], [c - 2 * ps, c + 2 * ps], [c - 2 * ps, c - 2 * ps]], np.float32)
+    off, xy = par.concat_rings((np.array([0, 5], np.uint32), full), (off, xy))
+    pu8 = np.concatenate([pu8, pu8])
+    want, _ = orc.extract([4], off, xy, pu8, ps, batch_size=2, threads=16)
+    got, _ = ctx.extract([4], off, xy, pu8, ps, batch_size=2)
+    assert np.isfinite(want).all() and np.abs(want).max() > 1.0
+    par.assert_rows_close(got, want, par.column_scales(nfx, [4], ps), what="gabor on 81 tiles")
+
+
 def test_huge_trait_and_tile_entries(nfx, synth, ctx):
     """ps = 160 through compute_features_batched (f32 patchs + masks) and through the tile entry."""
     ps, n = 160, 5
