@@ -452,7 +452,7 @@ size_t extract_ws_bytes(const int *sets, int n_sets, int64_t n, int64_t nv, int 
     if (any_pixel_set(sets, n_sets)) b += al(sizeof(uint64_t) * (size_t)n * ps * mask_words_per_row(ps));
     if (count_set(sets, n_sets, NFX_SET_GLCM)) b += al(sizeof(int) * (size_t)n); // mask areas
     if (count_set(sets, n_sets, NFX_SET_GEOMETRY)) b += al(polygon_scratch_bytes(n, nv));
-    if (gather) b += al((size_t)n * 3 * ps * ps);
+    if (gather) b += al((size_t)n * 3 * ps * ps) + al(sizeof(PatchRef) * (size_t)n); // packed slots (border nuclei only when windows are read in place) + the refs
     Job j; j.n = n; j.ps = ps; j.batch_size = batch_size;
     b += (size_t)count_set(sets, n_sets, NFX_SET_COLOR) * al(color_scratch_bytes(j)); // a repeated "color" gets scratch of its own
     if (count_set(sets, n_sets, NFX_SET_GLCM)) b += al(glcm_scratch_bytes(j));
@@ -472,7 +472,7 @@ nfx_status prepare_sets(nfx_ctx *ctx, const int *sets, int n_sets)
 // everything on the device; ws already reserved.  `forked` tells the caller that the side stream holds work to be joined.
 static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_off,
                                       const float *ring_xy, const uint8_t *patches_u8, const uint8_t *image, int64_t H, int64_t W,
-                                      int ps, int batch_size, float *out_rows, float *out_centroids, bool &forked, bool &gforked)
+                                      int ps, int batch_size, float *out_rows, float *out_centroids, const PatchRef *patch_refs, bool &forked, bool &gforked)
 {
     const int F = sets_total_columns(sets, n_sets);
     float *centred = (float *)ws_alloc(ctx, sizeof(float) * 2 * (size_t)nv);
@@ -500,9 +500,18 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
     }
     if (image && pix) {
         uint8_t *gp = (uint8_t *)ws_alloc(ctx, (size_t)n * 3 * ps * ps);
-        if (!gp) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
-        NFX_HIP(ctx, launch_gather_patches(ctx, n, centroids, image, H, W, ps, gp));
+        PatchRef *refs = (PatchRef *)ws_alloc(ctx, sizeof(PatchRef) * (size_t)n);
+        if (!gp || !refs) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
+        // WINDOWS IN PLACE (round 5, measured, OFF by default: NFX_TILE_WINDOWS=1 turns it on).  The image is resident, so the pixel kernels
+        // could read every window where it lies (PatchRef) and only the border nuclei's zero-padded patches would be copied.  Built, bit-identical
+        // (tests/test_tile_gpu.py) -- and slower: a window's rows start at any byte of an odd-pitch image, and the kernels' 16-byte loads at any
+        // alignment cost k_glrlm 9 ms and k_hue_batch 1.5 ms per 1.25 M nuclei where the one-off copy into aligned packed patches costs 7
+        // (profiles/r05_windows_in_place.txt: 187.9 against 181.6 ms).  Materialising the patches IS the cheaper form.
+        const char *wenv = getenv("NFX_TILE_WINDOWS");
+        const bool in_place = wenv && atoi(wenv) == 1 && windows_in_place_ok(ps, H, W);
+        NFX_HIP(ctx, launch_gather_patches_window(ctx, n, nullptr, centroids, image, H, W, 0, 0, H, W, ps, gp, in_place ? refs : nullptr));
         patches_u8 = gp;
+        if (in_place) patch_refs = refs;
     }
     // rasterise once; the mask-derived geometry columns are produced in the same kernel
     int geo_col = -1;
@@ -523,6 +532,7 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
     Job job;
     job.n = n; job.ps = ps; job.batch_size = batch_size; job.poly_off = ring_off; job.poly_xy = centred;
     job.patches = patches_u8; job.patches_f32 = false; job.mask_rows = rows; job.areas = areas; job.out = out_rows; job.F = F;
+    job.refs = (ps <= NFX_ROW_WORD_PS && (ps & 15) == 0) ? patch_refs : nullptr;
 
     int col = 0;
     bool geo_done = false;
@@ -583,12 +593,12 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
 
 nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_off,
                           const float *ring_xy, const uint8_t *patches_u8, const uint8_t *image, int64_t H, int64_t W,
-                                 int ps, int batch_size, float *out_rows, float *out_centroids)
+                                 int ps, int batch_size, float *out_rows, float *out_centroids, const PatchRef *patch_refs)
 {
     bool forked = false, gforked = false;
     hipStream_t const main_stream = ctx->stream;
     nfx_status st = extract_device_body(ctx, sets, n_sets, n, nv, ring_off, ring_xy, patches_u8, image, H, W, ps, batch_size,
-                                        out_rows, out_centroids, forked, gforked);
+                                        out_rows, out_centroids, patch_refs, forked, gforked);
     ctx->stream = main_stream;
     if (gforked) { // joined on every path, like the polygon kernel's stream below
         const hipError_t e1 = hipEventRecord(ctx->ev_gjoin, ctx->gabor_stream);

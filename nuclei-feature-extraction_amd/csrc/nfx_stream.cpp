@@ -207,14 +207,16 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     const size_t scratch = extract_ws_bytes(sets, n_sets, chunk_cap, (int64_t)max_chunk_nv, ps, batch_size, false, false);
     size_t need = al(4 * ((size_t)n + 1)) + al(8 * (size_t)nv + 8) + al(8 * (size_t)n + 8) + (size_t)n_slots * slot_bytes +
                   NB * al((size_t)chunk_cap * P3) + (rows_direct ? 0 : NB * al(4 * (size_t)chunk_cap * F + 8)) + NB * al(4 * (size_t)chunk_cap + 8) +
-                  NB * al(4 * ((size_t)chunk_cap + 1)) + 2 * al(scratch) + 8192 + (exp_rows_dev ? al(4 * (size_t)n * F + 8) : 0);
+                  NB * al(4 * ((size_t)chunk_cap + 1)) + 2 * al(scratch) + 8192 + (exp_rows_dev ? al(4 * (size_t)n * F + 8) : 0) +
+                  NB * al(sizeof(PatchRef) * (size_t)chunk_cap);
     if ((st = ws_reserve(ctx, need, NFX_MEM_HOST)) != NFX_OK) return st;
     uint32_t *d_off_all = (uint32_t *)ws_alloc(ctx, 4 * ((size_t)n + 1));
     float *d_xy = (float *)ws_alloc(ctx, 8 * (size_t)nv + 8);
     float *d_cen = (float *)ws_alloc(ctx, 8 * (size_t)n + 8);
     uint8_t *d_slots = (uint8_t *)ws_alloc(ctx, (size_t)n_slots * slot_bytes);
-    uint8_t *d_patches[NB]; float *d_rows[NB]; uint32_t *d_sel[NB], *d_off[NB];
+    uint8_t *d_patches[NB]; float *d_rows[NB]; uint32_t *d_sel[NB], *d_off[NB]; PatchRef *d_refs[NB];
     for (int b = 0; b < NB; ++b) {
+        d_refs[b] = (PatchRef *)ws_alloc(ctx, sizeof(PatchRef) * (size_t)chunk_cap);
         d_patches[b] = (uint8_t *)ws_alloc(ctx, (size_t)chunk_cap * P3);
         d_rows[b] = rows_direct ? rows_direct : (float *)ws_alloc(ctx, 4 * (size_t)chunk_cap * F + 8);
         d_sel[b] = (uint32_t *)ws_alloc(ctx, 4 * (size_t)chunk_cap + 8);
@@ -225,7 +227,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         if (!rows_direct) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
         for (int b = 0; b < NB; ++b) d_rows[b] = rows_direct;
     }
-    if (!d_off_all || !d_xy || !d_cen || !d_slots || !d_patches[NB - 1] || !d_rows[NB - 1] || !d_sel[NB - 1] || !d_off[NB - 1])
+    if (!d_off_all || !d_xy || !d_cen || !d_slots || !d_refs[NB - 1] || !d_patches[NB - 1] || !d_rows[NB - 1] || !d_sel[NB - 1] || !d_off[NB - 1])
         return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
     // a chunk's extraction bump-allocates its scratch from one of two marks: two extractions are in flight, on two streams
     const size_t ws_mark[2] = {ctx->ws->off, ctx->ws->off + al(scratch)};
@@ -455,6 +457,11 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     if (const char *e = getenv("NFX_STREAM_LEAD")) lead = std::max<int64_t>(1, std::min<int64_t>(3, atoll(e)));
     if (!all_resident) lead = 1;
     const bool split = lead > 1;
+    // WINDOWS IN PLACE (round 5, measured, OFF by default: NFX_STREAM_WINDOWS=1 turns it on): with every band resident for the rest of the call the
+    // pixel kernels can read each nucleus's window where it lies in its band (PatchRef; the "gather" then only writes the refs and copies the
+    // nuclei at the slide's border).  Bit-identical and slower -- 216.7 against 209.9 ms per shard: the kernels' loads at any alignment cost more
+    // than the one copy into aligned packed patches saves (nfx_api.cpp: extract_device_body, profiles/r05_windows_in_place.txt).
+    const bool in_place = split && windows_in_place_ok(ps, sh, W) && ([] { const char *e = getenv("NFX_STREAM_WINDOWS"); return e && atoi(e) == 1; }());
     auto send_bands = [&](int64_t k) -> nfx_status { // chunk k's bands that are not on the device yet: slot = band (nothing is evicted)
         const Chunk &c = plans[k & 3];
         for (size_t q = 0; q < c.blocks.size(); ++q) {
@@ -487,7 +494,8 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
             const int64_t wy0 = bid * B, wh = std::min<int64_t>(H - wy0, B + ps);
             ctx->stream = rows_s;
             const hipError_t ge = launch_gather_patches_window(ctx, c.sel_off[q + 1] - c.sel_off[q], d_sel[b] + c.sel_off[q], d_cen + 2 * c.i0,
-                                                               d_slots + (size_t)block_slot[bid] * slot_bytes, H, W, wy0, 0, wh, W, ps, d_patches[b]);
+                                                               d_slots + (size_t)block_slot[bid] * slot_bytes, H, W, wy0, 0, wh, W, ps, d_patches[b],
+                                                               in_place ? d_refs[b] : nullptr);
             ctx->stream = compute;
             NFX_HIP_S(ge);
         }
@@ -525,7 +533,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         ctx->stream = cstream;
         const uint32_t v0 = ring_offsets[i0], v1 = ring_offsets[i1];
         st = extract_device(ctx, sets, n_sets, m, (int64_t)(v1 - v0), d_off[b], d_xy + 2 * (size_t)v0, d_patches[b], nullptr, 0, 0, ps, batch_size,
-                            rows_direct ? rows_direct + (size_t)i0 * F : d_rows[b], nullptr);
+                            rows_direct ? rows_direct + (size_t)i0 * F : d_rows[b], nullptr, in_place ? d_refs[b] : nullptr);
         ctx->stream = compute;
         if (st != NFX_OK) return fail_sync(st);
         NFX_HIP_S(hipEventRecord(ctx->ev_done[b], cstream));

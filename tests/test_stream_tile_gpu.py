@@ -113,3 +113,30 @@ def test_geometry_alone_and_empty_calls_need_no_image(nfx, synth):
                                       rows.ctypes.data_as(C.c_void_p), None, None)
     assert st_ == 1 and b"image" in L.nfx_last_error(ctx._h)
     ctx.close()
+
+
+@pytest.mark.parametrize("ps,W", [(48, 701), (64, 700), (32, 703)])
+def test_streamed_windows_read_in_place_give_the_same_bits(nfx, synth, ps, W):
+    """NFX_STREAM_WINDOWS=1 (round 5: built, measured slower, off by default): with every band resident the pixel kernels read each window where
+    it lies in its band (PatchRef) and only the border nuclei are copied.  Same bytes, same arithmetic: the rows of the shipped form, bit for
+    bit -- random order (windows of one chunk in many bands), odd image widths (rows at every alignment), edge-case rings incl. a full-patch one."""
+    import os
+    n, H = 260, 520
+    off, xy, img = _scene(synth, ps, n, H, W, 29, False)
+    e_off, e_xy = par.edge_case_rings(ps)
+    off, xy = par.concat_rings((off, xy), (e_off, e_xy))
+    sets = [0, 1, 2, 3, 4]
+    ctx = nfx.Context(0)
+    image = nfx.pinned_empty(img.shape, np.uint8)
+    image[...] = img
+    rows = nfx.pinned_empty((len(off) - 1, 418), np.float32)
+    want, wcen, st0 = ctx.extract_tile_streamed(sets, off, xy, image, ps, batch_size=10, block=64, chunk_nuclei=50)
+    os.environ["NFX_STREAM_WINDOWS"] = "1"
+    try:
+        got, cen, st = ctx.extract_tile_streamed(sets, off, xy, image, ps, batch_size=10, block=64, chunk_nuclei=50, out=rows)
+    finally:
+        del os.environ["NFX_STREAM_WINDOWS"]
+    assert st["rows_direct"] == 1 and st["chunks"] > 3
+    assert np.array_equal(cen, wcen, equal_nan=True)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.argwhere(got.view(np.uint32) != want.view(np.uint32))[:5]
+    ctx.close()
