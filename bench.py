@@ -296,7 +296,8 @@ def roofline_of(timing, steps, n, bytes_per_nucleus, workload, full_size):
     elif issue is not None:
         top = {"bound": "valu", "achieved": issue["achieved"], "peak": issue["peak"], "unit": issue["rate_unit"], "frac": issue["frac"]}
     note = ("VALU issue + LDS atomics (DESIGN.md §3): no kernel of this path is HBM-bound at these byte counts; `hbm` is reported because "
-            "the metric asks for it")
+            "the metric asks for it" + ("; a streamed step launches every kernel once per chunk and runs two chunks at a time on two streams: a launch's "
+                                        "duration here includes what the other stream's kernels took from it (see `exclusive`)" if launches_per_step > 1 else ""))
     if top["bound"] == "hbm":
         note += "; bound says hbm only because no counter summary of this csrc/ is committed (counters_source)"
     return {"bound": top["bound"], "kernel": dom_name, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"],
@@ -421,6 +422,10 @@ class SharedRows:
         err = ""
         if ranks.rank == 0:
             try:
+                need = 4 * shape[0] * shape[1] + 4096
+                vfs = os.statvfs("/dev/shm")       # a tmpfs file may be created larger than the space behind it: writing it then raises SIGBUS, so ask first
+                if vfs.f_bavail * vfs.f_frsize < need * 1.05:
+                    raise OSError(f"/dev/shm has {vfs.f_bavail * vfs.f_frsize >> 20} MiB free, the shared row matrix needs {need >> 20} MiB")
                 np.lib.format.open_memmap(self.path, mode="w+", dtype=np.float32, shape=shape).flush()
             except OSError as e:
                 err = repr(e)
@@ -698,6 +703,15 @@ def main():
             torch.cuda.empty_cache()
             if rank == 0:
                 also["full_feature_set_resident"] = e
+                # The streamed step runs its chunks two at a time on two streams, so a launch's HIP-event duration there includes what the other
+                # stream's kernels took from it (k_gabor: ~11.5 ms per 89 k-nucleus chunk launch against 5.2 ms alone).  The SAME kernel's launch
+                # with the GPU to itself -- this leg: same nuclei, same feature sets, resident inputs, one launch per step -- is put beside it
+                rx = e["roofline"]
+                roofline["exclusive"] = {"what": "the same workload with resident inputs (also.full_feature_set_resident): one launch per kernel and step, nothing "
+                                                 "running beside it -- the figure that speaks for the kernel; the top-level one is the streamed step's own (launches of "
+                                                 "two chunks overlap on two streams)",
+                                         "kernel": rx["kernel"], "bound": rx["bound"], "achieved": rx["achieved"], "peak": rx["peak"], "unit": rx["unit"], "frac": rx["frac"],
+                                         "avg_launch_ms": rx["avg_launch_ms"], "hbm_frac": rx["hbm"]["frac"]}
 
     if rank == 0:
         sharding = "single GPU"

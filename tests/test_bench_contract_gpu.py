@@ -67,6 +67,9 @@ def test_bench_line(workload):
         assert a["config3_streamed"]["rows_equal_resident_tile_rows"] is True
         assert a["full_feature_set_resident"]["config"]["columns"] == 418
         _check_roofline(a["full_feature_set_resident"]["roofline"])
+        # the streamed step's launches overlap on two streams: the same kernel's launch with the GPU to itself is quoted beside it
+        ex = rf["exclusive"]
+        assert ex["kernel"] == a["full_feature_set_resident"]["roofline"]["kernel"] and ex["avg_launch_ms"] > 0 and 0 < ex["hbm_frac"] < 1
     else:
         assert c["inputs_mode"] == "resident"
 
