@@ -235,6 +235,22 @@ int main(int argc, char **argv)
         for (int s : sets) F += nfx_feature_set_num_columns(s);
         const int64_t n = (int64_t)poly.size();
         std::vector<float> rows((size_t)n * F), cen((size_t)n * 2);
+        // The decoded slide and the row matrix are PINNED for the extraction (hipHostRegister: 3-20 ms per GB on this host, scripts/pin_probe.hip --
+        // an order of magnitude cheaper than allocating pinned memory, 185 ms per GB): the slide's bands then travel asynchronously, beside the
+        // kernels, and the feature kernels write the rows straight into `rows` (nfx.h: nfx_extract_tile_streamed, rows_direct) instead of
+        // into a device buffer that is copied home chunk by chunk.  NFX_CLI_PIN=0 leaves both pageable (the round 1-4 behaviour).
+        struct Registered { // unregistered before the vectors go
+            void *p = nullptr;
+            explicit Registered(void *q, size_t bytes) { if (q && bytes && nfx_host_register(q, bytes) == NFX_OK) p = q; }
+            ~Registered() { if (p) nfx_host_unregister(p); }
+            Registered(const Registered &) = delete;
+            Registered &operator=(const Registered &) = delete;
+        };
+        const bool pin = !([] { const char *e = getenv("NFX_CLI_PIN"); return e && atoi(e) == 0; }());
+        const double t_pin = now_s();
+        Registered pinned_img(pin ? img.data.data() : nullptr, img.data.size()), pinned_rows(pin ? rows.data() : nullptr, rows.size() * sizeof(float));
+        if (pin) log_debug(std::string("Pinned the image (") + (pinned_img.p ? "ok" : "refused: pageable copies") + ") and the rows (" + (pinned_rows.p ? "ok" : "refused: staged on the device") +
+                           ") in " + std::to_string(now_s() - t_pin) + " s");
         // columns the reference's frame holds as f64 (shape.rs:116-127: geometric_features' own return values): kept at that
         // width in every output format.  wide[j] = column of `wide_rows` that feature column j comes from, -1 for f32 columns
         std::vector<int> wide((size_t)F, -1);
@@ -272,7 +288,8 @@ int main(int argc, char **argv)
                 if (st != NFX_OK) { errs[(size_t)r] = nfx_last_error(ctxs[(size_t)r]); return; }
                 log_debug("GPU " + std::to_string(r) + ": " + std::to_string(i1 - i0) + " nuclei in " + std::to_string(ss.chunks) + " chunks, " +
                           std::to_string(ss.blocks_copied) + " of " + std::to_string(ss.blocks_total) + " blocks (" +
-                          std::to_string(ss.image_bytes_h2d >> 20) + " MiB) to the device");
+                          std::to_string(ss.image_bytes_h2d >> 20) + " MiB) to the device" + (ss.image_pinned ? ", image pinned" : ", image pageable") +
+                          (ss.rows_direct ? ", rows written home by the kernels" : ", rows staged and copied"));
                 if (any_wide) { // the polygon columns once more, unrounded (preprocess_polygon + geometric_features::*, utils.rs:54-74, shape.rs:89-97)
                     std::vector<float> centred(2 * (size_t)off.back());
                     nfx_status s2 = nfx_preprocess_polygons(ctxs[(size_t)r], i1 - i0, off.back(), off.data(), poly.ring_xy.data() + 2 * (size_t)base,

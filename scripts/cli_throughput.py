@@ -32,10 +32,12 @@ with tempfile.TemporaryDirectory() as d:
             f.write(("," if i else "") + json.dumps({"type": "Feature", "bbox": [x0, y0, x1, y1], "geometry": {"type": "Polygon", "coordinates": [ring.astype(float).tolist()]}}, separators=(",", ":")))
         f.write("]}")
     print(f"inputs: {n} nuclei, {side}x{side} tile, geojson {os.path.getsize(os.path.join(d, 'n.geojson')) / 1e6:.0f} MB, png {os.path.getsize(os.path.join(d, 't.png')) / 1e6:.0f} MB, generated in {time.time() - t0:.1f} s", flush=True)
-    for ext in ("csv", "parquet", "feather", "json"):
+    for ext, env in (("csv", {}), ("parquet", {}), ("feather", {}), ("json", {}), ("parquet", {"NFX_CLI_PIN": "0"}), ("feather", {"NFX_CLI_PIN": "0"}), ("feather", {})):
         out = os.path.join(d, "o." + ext)
         t0 = time.time()
-        r = subprocess.run([CLI, "-v", "-g", "0", "-p", str(ps), os.path.join(d, "n.geojson"), os.path.join(d, "t.png"), out, "all"], capture_output=True, text=True)
+        r = subprocess.run([CLI, "-v", "-o", "-g", "0", "-p", str(ps), os.path.join(d, "n.geojson"), os.path.join(d, "t.png"), out, "all"], capture_output=True, text=True,
+                           env=dict(os.environ, **env))
         dt = time.time() - t0
+        ext = ext + (" NFX_CLI_PIN=0" if env else "")
         dbg = [ln.split(">", 1)[1].strip() for ln in r.stderr.splitlines() if "DEBUG" in ln]
-        print(f"{ext:8s} rc={r.returncode} wall {dt:6.2f} s  ({n / dt / 1e3:7.1f} k nuclei/s)  output {os.path.getsize(out) / 1e6:7.1f} MB | " + " | ".join(dbg), flush=True)
+        print(f"{ext:22s} rc={r.returncode} wall {dt:6.2f} s  ({n / dt / 1e3:7.1f} k nuclei/s)  output {os.path.getsize(out) / 1e6:7.1f} MB | " + " | ".join(dbg), flush=True)
