@@ -56,6 +56,24 @@ def read(d):
             a = by.setdefault(e[3], [0, 0.0]); a[0] += 1; a[1] += (e[1] - e[0]) / 1e6
     for k, (c, ms) in sorted(by.items(), key=lambda kv: -kv[1][1])[:14]:
         print(f"  {k:46s} x{c:4d} {ms:8.2f} ms")
+    # what runs beside what: wall time by the set of HEAVY kernels (k_gabor / k_glcm classes / k_glrlm) in flight -- the chunks' kernels run two at a
+    # time on two streams, so "k_gabor+k_glcm" is time in which the two share the chip, "k_gabor" time in which it has the chip to itself
+    heavy = lambda nm: nm.startswith("void nfx::k_gabor") or nm.startswith("void nfx::k_glcm<") or nm.startswith("void nfx::k_glrlm")
+    pts = []
+    for e in ev:
+        if e[2] == "K":
+            pts.append((e[0], 1, e[3])); pts.append((e[1], -1, e[3]))
+    pts.sort()
+    active, combo, last = {}, {}, t0
+    for t, d, nm in pts:
+        if t > last:
+            names = [k for k, v in active.items() if v > 0]
+            h = sorted(set(k.replace("void nfx::", "").split("<")[0] for k in names if heavy(k)))
+            key = "+".join(h) if h else ("light kernels only" if names else "no kernel")
+            combo[key] = combo.get(key, 0) + (t - last)
+        active[nm] = active.get(nm, 0) + d
+        last = t
+    print("wall time by heavy kernels in flight: " + ", ".join(f"{k} {v / 1e6:.1f} ms" for k, v in sorted(combo.items(), key=lambda kv: -kv[1])))
     # gaps in the feature kernels' union (> 0.2 ms): what the compute stream waited for
     iv = sorted((e[0], e[1], e[3]) for e in ev if feat(e))
     end, last = iv[0][1], iv[0][2]
