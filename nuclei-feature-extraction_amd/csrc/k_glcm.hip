@@ -53,6 +53,14 @@ namespace nfx {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// NFX_GL_DERIVE (round 5; 0 = the round 1-4 form, kept for A/B builds): the pass over levels 32 / 64 / 128 counts level 128 only, pair by pair; levels 64
+// and 32 nest in it (floor(128 g) >> k), so their dense tables, sum and difference histograms are filled afterwards from the DISTINCT level-128 cells (a
+// sweep over the hash slots: count-weighted plain adds instead of four returning atomics per pair on the addresses with the highest multiplicity) and
+// their sum G^2 / sum G ln G from a sweep over the final dense counts.  Every sum the slots' order could touch is an integer, so a nucleus still gets the
+// same bits in whichever class it runs.  -7.0 % at 48 x 48, -4.3 % at 64 x 64 (profiles/r05_glcm_derive.txt); counts == the oracle's as before.
+#ifndef NFX_GL_DERIVE
+#define NFX_GL_DERIVE 1
+#endif
 static constexpr int GL_NACC = 10;
 static constexpr int GL_RANKS = 4096;      // rank range of the global difference tables (a cell holds at most 4032 pairs)
 static constexpr int GL_COUNTS = 8200;     // count range of the x ln x table (a marginal bin holds at most 2 * 4032)
@@ -76,17 +84,21 @@ struct GlGeom {
     //   pass B: hx254 at 0 (64 HXB) | hs254 at 64 HXB (64 HSB)
     static constexpr int HS128_SLICES = FULL ? 4 : 3;
     static constexpr int HXB = FULL ? 4 : 3, HSB = 2 * HXB;
-    static constexpr int HIST_A = 320 + 64 * HS128_SLICES, HIST_B = 64 * (HXB + HSB);
+    // (NFX_GL_DERIVE) one more slice behind hs128: the DIFFERENCE histograms of levels 64 (low half of word d) and 32 (high half): pairs with |a - b| = d
+    static constexpr int PD_OFF = 320 + 64 * HS128_SLICES;
+    static constexpr int HIST_A = 320 + 64 * HS128_SLICES + (NFX_GL_DERIVE ? 64 : 0), HIST_B = 64 * (HXB + HSB);
     static constexpr int HIST_WORDS = HIST_A > HIST_B ? HIST_A : HIST_B;
     static_assert(2 * R32 <= 64 && 2 * R64 <= 128 && 2 * R128 <= 64 * HS128_SLICES && R254 <= 64 * HXB && 2 * R254 <= 64 * HSB, "histogram segments");
 };
 
 __constant__ int kGlcmOffsets[4][2] = {{0, 1}, {1, 1}, {1, 0}, {1, -1}}; // texture.rs:20 (dy,dx)
 
+static constexpr int GL_ROWEND = 1048;     // words of the largest dense triangular table (64 levels: 2080 packed 16-bit cells), rounded up
 struct GlcmLuts {           // device tables built on the host
     double dO[GL_RANKS];    // 2[h(k+1)-h(k)]
     double dD[GL_RANKS];    // H(k+1)-H(k)
     double xlnx[GL_COUNTS]; // x ln x
+    unsigned short rowend[GL_ROWEND]; // (NFX_GL_DERIVE) word w of a dense triangular table holds cells 2w, 2w + 1; rowend[w] = index of the DIAGONAL cell of the row cell 2w lies in
 };
 
 // table look-ups by a 32-bit BYTE offset from a wave-uniform base: the address is one shift and the scalar-base form of the load
@@ -648,6 +660,79 @@ __global__ __launch_bounds__(64, (QCAP <= (FULL ? 768 : 1024) ? 3 : (QCAP <= 204
             unsigned np = 0;
             unsigned pend[2][3] = {{0u, 0u, 0u}, {0u, 0u, 0u}}; // rank-table indices of the previous iteration (entry 0 holds 0.0)
             bool table_full = false;
+#if NFX_GL_DERIVE
+            // level 128 alone is counted pair by pair (its marginal and sum histograms, its cells in the hash table with their ranks)
+#pragma unroll 1
+            for (int e = lane; e < K; e += 128) {
+                const double ev0 = lut_at(rank_tab, pend[0][2]), ev1 = lut_at(rank_tab, pend[1][2]);
+                const Located X = locate(e, true, ps, dy, dx, s_q, s_rows1, s_rowstart);
+                const Located Y = locate(e + 64, e + 64 < K, ps, dy, dx, s_q, s_rows1, s_rowstart);
+                const u16x2 a2 = bytes2<1>(X.qa, Y.qa) - base2, b2 = bytes2<1>(X.qb, Y.qb) - base2;
+                const Ordered2 P2 = order2(a2, b2);
+                const unsigned fmask = (X.fwd ? 0xFFFFu : 0u) | (Y.fwd ? 0xFFFF0000u : 0u);
+                s_memo[e] = (unsigned char)X.memo;
+                s_memo[e + 64] = (unsigned char)Y.memo;
+                atomicAdd(&s_hist[a2.x], X.deg);
+                atomicAdd(&s_hist[a2.y], Y.deg);
+                np += (X.fwd ? 1u : 0u) + (Y.fwd ? 1u : 0u);
+                const u16x2 s2 = a2 + b2;
+                atomicAdd(&s_hist[320 + s2.x], X.fwd ? 1u : 0u);
+                atomicAdd(&s_hist[320 + s2.y], Y.fwd ? 1u : 0u);
+                unsigned rx2, ry2;
+                const u16x2 k2 = cell_key2(P2);
+                hash_rank2<SLOTS>(s_tab + GL_H128_OFF, s_dummy + (lane & 7), k2.x, X.fwd, k2.y, Y.fwd, rx2, ry2, table_full);
+                pair_acc2(X.fwd, Y.fwd, fmask, P2, rx2, ry2, A2, pend[0][2], pend[1][2]);
+                A2.ents += ev0 + ev1;
+            }
+            A2.ents += lut_at(rank_tab, pend[0][2]) + lut_at(rank_tab, pend[1][2]);
+            wave_lds_fence();
+            if (!FULL && __any(table_full)) { abandoned = true; break; } // wave-uniform
+            // levels 64 and 32 from the DISTINCT level-128 cells: slot word = key << 16 | pairs, key = hi << 8 | lo (relative levels, lo <= hi).  A cell of
+            // c pairs adds c to its coarse cell (dense triangular tables, packed 16-bit counts), to the sum histogram at lo' + hi' and to the difference
+            // histogram at hi' - lo' -- integers, so the order the slots are met in (it depends on the class's table size) does not show in any sum
+            for (int sl = lane; sl < SLOTS; sl += 64) {
+                const unsigned wd = s_tab[GL_H128_OFF + sl];
+                if (wd != GL_EMPTY) {
+                    const unsigned c = wd & 0xFFFFu, lo = (wd >> 16) & 255u, hi = wd >> 24;
+                    const unsigned lo1 = lo >> 1, hi1 = hi >> 1, lo0 = lo >> 2, hi0 = hi >> 2;
+                    const unsigned t1 = ((hi1 * (hi1 + 1u)) >> 1) + lo1, t0 = ((hi0 * (hi0 + 1u)) >> 1) + lo0;
+                    atomicAdd(&s_tab[GL_D64_OFF + (t1 >> 1)], c << ((t1 & 1u) * 16u));
+                    atomicAdd(&s_tab[t0 >> 1], c << ((t0 & 1u) * 16u));
+                    atomicAdd(&s_hist[192 + lo1 + hi1], c);
+                    atomicAdd(&s_hist[128 + lo0 + hi0], c);
+                    atomicAdd(&s_hist[G::PD_OFF + (hi1 - lo1)], c);
+                    atomicAdd(&s_hist[G::PD_OFF + (hi0 - lo0)], c << 16);
+                }
+            }
+            wave_lds_fence();
+            {   // sum G^2 and sum G ln G of levels 64 and 32 from the final counts of their dense tables (only the rows the nucleus's span reaches): a cell of
+                // m pairs stands for G[a][b] = G[b][a] = m off the diagonal (2 m^2, 2 m ln m) and for G[a][a] = 2 m on it (4 m^2, 2m ln 2m); which cells are
+                // diagonal comes from the row-end table.  Look-ups of one trip are used in the next (their round trip hides behind it)
+                const int span64 = (hi128 - b128) >> 1, span32 = span64 >> 1;
+                const int words64 = ((span64 * (span64 + 3)) >> 2) + 1, words32 = ((span32 * (span32 + 3)) >> 2) + 1; // words up to the last row's diagonal cell
+                auto dense_sums = [&](const unsigned *tab, int words, unsigned &asmn, double &ents) {
+                    double p0 = 0.0, p1 = 0.0;
+                    for (int w = lane; w < words; w += 64) {
+                        const unsigned v = tab[w], re = lut->rowend[w];
+                        const unsigned m0 = v & 0xFFFFu, m1 = v >> 16;
+                        const bool dg0 = (unsigned)(2 * w) == re, dg1 = (unsigned)(2 * w + 1) == re;
+                        asmn += (dg0 ? 4u : 2u) * m0 * m0 + (dg1 ? 4u : 2u) * m1 * m1;
+                        ents += p0 + p1;
+                        const double x0 = lut_at(lut->xlnx, dg0 ? 2u * m0 : m0), x1 = lut_at(lut->xlnx, dg1 ? 2u * m1 : m1);
+                        p0 = dg0 ? x0 : x0 + x0;
+                        p1 = dg1 ? x1 : x1 + x1;
+                    }
+                    ents += p0 + p1;
+                };
+                dense_sums(s_tab + GL_D64_OFF, words64, A1.asmn, A1.ents);
+                dense_sums(s_tab, words32, A0.asmn, A0.ents);
+                // the difference histograms: lane d holds the pairs with |a - b| = d (level 64 in the low half, level 32 in the high half)
+                const unsigned pdw = s_hist[G::PD_OFF + lane], p64 = pdw & 0xFFFFu, p32 = pdw >> 16, dl = (unsigned)lane;
+                const float rinv = __builtin_amdgcn_rcpf(1.0f + (float)(dl * dl));
+                A1.D1 = dl * p64; A1.D2 = dl * dl * p64; A1.idm = (float)p64 * rinv;
+                A0.D1 = dl * p32; A0.D2 = dl * dl * p32; A0.idm = (float)p32 * rinv;
+            }
+#else
 #pragma unroll 1
             for (int e = lane; e < K; e += 128) {
                 double ev[2][3];
@@ -693,6 +778,7 @@ __global__ __launch_bounds__(64, (QCAP <= (FULL ? 768 : 1024) ? 3 : (QCAP <= 204
             A2.ents += lut_at(rank_tab, pend[0][2]) + lut_at(rank_tab, pend[1][2]);
             wave_lds_fence();
             if (!FULL && __any(table_full)) { abandoned = true; break; } // wave-uniform
+#endif
             unsigned np_w;
             {
                 // fold: read and clear the histogram words, request every x ln x together, and only then do the
@@ -1144,18 +1230,23 @@ hipError_t prepare_glcm(nfx_ctx *ctx)
 {
     if (ctx->glcm_lut) return hipSuccess;
     if (tables_locked(ctx)) return hipErrorNotReady; // device-memory calls on a reserved context and captures never allocate: nfx_ctx_reserve builds the tables
-    std::vector<double> h(2 * GL_RANKS + GL_COUNTS);
+    std::vector<GlcmLuts> hv(1);
+    GlcmLuts &h = hv[0];
     auto xl = [](double x) { return x > 0.0 ? x * std::log(x) : 0.0; };
     for (int k = 0; k < GL_RANKS; ++k) {
-        h[k] = 2.0 * (xl(k + 1.0) - xl((double)k));                       // dO
-        h[GL_RANKS + k] = xl(2.0 * (k + 1.0)) - xl(2.0 * (double)k);      // dD: H(x) = 2x ln 2x
+        h.dO[k] = 2.0 * (xl(k + 1.0) - xl((double)k));                    // dO
+        h.dD[k] = xl(2.0 * (k + 1.0)) - xl(2.0 * (double)k);              // dD: H(x) = 2x ln 2x
     }
-    for (int k = 0; k < GL_COUNTS; ++k) h[2 * GL_RANKS + k] = xl((double)k); // x ln x
-    static_assert(sizeof(GlcmLuts) == sizeof(double) * (2 * GL_RANKS + GL_COUNTS), "table layout");
+    for (int k = 0; k < GL_COUNTS; ++k) h.xlnx[k] = xl((double)k);        // x ln x
+    for (int w = 0, hi = 0; w < GL_ROWEND; ++w) {                          // row of cell 2w: the largest hi with hi (hi + 1) / 2 <= 2w
+        while ((hi + 1) * (hi + 2) / 2 <= 2 * w) ++hi;
+        h.rowend[w] = (unsigned short)(hi * (hi + 3) / 2);
+    }
+    static_assert(offsetof(GlcmLuts, xlnx) == sizeof(double) * 2 * GL_RANKS && offsetof(GlcmLuts, rowend) == sizeof(double) * (2 * GL_RANKS + GL_COUNTS), "table layout");
     double *d = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), sizeof(double) * h.size());
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), sizeof(GlcmLuts));
     if (e != hipSuccess) return e;
-    e = hipMemcpy(d, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
+    e = hipMemcpy(d, &h, sizeof(GlcmLuts), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d); return e; }
     ctx->glcm_lut = d; // published only once it is complete
     return hipSuccess;

@@ -1,7 +1,7 @@
 import os, sys, subprocess, json
 # compares alternative builds of libnfx.so (scratch_exp/*.so) on one workload
 libs = [None] + sorted(p for p in os.listdir("scratch_exp") if p.endswith(".so"))
-args = sys.argv[1:] or ["--workload", "config3", "--nuclei", "300000", "--steps", "2", "--warmup", "1", "--sets", "glcm"]
+args = sys.argv[1:] or ["--workload", "config3", "--inputs", "resident", "--nuclei", "300000", "--steps", "2", "--warmup", "1", "--sets", "glcm", "--no-also"]
 for lib in libs:
     env = dict(os.environ)
     if lib: env["NFX_LIB_PATH"] = os.path.abspath(os.path.join("scratch_exp", lib))
