@@ -22,17 +22,15 @@ def read(d):
         for r in csv.DictReader(open(f)):
             ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "C", r["Direction"], ""))
     ev.sort()
-    # the LAST streamed call: everything after the last long idle stretch of kernels before the final burst of k_gather launches
+    # the LAST call: the calls are separated by a host-side pause of 0.2 s, so walk back from the end until an idle stretch of > 50 ms
     t_end = max(e[1] for e in ev)
-    gathers = [e for e in ev if "gather_patches" in e[3]]
-    # calls are separated by a host-side pause; take the events after the largest gap among the last half of the gathers' starts
-    starts = [g[0] for g in gathers]
-    cut = 0
-    if len(starts) > 2:
-        half = starts[len(starts) // 2 - 1:]
-        gaps = [(half[i + 1] - half[i], half[i + 1]) for i in range(len(half) - 1)]
-        cut = max(gaps)[1] - 1 if gaps else 0
-    ev = [e for e in ev if e[0] >= cut - 30_000_000]
+    cut, nxt = ev[0][0], None
+    for e in sorted(ev, key=lambda x: -x[0]):
+        if nxt is not None and nxt - e[1] > 50_000_000 and e[1] < nxt:
+            cut = nxt
+            break
+        nxt = e[0] if nxt is None else min(nxt, e[0])
+    ev = [e for e in ev if e[0] >= cut]
     t0 = min(e[0] for e in ev)
     print(f"{len(ev)} events over {(t_end - t0) / 1e6:.1f} ms")
 
@@ -54,7 +52,7 @@ def read(d):
     for e in ev:
         if e[2] == "K":
             a = by.setdefault(e[3], [0, 0.0]); a[0] += 1; a[1] += (e[1] - e[0]) / 1e6
-    for k, (c, ms) in sorted(by.items(), key=lambda kv: -kv[1][1])[:14]:
+    for k, (c, ms) in sorted(by.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('TL_TOP', '14'))]:
         print(f"  {k:46s} x{c:4d} {ms:8.2f} ms")
     # what runs beside what: wall time by the set of HEAVY kernels (k_gabor / k_glcm classes / k_glrlm) in flight -- the chunks' kernels run two at a
     # time on two streams, so "k_gabor+k_glcm" is time in which the two share the chip, "k_gabor" time in which it has the chip to itself
@@ -114,10 +112,21 @@ torch.cuda.empty_cache()
 sets = [0, 1, 2, 3, 4]
 rows = nfx.pinned_empty((n, sum(nfx.num_columns(s) for s in sets)), np.float32)
 import time
-for _ in range(2):
-    t0 = time.perf_counter()
-    ctx.extract_tile_streamed(sets, off, xy, h_tile, ps, chunk_nuclei=chunk, out=rows)
-    print(f"streamed call {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
-    time.sleep(0.2)
+if os.environ.get("TL_MODE") == "resident":   # the same shard with the slide resident in HBM: one launch per kernel (what the chunks' launches are compared with)
+    d_tile = torch.from_numpy(h_tile).to(dev)
+    ctx.reserve(sets, n, len(xy), ps)
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.extract_tile(sets, d_off, d_xy, d_tile, ps)
+        torch.cuda.synchronize()
+        print(f"resident-tile call {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
+        time.sleep(0.2)
+else:
+    for _ in range(2):
+        t0 = time.perf_counter()
+        ctx.extract_tile_streamed(sets, off, xy, h_tile, ps, chunk_nuclei=chunk, out=rows)
+        print(f"streamed call {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
+        time.sleep(0.2)
 ctx.set_stream(0)
 ctx.close()
