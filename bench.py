@@ -33,8 +33,8 @@ The one JSON line also carries
                   streamed, the full feature set resident with its own roofline.
 """
 import argparse
-import hashlib
 import importlib
+import importlib.util
 import json
 import os
 import sys
@@ -65,15 +65,37 @@ PMC_NUCLEI = {"config2": 100_000, "config3": 1_000_000, "config5": 1_250_000}   
 
 
 def csrc_stamp():
-    """sha256 over the kernel and ABI sources: committed counter summaries carry the stamp they were taken on."""
-    d = os.path.join(ROOT, PKG, "csrc")
-    h = hashlib.sha256()
-    for fn in sorted(os.listdir(d)):
-        if fn.endswith((".hip", ".h", ".cpp")):
-            h.update(fn.encode())
-            with open(os.path.join(d, fn), "rb") as fh:
-                h.update(fh.read())
-    return h.hexdigest()[:16]
+    """The hash of the kernel and ABI sources ON DISK (csrc/stamp.py -- the computation csrc/Makefile compiles into the library as
+    nfx_build_stamp()): committed counter summaries carry the stamp they were taken on."""
+    spec = importlib.util.spec_from_file_location("_nfx_stamp", os.path.join(ROOT, PKG, "csrc", "stamp.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_stamp()
+
+
+def library_is_fresh():
+    """Whether the prebuilt libnfx.so was built from the sources on disk -- asked of a CHILD process, so that a stale library is never
+    mapped into this one (it could not be unloaded before the rebuilt one is loaded)."""
+    import subprocess
+    lib = os.path.join(ROOT, PKG, "libnfx.so")
+    if not os.path.exists(lib):
+        return False
+    code = "import ctypes,sys; L=ctypes.CDLL(sys.argv[1]); L.nfx_build_stamp.restype=ctypes.c_char_p; print(L.nfx_build_stamp().decode())"
+    try:
+        out = subprocess.run([sys.executable, "-c", code, lib], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
+        return out.returncode == 0 and out.stdout.strip() == csrc_stamp()
+    except Exception:
+        return False
+
+
+def require_fresh_library(nfx, source_stamp=None):
+    """The binary that is about to be measured IS a build of the sources next to it, or no line is printed: nfx_build_stamp() (compiled
+    in by csrc/Makefile) against the hash of the sources on disk.  Returns the stamp that goes into config.csrc_stamp."""
+    built, src = nfx.build_stamp(), (source_stamp or csrc_stamp())
+    if built != src:
+        sys.exit(f"bench.py: libnfx.so is stale -- built from sources with stamp {built}, the sources on disk hash to {src}; "
+                 f"run `make -C {os.path.join(PKG, 'csrc')}` (no line is printed for a binary that is not a build of these sources)")
+    return built
 
 
 def committed_counters(workload):
@@ -123,6 +145,9 @@ def parse_args():
                     help="N>1, resident legs: what carries the rows to rank 0 -- torch.distributed.gather (c10d over RCCL; default) or the engine's "
                          "own nfx_gather_rows (include/nfx.h: grouped ncclSend / ncclRecv below any framework; has only ever run with one rank -- "
                          "tests/test_comm_gpu.py needs two GPUs for more -- so unverified for N>1)")
+    ap.add_argument("--numa", default="auto", choices=["auto", "off"],
+                    help="auto (default): before its first GPU call every rank binds itself to the CPUs of its GPU's NUMA node (sysfs), so that its "
+                         "pinned slide, row matrix and staging are first-touched locally; recorded per rank in config.numa.  off: leave placement to the OS")
     ap.add_argument("--ipc-legacy", default="env", choices=["env", "0", "1"],
                     help="N>1: HSA_ENABLE_IPC_MODE_LEGACY for the ranks (RCCL peer access across processes).  env (default) = whatever the "
                          "environment holds, 0 if it holds nothing (dmabuf IPC: what this pool's host driver supports); recorded in the line")
@@ -334,6 +359,10 @@ def oracle_port_baseline(args, nfx, sets, off, xy, patches_u8_of, ps, n_local, g
     import _oracle as orc      # checker / baseline only -- never on the product path
     import _parity as par
     B = args.batch_size
+    # on the CPUs the process started with (the NUMA prologue confined it to its GPU's node; the baseline is a host measurement): the
+    # OpenMP workers are created inside the first call and inherit the mask in force then
+    bound_to = os.sched_getaffinity(0)
+    os.sched_setaffinity(0, getattr(args, "cpu_affinity0", None) or bound_to)
     cores = int(os.environ.get("NFX_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))   # the GPU box grants 16 host cores per GPU
 
     def run_sample(m):
@@ -343,8 +372,11 @@ def oracle_port_baseline(args, nfx, sets, off, xy, patches_u8_of, ps, n_local, g
         rows, _ = orc.extract(sets, off[:m + 1], xy[:off[m]], pu, ps, batch_size=B, threads=cores)
         return m, time.perf_counter() - t, rows
 
-    m0, dt0, _ = run_sample(max(B, cores * B))
-    m1, dt1, rows = run_sample(int(m0 / dt0 * args.cpu_seconds))
+    try:
+        m0, dt0, _ = run_sample(max(B, cores * B))
+        m1, dt1, rows = run_sample(int(m0 / dt0 * args.cpu_seconds))
+    finally:
+        os.sched_setaffinity(0, bound_to)
     worst = par.assert_rows_close(got_rows(m1), rows, par.column_scales(nfx, sets, ps), what="bench sample vs oracle")
     return {"value": round(m1 / dt1, 1), "unit": "nuclei/s", "cores": cores, "kind": "port",
             "what": "C/OpenMP oracle port of the reference's arithmetic (oracle/nfx_oracle.c): a stronger (faster) CPU baseline than the reference's "
@@ -364,6 +396,7 @@ class Ranks:
         import datetime
         self.dist, self.world, self.rank = dist, world, rank
         self.rccl_failure = None
+        self.rccl_ranks_seen = None     # what the probe all-reduce of ones returned on this rank: the number of ranks RCCL really joined
         self.wire_cpu = rehearsal
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
@@ -375,7 +408,8 @@ class Ranks:
                 probe = torch.ones(1, device=dev)
                 dist.all_reduce(probe, group=grp)               # the first collective brings the communicator up: a failure shows here
                 torch.cuda.synchronize()
-                if int(probe.item()) != world:
+                self.rccl_ranks_seen = int(probe.item())
+                if self.rccl_ranks_seen != world:
                     raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
             except Exception as e:
                 ok, why = 0, repr(e)[:300]
@@ -477,26 +511,33 @@ def main():
     import torch
     import torch.distributed as dist
 
-    if not os.path.exists(os.path.join(ROOT, PKG, "libnfx.so")):
-        # a checkout without the (git-ignored) built library: build it as the driver's build step would.  Rank 0 builds,
-        # the others wait for the file; the product itself never builds or falls back at run time
-        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not library_is_fresh():
+        # a checkout without the (git-ignored) built library, or one whose library was built from other sources: build it as the driver's
+        # build step would (make rebuilds what changed).  Local rank 0 builds, the others wait; the product itself never builds or falls
+        # back at run time, and require_fresh_library below refuses to measure a binary that still is not a build of these sources
+        if local_rank == 0:
             import __graft_entry__
             __graft_entry__.build()
         else:
-            while not os.path.exists(os.path.join(ROOT, PKG, "libnfx.so")):
-                time.sleep(1.0)
-            time.sleep(2.0)
+            t_wait = time.time()
+            while not library_is_fresh() and time.time() - t_wait < 900:
+                time.sleep(2.0)
     nfx = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
     D = importlib.import_module(PKG + ".distributed")
+    built_stamp = require_fresh_library(nfx)
 
     world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
-    n_dev = torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()          # (counts devices without initialising the runtime)
+    # NUMA: bind this rank to its GPU's node BEFORE the first GPU call and the first pinned allocation (distributed.py).  The CPU
+    # baselines keep the process's original CPU set (cpu_affinity0)
+    cpu_affinity0 = sorted(os.sched_getaffinity(0))
+    numa = {"bound": False, "why": "--numa off"} if args.numa == "off" else D.bind_rank_to_gpu_numa(local_rank % max(1, n_dev))
+    args.cpu_affinity0 = cpu_affinity0
     # fewer GPUs than ranks (a one-GPU box rehearsing the N>1 path): ranks share devices and the collectives run over gloo
     # through host memory -- same sharding, slicing and verification code, NOT a scaling measurement (flagged in the line)
     rehearsal = world > max(1, n_dev)
@@ -550,7 +591,13 @@ def main():
 
     also = {}
     cfg_extra = {}
+    cfg_rccl = {}
     cpu_port = None
+    # what every rank's NUMA prologue found and did, in rank order (config.numa)
+    numa_all = [numa]
+    if use_dist:
+        numa_all = [None] * world
+        dist.all_gather_object(numa_all, dict(numa, rank=rank, cpus_allowed_at_start=len(cpu_affinity0)))
     # ---- the top line ----------------------------------------------------------------------------------------------------------------
     if inputs == "streamed":
         slide = StreamedSlide(nfx, synth, torch, ctx, dev, args.workload, n_local, rank * n_local, B, set_names)
@@ -642,6 +689,9 @@ def main():
             sxl = sharded(world * n, r.F)
             el, t = timed(torch, ctl, ctx, k, 1, lambda: sxl.step(lambda b0, b1, out: r.extract(ctx, b0, b1, out, B)), lambda: fence(sxl))
             okl = sxl.verify_transport()
+            # the same shards with the rows left on the rank that computed them: what the gather adds to a step
+            o = sxl.local_rows()
+            el_nogather, _ = timed(torch, ctl, ctx, k, 1, lambda: r.extract(ctx, 0, r.n, o[:r.n], B), fence)
         else:
             o = torch.empty((r.n, r.F), dtype=torch.float32, device=dev)
             el, t = timed(torch, ctl, ctx, k, 1, lambda: r.extract(ctx, 0, r.n, o, B), fence)
@@ -654,6 +704,9 @@ def main():
              "roofline": roofline_of(t, k, r.n, r.bytes_per_nucleus, workload, n == WORKLOADS[workload][0])}
         if okl is not None:
             e["gather_checksums_match"] = bool(all(okl)) if rank == 0 else None
+            e["gather"] = {"transport": "gloo through host memory" if wire_cpu else ("RCCL (torch.distributed.gather)" if args.transport == "torch" else "RCCL (nfx_gather_rows)"),
+                           "bytes_per_step_to_rank0": 4 * (world - 1) * r.n * r.F, "ms_per_step_without_gather": round(el_nogather / k * 1e3, 3),
+                           "cost_ms_per_step": round((el - el_nogather) / k * 1e3, 3)}
         return e, r
 
     na = lambda wl: ((args.also_nuclei or (WORKLOADS[wl][0] if full_size else 0)) // B) * B
@@ -663,6 +716,13 @@ def main():
             e, r3 = resident_leg("config3", na("config3"), args.steps, True)
             if rank == 0:
                 also["config3_resident" if world == 1 else "weak_config3_rccl_gather"] = e
+                if world > 1 and "gather" in e:
+                    # on the TOP LEVEL of an N > 1 line (the driver's parsed record keeps `config`): the row gather over RCCL / xGMI that
+                    # north_star names, measured in this same run on configs[2]'s shards (the top line's own rows land in host memory)
+                    cfg_rccl = {"rccl_gather_ms_per_step": e["ms_per_step"], "rccl_gather_cost_ms_per_step": e["gather"]["cost_ms_per_step"],
+                                "rccl_gather_bytes_per_step": e["gather"]["bytes_per_step_to_rank0"], "rccl_gather_transport": e["gather"]["transport"],
+                                "rccl_gather_checksums_match": e["gather_checksums_match"],
+                                "rccl_gather_workload": f"{WORKLOADS['config3'][3]}, {e['config']['nuclei_per_gpu']} nuclei per GPU, rows gathered to rank 0"}
             # BASELINE configs[3]: the SAME nuclei cut into `world` batch-aligned shards (strong scaling); rank 0's weak-scaling inputs start with
             # exactly those nuclei, so it can check the gathered matrix against its own single-GPU result
             n_strong = args.strong_nuclei or (WORKLOADS["config3"][0] if full_size else 0)     # (any number: the last shard may be ragged, later ones empty)
@@ -729,16 +789,25 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32/f64 (u8 pixels, integer counts)", "data": "synthetic",
             "config": dict({"workload": wl_desc + (", slide streamed from pinned host memory, rows to host memory" if inputs == "streamed" else ""),
                             "nuclei_per_gpu": n_local, "patch_size": ps, "feature_sets": set_names, "columns": F, "batch_size": B,
-                            "inputs_mode": inputs, "sharding": sharding, "gen_seconds": round(gen_s, 1), "csrc_stamp": csrc_stamp(),
+                            "inputs_mode": inputs, "sharding": sharding, "gen_seconds": round(gen_s, 1), "csrc_stamp": built_stamp,
                             "hip_runtimes_mapped": nfx.hip_runtimes_mapped(),
                             "gather": (None if world == 1 else ("none needed: rows land in host memory" if inputs == "streamed" else args.gather)),
                             "transport": (("torch.distributed.gather" if (wire_cpu or args.transport == "torch") else "nfx_gather_rows (grouped ncclSend/ncclRecv)")
                                           if use_dist and inputs != "streamed" and args.gather == "rank0" else None),
                             "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") if use_dist else None,
-                            "rccl_failure": rccl_failure}, **cfg_extra),
-            "roofline": roofline, "cpu_baseline": cpu_twin if cpu_twin is not None else cpu_port,
-            "cpu_baseline_port": cpu_port if cpu_twin is not None else None, "also": also or None,
+                            "rccl_failure": rccl_failure,
+                            "rccl_ranks_seen": ranks.rccl_ranks_seen if ranks else None,   # the probe all-reduce of ones: how many ranks RCCL joined
+                            "numa": numa_all}, **cfg_rccl, **cfg_extra),
+            "roofline": roofline,
+            # TWO CPU baselines, each under its own name; `cpu_baseline` (the contract's key) repeats the one that restates the reference's
+            # own libtorch-CPU tensor programs (kind aten-twin) when it was measured, else the port -- and says which in `is`
+            "cpu_baseline": dict(cpu_twin, **{"is": "cpu_baseline_aten_twin"}) if cpu_twin is not None else (dict(cpu_port, **{"is": "cpu_baseline_port"}) if cpu_port else None),
+            "cpu_baseline_aten_twin": cpu_twin, "cpu_baseline_port": cpu_port,
+            "also": also or None,
         }
+        gpu1 = value / world     # per-GPU rate against the host's cores
+        line["speedup_vs_cpu"] = {k: round(gpu1 / b["value"], 1) for k, b in (("cpu_baseline_aten_twin", cpu_twin), ("cpu_baseline_port", cpu_port))
+                                  if b and b.get("value")} or None
         if rccl_failure:
             line["degraded"] = True     # a multi-GPU figure whose rows travelled through host memory over gloo: not an xGMI measurement
         print(json.dumps(line), flush=True)

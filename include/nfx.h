@@ -25,7 +25,7 @@
  *   nfx_extract_tile                              same, patches gathered from a resident [3,H,W]
  *                                                 u8 image by load_image_dataset's addressing rules
  *                                                 (utils.rs:141-206)
- *   nfx_extract_tile_streamed                     the same pipeline stage on a slide that is NOT resident: the image
+ *   nfx_extract_tile_streamed_v2                  the same pipeline stage on a slide that is NOT resident: the image
  *                                                 travels band by band over the host link while earlier bands'
  *                                                 nuclei are extracted (BASELINE configs[4]); replaces the crop
  *                                                 utils.rs:141-206 + move_tensors_to_device utils.rs:211-224 per batch
@@ -58,10 +58,13 @@
 extern "C" {
 #endif
 
-/* 0.4.0 -- ABI break against 0.3.0: nfx_stream_stats now starts with `struct_size` (set by the caller) and the library never
-   writes past it, so the struct can grow without corrupting callers built against an older header (0.3.0 grew it from 8 to 9
-   fields under an unchanged version number).  Everything else is unchanged. */
-#define NFX_VERSION 400
+/* 0.5.0.  Against 0.4.0: (i) the streamed entry is nfx_extract_tile_streamed_v2 -- the un-suffixed symbol of 0.3.0 / 0.4.0 is still
+   exported and returns NFX_ERR_UNSUPPORTED, so a binary built against an older header (whose nfx_stream_stats had no leading
+   `struct_size`, or a shorter one) gets an error instead of memory written past its struct; (ii) nfx_ctx_set_option replaces the
+   environment variables that used to steer the library (the default build reads NO environment variable except NFX_RCCL_PATH, see
+   nfx_comm_*); (iii) nfx_build_stamp ties a binary to the sources it was built from.  Everything else is unchanged.
+   0.4.0: nfx_stream_stats starts with `struct_size` (set by the caller) and the library never writes past it. */
+#define NFX_VERSION 500
 
 typedef struct nfx_ctx nfx_ctx;
 
@@ -96,6 +99,11 @@ typedef enum { NFX_MEM_HOST = 0, NFX_MEM_DEVICE = 1 } nfx_mem;
 
 /* ---- registry (no context, no GPU needed) ------------------------------------------------ */
 int nfx_version(void);
+/* sha-256 (first 16 hex digits) of the library's sources -- csrc's *.hip, *.cpp, *.h and this header, in name order -- as
+   csrc/Makefile computed it when the library was built (scripts/csrc_stamp.py is that computation).  bench.py prints it as
+   config.csrc_stamp and refuses to run when it differs from the hash of the sources on disk: a stale prebuilt library cannot carry a
+   fresh stamp.  "unstamped" when the library was built without the Makefile. */
+const char *nfx_build_stamp(void);
 int nfx_feature_set_count(void);
 /* FeatureSet::name(): "geometry","color","GLCM","GLRLM","gabor filter"; NULL if out of range */
 const char *nfx_feature_set_name(int set);
@@ -138,6 +146,13 @@ typedef enum { NFX_ADDR_IMAGE = 0, NFX_ADDR_SLIDE = 1 } nfx_addressing;
 nfx_status nfx_ctx_set_patch_addressing(nfx_ctx *ctx, nfx_addressing mode);
 /* blocks until everything enqueued by this context has finished */
 nfx_status nfx_ctx_synchronize(nfx_ctx *ctx);
+/* Behaviour switches of a context (set between calls; each takes effect from the next call on).  Unknown option or value:
+   NFX_ERR_INVALID_ARGUMENT.
+     NFX_OPT_STREAM_ROWS_STAGED  0 (default): when nfx_extract_tile_streamed_v2's out_rows is pinned the kernels write the rows
+                                 straight into it over the link; 1: rows are always staged in a device buffer per chunk and copied home
+                                 behind it (what a pageable out_rows gets anyway).  Same rows either way. */
+typedef enum { NFX_OPT_STREAM_ROWS_STAGED = 0, NFX_OPT_COUNT = 1 } nfx_option;
+nfx_status nfx_ctx_set_option(nfx_ctx *ctx, int option, int64_t value);
 /* Sizes the context's device workspace and builds every device table the listed sets need, once, up front, for
    device-memory calls (nfx_extract, nfx_extract_tile, nfx_compute_features_batched, nfx_rasterize_polygons) of up to n nuclei,
    n_vertices ring vertices, patch size ps and reference batch size batch_size (repeat the call for the largest of several
@@ -228,12 +243,12 @@ nfx_status nfx_extract_tile(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n
    HIP runtime: /opt/rocm's when nothing else brought one, PyTorch's bundled one when torch was imported before this library was loaded --
    its pinned tensors are then pinned for this library too; the other load order maps two runtimes and leaves torch without a GPU
    (the Python binding refuses it).
-   When out_rows is pinned the kernels write the rows straight into it over the link (NFX_STREAM_ROWS=copy in the environment keeps the
-   staged form: a device buffer per chunk and a copy behind it).
+   When out_rows is pinned the kernels write the rows straight into it over the link (nfx_ctx_set_option(NFX_OPT_STREAM_ROWS_STAGED, 1)
+   keeps the staged form: a device buffer per chunk and a copy behind it).
    stats (may be NULL; set stats->struct_size = sizeof(nfx_stream_stats) before the call): what travelled ("blocks" = bands). */
 typedef struct {
     int64_t struct_size;      /* IN: sizeof(nfx_stream_stats) as the caller was compiled; the library fills at most that many bytes
-                                 (a value below 16 or not a multiple of 8 is NFX_ERR_INVALID_ARGUMENT) and leaves it as it was */
+                                 (a value below 16, above 4096 or not a multiple of 8 is NFX_ERR_INVALID_ARGUMENT) and leaves it as it was */
     int64_t image_bytes_h2d;  /* block windows copied to the device (3 bytes per pixel, halos and re-copies included) */
     int64_t other_bytes_h2d;  /* ring offsets and vertices, per-chunk selection lists and rebased offsets */
     int64_t rows_bytes_d2h;   /* feature rows + centroids */
@@ -243,10 +258,10 @@ typedef struct {
     int64_t rows_direct;      /* 1: out_rows is pinned and the feature kernels wrote the rows into it themselves (no staging buffer, no
                                  device -> host copy); 0: rows staged on the device and copied home chunk by chunk */
 } nfx_stream_stats;
-nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t n_vertices,
-                                     const uint32_t *ring_offsets, const float *ring_xy, const uint8_t *image_u8, int64_t H, int64_t W,
-                                     int ps, int batch_size, int block, int64_t chunk_nuclei, int64_t cache_bytes, float *out_rows,
-                                     float *out_centroids_xy, nfx_stream_stats *stats);
+nfx_status nfx_extract_tile_streamed_v2(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t n_vertices,
+                                        const uint32_t *ring_offsets, const float *ring_xy, const uint8_t *image_u8, int64_t H, int64_t W,
+                                        int ps, int batch_size, int block, int64_t chunk_nuclei, int64_t cache_bytes, float *out_rows,
+                                        float *out_centroids_xy, nfx_stream_stats *stats);
 /* pinned host memory of this library's HIP runtime (hipHostMalloc / hipHostRegister): what makes host <-> device copies asynchronous
    and full rate.  nfx_host_alloc returns NULL when out of memory; nfx_host_register accepts memory that is registered already. */
 void *nfx_host_alloc(size_t bytes);

@@ -32,15 +32,15 @@ _STATUS = {0: "NFX_OK", 1: "NFX_ERR_INVALID_ARGUMENT", 2: "NFX_ERR_UNSUPPORTED",
 
 # every symbol include/nfx.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
-    "nfx_version", "nfx_feature_set_count", "nfx_feature_set_name", "nfx_feature_set_cli_name",
+    "nfx_version", "nfx_build_stamp", "nfx_feature_set_count", "nfx_feature_set_name", "nfx_feature_set_cli_name",
     "nfx_feature_set_num_columns", "nfx_feature_set_column_name", "nfx_parse_feature_sets", "nfx_centroid_key",
-    "nfx_ctx_create", "nfx_ctx_destroy", "nfx_last_error", "nfx_ctx_set_stream", "nfx_ctx_synchronize",
+    "nfx_ctx_create", "nfx_ctx_destroy", "nfx_last_error", "nfx_ctx_set_stream", "nfx_ctx_synchronize", "nfx_ctx_set_option",
     "nfx_ctx_set_patch_addressing", "nfx_ctx_reserve", "nfx_ctx_workspace_generation", "nfx_feature_set_column_dtype",
     "nfx_polygon_features_f64", "nfx_debug_texture_counts",
     "nfx_ctx_enable_timing", "nfx_ctx_kernel_timing", "nfx_ctx_reset_timing",
     "nfx_preprocess_polygons", "nfx_rasterize_polygons", "nfx_compute_features_batched",
     "nfx_extract", "nfx_extract_tile", "nfx_gather_patches",
-    "nfx_extract_tile_streamed", "nfx_host_alloc", "nfx_host_free", "nfx_host_register", "nfx_host_unregister",
+    "nfx_extract_tile_streamed_v2", "nfx_host_alloc", "nfx_host_free", "nfx_host_register", "nfx_host_unregister",
     "nfx_comm_unique_id", "nfx_comm_create", "nfx_comm_destroy", "nfx_comm_rank", "nfx_comm_world", "nfx_gather_rows",
 )
 
@@ -95,7 +95,9 @@ def lib() -> C.CDLL:
     L.nfx_feature_set_column_dtype.argtypes = [C.c_int, C.c_int]
     L.nfx_polygon_features_f64.argtypes = [vp, i64, i64, u32p, f32p, vp, C.c_int]
     L.nfx_debug_texture_counts.argtypes = [vp, i64, i64, u32p, f32p, u8p, C.c_int, vp, vp, C.c_int]
-    L.nfx_extract_tile_streamed.argtypes = [vp, i32p, C.c_int, i64, i64, u32p, f32p, u8p, i64, i64, C.c_int, C.c_int, C.c_int, i64, i64, f32p, f32p, vp]
+    L.nfx_build_stamp.restype = C.c_char_p
+    L.nfx_ctx_set_option.argtypes = [vp, C.c_int, i64]
+    L.nfx_extract_tile_streamed_v2.argtypes = [vp, i32p, C.c_int, i64, i64, u32p, f32p, u8p, i64, i64, C.c_int, C.c_int, C.c_int, i64, i64, f32p, f32p, vp]
     L.nfx_host_alloc.argtypes = [C.c_size_t]
     L.nfx_host_alloc.restype = vp
     L.nfx_host_free.argtypes = [vp]
@@ -112,6 +114,20 @@ def lib() -> C.CDLL:
     L.nfx_gather_rows.argtypes = [vp, vp, f32p, C.c_int, C.POINTER(C.c_int64), f32p, C.c_int]
     _lib = L
     return L
+
+
+def build_stamp() -> str:
+    """nfx_build_stamp(): the hash of the sources the loaded libnfx.so was built from."""
+    return lib().nfx_build_stamp().decode()
+
+
+def source_stamp() -> str:
+    """The same hash over the sources on disk (csrc/stamp.py, the Makefile's own computation)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_nfx_stamp", os.path.join(_HERE, "csrc", "stamp.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_stamp()
 
 
 def hip_runtimes_mapped() -> List[str]:
@@ -264,6 +280,14 @@ class Context:
         if mode not in ("image", "slide"):
             raise ValueError("patch addressing is 'image' or 'slide'")
         self._check(lib().nfx_ctx_set_patch_addressing(self._h, 1 if mode == "slide" else 0))
+
+    def set_option(self, option: str, value: int):
+        """nfx_ctx_set_option.  "stream_rows_staged": 1 keeps the streamed entry's rows staged on the device and copied home chunk by
+        chunk even when `out` is pinned (0, the default: the kernels write pinned rows straight home)."""
+        opts = {"stream_rows_staged": 0}
+        if option not in opts:
+            raise ValueError(f"unknown option {option!r} (known: {sorted(opts)})")
+        self._check(lib().nfx_ctx_set_option(self._h, opts[option], int(value)))
 
     def synchronize(self):
         self._check(lib().nfx_ctx_synchronize(self._h))
@@ -419,7 +443,7 @@ class Context:
 
     def extract_tile_streamed(self, sets: Sequence[int], ring_offsets, ring_xy, image_u8, ps: int, batch_size: int = 100, block: int = 0,
                               chunk_nuclei: int = 0, cache_bytes: int = 0, out=None):
-        """nfx_extract_tile_streamed: host numpy arrays in (image [3,H,W] u8 -- a :func:`pinned_empty` array for the link's full
+        """nfx_extract_tile_streamed_v2: host numpy arrays in (image [3,H,W] u8 -- a :func:`pinned_empty` array for the link's full
         rate), rows / centroids / what-travelled out.  Bit-identical to :meth:`extract_tile` on the resident image."""
         off = _prep(ring_offsets, np.uint32, False, "ring_offsets")
         xy = _prep(ring_xy, np.float32, False, "ring_xy")
@@ -435,7 +459,7 @@ class Context:
         cen = np.empty((n, 2), np.float32)
         st = (C.c_int64 * (1 + len(STREAM_STATS_FIELDS)))()
         st[0] = C.sizeof(st)                                          # nfx_stream_stats.struct_size: the library writes no further
-        self._check(lib().nfx_extract_tile_streamed(self._h, sets_arr, len(sets), n, nv, _ptr(off), _ptr(xy), _ptr(image_u8), int(image_u8.shape[1]),
+        self._check(lib().nfx_extract_tile_streamed_v2(self._h, sets_arr, len(sets), n, nv, _ptr(off), _ptr(xy), _ptr(image_u8), int(image_u8.shape[1]),
                                                     int(image_u8.shape[2]), ps, batch_size, block, chunk_nuclei, cache_bytes, _ptr(out), _ptr(cen), st))
         return out, cen, {k: int(st[1 + j]) for j, k in enumerate(STREAM_STATS_FIELDS)}
 

@@ -120,16 +120,14 @@ static __device__ __forceinline__ void hed_from_od(float o0, float o1, float o2,
 
 // ---- k_hue_batch ---------------------------------------------------------------------------------
 // VEC pixels per lane (one VEC-byte load per channel and patch; VEC = 4 when ps*ps is a multiple of 4)
-// WIN: the pixels of nucleus j lie where refs[j] says (a window of a resident image, or a packed slot): same bytes, other addresses
-template <typename T, int VEC, bool WIN = false>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void k_hue_batch(int64_t n, int ps, int batch_size, const T *__restrict__ patches,
-                                                   double *__restrict__ SC, const PatchRef *__restrict__ refs = nullptr)
+                                                   double *__restrict__ SC)
 {
     const int P = ps * ps;
     const int64_t b = blockIdx.y;
     const int px = (blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (px >= P) return;
-    const int wrow = px / ps, wcol = px - wrow * ps; // (WIN) the thread's four pixels lie in one row: ps is a multiple of 4
     const int64_t j0 = b * batch_size;
     const int64_t j1 = (j0 + batch_size) < n ? (j0 + batch_size) : n;
     double S[VEC], C[VEC];
@@ -138,16 +136,7 @@ __global__ __launch_bounds__(256) void k_hue_batch(int64_t n, int ps, int batch_
     for (int64_t j = j0; j < j1; ++j) {
         const T *p = patches + (size_t)j * 3 * P;
         float r[VEC], g[VEC], bl[VEC];
-        if constexpr (WIN) {
-            static_assert(sizeof(T) == 1 && VEC == 4, "windows are u8, four pixels per lane");
-            const PatchRef rf = refs[j]; // the same for every lane of the block
-            const uint8_t *pb = reinterpret_cast<const uint8_t *>((uintptr_t)rf.base) + (size_t)wrow * rf.row_stride + wcol;
-            uchar4 r4, g4, b4; // a window's rows start anywhere: four-byte loads at any alignment
-            __builtin_memcpy(&r4, pb, 4); __builtin_memcpy(&g4, pb + rf.chan_stride, 4); __builtin_memcpy(&b4, pb + 2 * (size_t)rf.chan_stride, 4);
-            const uint8_t rr[4] = {r4.x, r4.y, r4.z, r4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) { r[q] = (float)rr[q]; g[q] = (float)gg[q]; bl[q] = (float)bb[q]; }
-        } else if (sizeof(T) == 1 && VEC == 4) {
+        if (sizeof(T) == 1 && VEC == 4) {
             const uint8_t *pb = reinterpret_cast<const uint8_t *>(p);
             const uchar4 r4 = *reinterpret_cast<const uchar4 *>(pb + px), g4 = *reinterpret_cast<const uchar4 *>(pb + P + px),
                          b4 = *reinterpret_cast<const uchar4 *>(pb + 2 * P + px);
@@ -194,11 +183,11 @@ static __device__ __forceinline__ void pixel_channels(float r, float g, float b,
 }
 
 // ---- k_color ---------------------------------------------------------------------------------------
-template <typename T, bool WIN = false>
+template <typename T>
 __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size, int64_t n_batches, int blocks_per_batch,
                                                const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
                                                const double *__restrict__ SC, const float *__restrict__ od_lut,
-                                               float *__restrict__ out, int F, int col0, const PatchRef *__restrict__ refs = nullptr)
+                                               float *__restrict__ out, int F, int col0)
 {
     __shared__ float s_od[256];
     extern __shared__ __attribute__((aligned(16))) uint8_t s_patch_all[]; // 4 waves x min(ps*ps, COLOR_LIST_CAP) list entries
@@ -217,25 +206,9 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
 
     const int P = ps * ps;
     const T *pp = patches + (size_t)i * 3 * P;
-    // WIN: pixel p = r ps + c of channel ch lies at wb + ch wcs + r wrs + c (PatchRef); the list holds p, so r = p / ps comes back by one
-    // multiplication with a rounded-up 20-bit reciprocal (exact for p < ps^2 <= 4096: tests/test_exact_div.py)
-    const uint8_t *wb = nullptr;
-    unsigned wrs = 0, wcs = 0, winv = 0;
-    if constexpr (WIN) {
-        static_assert(sizeof(T) == 1, "windows are u8");
-        const PatchRef rf = refs[i];
-        wb = reinterpret_cast<const uint8_t *>((uintptr_t)rf.base); wrs = rf.row_stride; wcs = rf.chan_stride;
-        winv = ((1u << 20) + (unsigned)ps - 1u) / (unsigned)ps; // 20 bits: (p winv) >> 20 == p / ps for every p < ps^2, ps <= 64 (16 bits are NOT enough at 48: p = 2303)
-    }
     auto ld3 = [&](int p, unsigned &b0, unsigned &b1, unsigned &b2) { // the three channel bytes of pixel p (u8 paths)
-        if constexpr (WIN) {
-            const unsigned r = ((unsigned)p * winv) >> 20, c = (unsigned)p - r * (unsigned)ps;
-            const uint8_t *q = wb + (size_t)r * wrs + c;
-            b0 = q[0]; b1 = q[wcs]; b2 = q[2 * (size_t)wcs];
-        } else {
-            const uint8_t *pb = reinterpret_cast<const uint8_t *>(pp);
-            b0 = pb[p]; b1 = pb[P + p]; b2 = pb[2 * P + p];
-        }
+        const uint8_t *pb = reinterpret_cast<const uint8_t *>(pp);
+        b0 = pb[p]; b1 = pb[P + p]; b2 = pb[2 * P + p];
     };
     // the masked pixels' positions, compacted: masks beyond the list's capacity (only the largest nuclei of a 64x64
     // patch) leave their last pixels to a row-wise tail, so the LDS footprint stays at four waves x 4 KB
@@ -545,12 +518,8 @@ hipError_t launch_color(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
                     if (w < waste) { waste = w; bs = cand; }
                 }
                 dim3 grid4((unsigned)((groups + bs - 1) / bs), (unsigned)nbs);
-                if (job.refs)
-                    hipLaunchKernelGGL((k_hue_batch<uint8_t, 4, true>), grid4, dim3(bs), 0, ctx->stream, nn, job.ps, job.batch_size,
-                                       reinterpret_cast<const uint8_t *>(job.patches) + (size_t)j0 * 3 * P, SC + (size_t)b0 * 2 * P, job.refs + j0);
-                else
-                    hipLaunchKernelGGL((k_hue_batch<uint8_t, 4>), grid4, dim3(bs), 0, ctx->stream, nn, job.ps, job.batch_size,
-                                       reinterpret_cast<const uint8_t *>(job.patches) + (size_t)j0 * 3 * P, SC + (size_t)b0 * 2 * P, (const PatchRef *)nullptr);
+                hipLaunchKernelGGL((k_hue_batch<uint8_t, 4>), grid4, dim3(bs), 0, ctx->stream, nn, job.ps, job.batch_size,
+                                   reinterpret_cast<const uint8_t *>(job.patches) + (size_t)j0 * 3 * P, SC + (size_t)b0 * 2 * P);
             } else
                 hipLaunchKernelGGL((k_hue_batch<uint8_t, 1>), grid, dim3(256), 0, ctx->stream, nn, job.ps, job.batch_size,
                                    reinterpret_cast<const uint8_t *>(job.patches) + (size_t)j0 * 3 * P, SC + (size_t)b0 * 2 * P);
@@ -575,15 +544,13 @@ hipError_t launch_color(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
         const int64_t nb8 = (nb + 7) / 8 * 8;
         const int64_t blocks = nb8 * bpb;
         if (blocks > 0x7FFFFFFFll) return hipErrorInvalidValue;
+        const size_t lds = 4 * (size_t)(P < COLOR_LIST_CAP ? P : COLOR_LIST_CAP) * sizeof(unsigned short);
         if (job.patches_f32)
-            hipLaunchKernelGGL((k_color<float, false>), dim3((unsigned)blocks), dim3(256), 4 * (size_t)(P < COLOR_LIST_CAP ? P : COLOR_LIST_CAP) * sizeof(unsigned short), ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
-                               reinterpret_cast<const float *>(job.patches), job.mask_rows, SC, ctx->od_lut, job.out, job.F, col0, (const PatchRef *)nullptr);
-        else if (job.refs)
-            hipLaunchKernelGGL((k_color<uint8_t, true>), dim3((unsigned)blocks), dim3(256), 4 * (size_t)(P < COLOR_LIST_CAP ? P : COLOR_LIST_CAP) * sizeof(unsigned short), ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
-                               reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, SC, ctx->od_lut, job.out, job.F, col0, job.refs);
+            hipLaunchKernelGGL(k_color<float>, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
+                               reinterpret_cast<const float *>(job.patches), job.mask_rows, SC, ctx->od_lut, job.out, job.F, col0);
         else
-            hipLaunchKernelGGL((k_color<uint8_t, false>), dim3((unsigned)blocks), dim3(256), 4 * (size_t)(P < COLOR_LIST_CAP ? P : COLOR_LIST_CAP) * sizeof(unsigned short), ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
-                               reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, SC, ctx->od_lut, job.out, job.F, col0, (const PatchRef *)nullptr);
+            hipLaunchKernelGGL(k_color<uint8_t>, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, job.n, job.ps, job.batch_size, nb, bpb,
+                               reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, SC, ctx->od_lut, job.out, job.F, col0);
         e = hipGetLastError();
     }
     return e;

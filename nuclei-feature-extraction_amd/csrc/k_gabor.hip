@@ -553,15 +553,13 @@ static __device__ __forceinline__ uint64_t window_bits(const uint64_t *row, int 
 // MODE = GB_MAIN: the launch over all n nuclei; a nucleus one of whose variances came out of a badly centred sum is appended to
 // redo_list.  GB_REFINED: the launch over redo_list (count read on the device), shifts = the means already in the rows.
 // GB_TILES: the launch over the tiles of wide nuclei (above).
-// WIN: nucleus i's pixels lie where refs[i] says (PatchRef: a window of a resident image or a packed slot) -- same bytes, other addresses
-template <typename T, int MODE, bool WIN = false>
+template <typename T, int MODE>
 __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t n, int ps, const T *__restrict__ patches,
                                                          const uint64_t *__restrict__ mask_rows,
                                                          const GaborTables *__restrict__ tab, float *__restrict__ out,
                                                          int F, int col0, int dbg, int *__restrict__ redo_list, int *__restrict__ redo_count,
-                                                         GaborTileArgs ta, const PatchRef *__restrict__ refs = nullptr)
+                                                         GaborTileArgs ta)
 {
-    static_assert(!WIN || (sizeof(T) == 1 && MODE != GB_TILES), "windows are u8 patches of the row-word family");
     constexpr bool REFINED = MODE == GB_REFINED, TILES = MODE == GB_TILES;
     __shared__ float s_g[NFX_ROW_WORD_PS * GB_GW + 16];
     __shared__ f2 s_UW[GB_UH * GB_UW]; // plane pair; row r lives at index r + GB_PAD; aprons stay zero
@@ -582,7 +580,7 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
     GaborShared S;
     S.g = s_g; S.UW = s_UW;
     // u8 patches whose rows are whole 16-byte pieces come in with one 16-byte load per channel and thread
-    const bool vec = WIN || (!TILES && sizeof(T) == 1 && (ps & 15) == 0 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0);
+    const bool vec = !TILES && sizeof(T) == 1 && (ps & 15) == 0 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0;
     const int pse = TILES ? NFX_ROW_WORD_PS : ps; // the patch the nucleus code below sees: a tile's window is 64 x 64
 
     // the next nucleus's mask row and (16-byte-piece) patch travel in registers while the current nucleus is processed: their
@@ -592,16 +590,7 @@ __global__ __launch_bounds__(GB_THREADS, GB_THREADS / 128) void k_gabor(int64_t 
     auto request = [&](int64_t i2) {
         if (TILES) return; // (a tile's window rows are read where they are staged)
         if (t < 64) row_next = t < ps ? mask_rows[i2 * ps + t] : 0ull;
-        if constexpr (WIN) { // piece t of a channel = pixels [16 t, 16 t + 16): row t / (ps / 16); a window's rows start anywhere (unaligned 16-byte loads)
-            if (t < P / 16) {
-                const PatchRef rf = refs[i2];
-                const unsigned ppr = (unsigned)ps >> 4, inv = (65536u + ppr - 1u) / ppr, q = (unsigned)t, r = (q * inv) >> 16, c0 = (q - r * ppr) << 4;
-                const uint8_t *src = reinterpret_cast<const uint8_t *>((uintptr_t)rf.base) + (size_t)r * rf.row_stride + c0;
-                __builtin_memcpy(&r4n, src, 16);
-                __builtin_memcpy(&g4n, src + rf.chan_stride, 16);
-                __builtin_memcpy(&b4n, src + 2 * (size_t)rf.chan_stride, 16);
-            }
-        } else if (vec && t < P / 16) {
+        if (vec && t < P / 16) {
             const uint4 *src = reinterpret_cast<const uint4 *>(patches + (size_t)i2 * 3 * P) + t;
             r4n = src[0]; g4n = src[P / 16]; b4n = src[2 * (P / 16)];
         }
@@ -1106,22 +1095,19 @@ hipError_t launch_gabor(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
     // the BASELINE patch sizes it holds a percent of the nuclei or less, on patches smaller than the filter nearly all of them)
     const unsigned grid2 = (unsigned)(job.n < 256 * 2 * 4 ? job.n : 256 * 2 * 4);
     const GaborTileArgs none{nullptr, nullptr, nullptr, nullptr};
-    // EXPERIMENT (NFX_GABOR_PAD = bytes of dynamic LDS nobody uses): 8192 leaves room for ONE workgroup per CU instead of two, so that the
-    // waves of another stream's kernels (k_glcm: LDS-bound) share the CU with it -- DESIGN.md §8
-    static const unsigned pad = [] { const char *e = getenv("NFX_GABOR_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+#ifdef NFX_EXPERIMENTS // NFX_GABOR_PAD = bytes of dynamic LDS nobody uses: 8192 leaves room for ONE workgroup per CU (co-residency A/Bs, profiles/EXPERIMENTS.md)
+    static const unsigned pad = [] { const char *e = getenv("NFX_GABOR_PAD"); const long v = e ? atol(e) : 0; return (unsigned)(v < 0 ? 0 : (v > 65536 ? 65536 : v)); }();
+#else
+    constexpr unsigned pad = 0;
+#endif
     if (job.patches_f32) {
         const float *pf = reinterpret_cast<const float *>(job.patches);
         hipLaunchKernelGGL((k_gabor<float, GB_MAIN>), dim3(grid), dim3(GB_THREADS), pad, ctx->stream, job.n, job.ps, pf, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none);
         hipLaunchKernelGGL((k_gabor<float, GB_REFINED>), dim3(grid2), dim3(GB_THREADS), pad, ctx->stream, job.n, job.ps, pf, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none);
     } else {
         const uint8_t *pb = reinterpret_cast<const uint8_t *>(job.patches);
-        if (job.refs) {
-            hipLaunchKernelGGL((k_gabor<uint8_t, GB_MAIN, true>), dim3(grid), dim3(GB_THREADS), pad, ctx->stream, job.n, job.ps, pb, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none, job.refs);
-            hipLaunchKernelGGL((k_gabor<uint8_t, GB_REFINED, true>), dim3(grid2), dim3(GB_THREADS), pad, ctx->stream, job.n, job.ps, pb, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none, job.refs);
-            return hipGetLastError();
-        }
-        hipLaunchKernelGGL((k_gabor<uint8_t, GB_MAIN>), dim3(grid), dim3(GB_THREADS), pad, ctx->stream, job.n, job.ps, pb, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none, (const PatchRef *)nullptr);
-        hipLaunchKernelGGL((k_gabor<uint8_t, GB_REFINED>), dim3(grid2), dim3(GB_THREADS), pad, ctx->stream, job.n, job.ps, pb, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none, (const PatchRef *)nullptr);
+        hipLaunchKernelGGL((k_gabor<uint8_t, GB_MAIN>), dim3(grid), dim3(GB_THREADS), pad, ctx->stream, job.n, job.ps, pb, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none);
+        hipLaunchKernelGGL((k_gabor<uint8_t, GB_REFINED>), dim3(grid2), dim3(GB_THREADS), pad, ctx->stream, job.n, job.ps, pb, job.mask_rows, tab, job.out, job.F, col0, dbg, redo_list, redo_count, none);
     }
     return hipGetLastError();
 }

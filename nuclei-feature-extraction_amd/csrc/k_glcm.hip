@@ -445,15 +445,13 @@ static __device__ void glcm_features(const double (&a)[GL_NACC], double base, co
 // Occupancy asked of the compiler: three waves per SIMD (168 registers) wherever the class's LDS lets a CU hold more than eight waves.  At
 // 64 x 64 (twelve prefetch registers of four words) that costs 8 spilled registers in the small classes and buys a ninth and tenth wave
 // per CU: 31.34 -> 30.87 ms per 600 k nuclei (round 3; rounds 1-2 kept those classes at two waves per SIMD, 189 registers).
-// WIN: nucleus i's pixels lie where refs[i] says (PatchRef: a window of a resident image or a packed slot) -- same bytes, other addresses
-template <typename T, int QCAP, int NPRE, bool FULL, bool WIN = false>
+template <typename T, int QCAP, int NPRE, bool FULL>
 __global__ __launch_bounds__(64, (QCAP <= (FULL ? 768 : 1024) ? 3 : (QCAP <= 2048 ? 2 : 1))) void k_glcm(const int *__restrict__ list, const int *__restrict__ count, int *__restrict__ cursor,
                                              int *__restrict__ next_list, int *__restrict__ next_count, int *__restrict__ top_list, int *__restrict__ top_count, int ps,
                                              const T *__restrict__ patches, const uint64_t *__restrict__ mask_rows,
                                              const GlcmLuts *__restrict__ lut, double *__restrict__ slots, float *__restrict__ out, int F,
-                                             int col0, int64_t *__restrict__ dbg, const PatchRef *__restrict__ refs = nullptr)
+                                             int col0, int64_t *__restrict__ dbg)
 {
-    static_assert(!WIN || sizeof(T) == 1, "windows are u8");
     using G = GlGeom<FULL>;
     constexpr int GL_HIST_WORDS = G::HIST_WORDS, GL_D64_OFF = G::D64_OFF, GL_H128_OFF = G::H128_OFF;
     // never less than what lets the table memory (with the pass-A memo behind it: nothing of a nucleus lives there yet) double as
@@ -494,11 +492,7 @@ __global__ __launch_bounds__(64, (QCAP <= (FULL ? 768 : 1024) ? 3 : (QCAP <= 204
     // current ones have been put down in LDS, so their HBM latency hides behind a whole nucleus of work
     const int n16 = (3 * P) / 16;
     static_assert(sizeof(T) != 1 || (int)sizeof(s_mem) >= NPRE * 1024, "the staging area holds all NPRE KiB the prefetch registers put down");
-    const bool stage = sizeof(T) == 1 && ((3 * P) & 15) == 0 && 3 * P <= (int)sizeof(s_mem) && 3 * P <= NPRE * 1024 && (WIN || (reinterpret_cast<uintptr_t>(patches) & 15) == 0);
-    // WIN: piece x of the 3 P / 16 pieces of a patch = channel x / (P / 16), row (x mod (P / 16)) / (ps / 16); the pieces land in LDS exactly as
-    // a packed patch's do ((x inv) >> 20 == x / d for x < 768, d <= 256: d x < 2^20)
-    const unsigned w_pc = (unsigned)P >> 4, w_ppr = (unsigned)ps >> 4;
-    const unsigned w_inv_pc = WIN ? ((1u << 20) + w_pc - 1u) / (w_pc ? w_pc : 1u) : 0u, w_inv_ppr = WIN ? ((1u << 20) + w_ppr - 1u) / (w_ppr ? w_ppr : 1u) : 0u;
+    const bool stage = sizeof(T) == 1 && ((3 * P) & 15) == 0 && 3 * P <= (int)sizeof(s_mem) && 3 * P <= NPRE * 1024 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0;
     u32x4 pre[NPRE > 0 ? NPRE : 1]; // a native vector type: HIP's uint4 struct is copied with memcpy, which keeps the array in scratch memory
     uint64_t row_next;
     int i_next = list[j];
@@ -506,18 +500,7 @@ __global__ __launch_bounds__(64, (QCAP <= (FULL ? 768 : 1024) ? 3 : (QCAP <= 204
     do {                                                                                                          \
         const int64_t i_ = (I);                                                                                   \
         row_next = lane < ps ? mask_rows[i_ * ps + lane] : 0ull;                                                  \
-        if constexpr (WIN) {                                                                                      \
-            if (stage) {                                                                                          \
-                const PatchRef rf_ = refs[i_];                                                                    \
-                const uint8_t *wb_ = reinterpret_cast<const uint8_t *>((uintptr_t)rf_.base);                      \
-                _Pragma("unroll") for (int k_ = 0; k_ < NPRE; ++k_) {                                             \
-                    const unsigned x_ = lane + 64 * k_ < n16 ? (unsigned)(lane + 64 * k_) : 0u;                   \
-                    const unsigned ch_ = (x_ * w_inv_pc) >> 20, xx_ = x_ - ch_ * w_pc;                            \
-                    const unsigned r_ = (xx_ * w_inv_ppr) >> 20, c_ = (xx_ - r_ * w_ppr) << 4;                    \
-                    __builtin_memcpy(&pre[k_], wb_ + (size_t)ch_ * rf_.chan_stride + (size_t)r_ * rf_.row_stride + c_, 16); \
-                }                                                                                                 \
-            }                                                                                                     \
-        } else if (stage) {                                                                                       \
+        if (stage) {                                                                                              \
             const u32x4 *src_ = reinterpret_cast<const u32x4 *>(patches + (size_t)i_ * 3 * P);                    \
             _Pragma("unroll") for (int k_ = 0; k_ < NPRE; ++k_) pre[k_] = src_[lane + 64 * k_ < n16 ? lane + 64 * k_ : 0]; \
         }                                                                                                         \
@@ -595,11 +578,6 @@ __global__ __launch_bounds__(64, (QCAP <= (FULL ? 768 : 1024) ? 3 : (QCAP <= 204
         wave_lds_fence();
         // ---- every masked pixel is read and quantised once, all lanes busy --------------------------------------
         const T *pp = patches + (size_t)i * 3 * P;
-        const uint8_t *w_base = nullptr;
-        unsigned w_rs = 0, w_cs = 0;
-        if constexpr (WIN) {
-            if (!stage) { const PatchRef rf = refs[i]; w_base = reinterpret_cast<const uint8_t *>((uintptr_t)rf.base); w_rs = rf.row_stride; w_cs = rf.chan_stride; }
-        }
         int mx128 = 0, mn128n = 0, mx254 = 0, mn254n = 0; // maxima of q and of (top - q): minima through the same non-negative maximum
         for (int e = lane; e < K; e += 128) { // two entries per lane: both read chains in flight
             const int e2 = e + 64 < K ? e + 64 : e;
@@ -609,14 +587,6 @@ __global__ __launch_bounds__(64, (QCAP <= (FULL ? 768 : 1024) ? 3 : (QCAP <= 204
             if (stage) {
                 const uint8_t *sb = reinterpret_cast<const uint8_t *>(s_mem);
                 const unsigned r0 = sb[p], g0 = sb[P + p], b0 = sb[2 * P + p], r1 = sb[p2], g1 = sb[P + p2], b1 = sb[2 * P + p2];
-                float gs = u8_unit(r0) + u8_unit(g0), gs2 = u8_unit(r1) + u8_unit(g1); // utils.rs:172
-                gs = gs + u8_unit(b0);
-                gs2 = gs2 + u8_unit(b1);
-                g = third_of_u8_sum(gs);                                                // texture.rs:36
-                g2 = third_of_u8_sum(gs2);
-            } else if constexpr (WIN) { // the pixels where they lie: row and column are in the list entry
-                const uint8_t *q1 = w_base + (size_t)(pos >> 24) * w_rs + ((pos >> 16) & 255u), *q2 = w_base + (size_t)(pos2 >> 24) * w_rs + ((pos2 >> 16) & 255u);
-                const unsigned r0 = q1[0], g0 = q1[w_cs], b0 = q1[2 * (size_t)w_cs], r1 = q2[0], g1 = q2[w_cs], b1 = q2[2 * (size_t)w_cs];
                 float gs = u8_unit(r0) + u8_unit(g0), gs2 = u8_unit(r1) + u8_unit(g1); // utils.rs:172
                 gs = gs + u8_unit(b0);
                 gs2 = gs2 + u8_unit(b1);
@@ -1255,7 +1225,7 @@ hipError_t prepare_glcm(nfx_ctx *ctx)
 // One launch per size class whose capacity the patch can reach.  The grid is four rounds of the workgroups a CU really
 // holds (asked of the runtime once per instantiation: LDS allocation granularity and register budget included); blocks
 // beyond a list's length exit at once.
-template <typename T, int QCAP, int NPRE, bool FULL, bool WIN>
+template <typename T, int QCAP, int NPRE, bool FULL>
 static void launch_class(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *slots, const int *lists, const int *counts, int cls, int top, int col0)
 {
     // same answer for every context (one device type per process); contexts are driven from concurrent host threads, so the cached
@@ -1264,7 +1234,7 @@ static void launch_class(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, doub
     int wgs_per_cu = wgs_cached.load(std::memory_order_relaxed);
     if (wgs_per_cu == 0) {
         int b = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_glcm<T, QCAP, NPRE, FULL, WIN>, 64, 0) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 1; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_glcm<T, QCAP, NPRE, FULL>, 64, 0) != hipSuccess || b < 1) { (void)hipGetLastError(); b = 1; }
         wgs_per_cu = b > 12 ? 12 : b;
         wgs_cached.store(wgs_per_cu, std::memory_order_relaxed);
     }
@@ -1277,9 +1247,9 @@ static void launch_class(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, doub
     // ... and one whose gray levels span more of the scale than the typical-size tables to the top class's (full-range structures)
     int *top_list = FULL ? nullptr : const_cast<int *>(lists) + (int64_t)top * job.n;
     int *top_count = FULL ? nullptr : const_cast<int *>(counts) + top;
-    hipLaunchKernelGGL((k_glcm<T, QCAP, NPRE, FULL, WIN>), dim3(grid), dim3(64), 0, ctx->stream, lists + (int64_t)cls * job.n, counts + cls, const_cast<int *>(counts) + GL_CLASSES + cls,
+    hipLaunchKernelGGL((k_glcm<T, QCAP, NPRE, FULL>), dim3(grid), dim3(64), 0, ctx->stream, lists + (int64_t)cls * job.n, counts + cls, const_cast<int *>(counts) + GL_CLASSES + cls,
                        next_list, next_count, top_list, top_count, job.ps,
-                       reinterpret_cast<const T *>(job.patches), job.mask_rows, lut, slots, job.out, job.F, col0, job.dbg_glcm, WIN ? job.refs : (const PatchRef *)nullptr);
+                       reinterpret_cast<const T *>(job.patches), job.mask_rows, lut, slots, job.out, job.F, col0, job.dbg_glcm);
 }
 
 // At 64 x 64 the two smallest classes read their (at most 768) mask pixels where they lie instead of staging the 12 KB patch through LDS: the
@@ -1288,15 +1258,15 @@ static void launch_class(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, doub
 #ifndef NFX_GL_NOSTAGE_CLS
 #define NFX_GL_NOSTAGE_CLS 2
 #endif
-template <typename T, int NPRE, bool WIN = false>
+template <typename T, int NPRE>
 static void launch_classes(nfx_ctx *ctx, const Job &job, const GlcmLuts *lut, double *slots, const int *lists, const int *counts, int col0, int only)
 {
     const int top = glcm_class(job.ps * job.ps); // the class every mask of this patch size fits: its tables are full-size
     auto run = [&](int cls) { return cls <= top && (only < 0 || only == cls); };
 #define NFX_GL_CLASS(CLS, QCAP)                                                                                         \
     if (run(CLS)) {                                                                                                     \
-        if (CLS == top) launch_class<T, QCAP, NPRE, true, WIN>(ctx, job, lut, slots, lists, counts, CLS, top, col0);         \
-        else launch_class<T, QCAP, (NPRE == 12 && CLS < NFX_GL_NOSTAGE_CLS) ? 0 : NPRE, false, WIN>(ctx, job, lut, slots, lists, counts, CLS, top, col0); \
+        if (CLS == top) launch_class<T, QCAP, NPRE, true>(ctx, job, lut, slots, lists, counts, CLS, top, col0);              \
+        else launch_class<T, QCAP, (NPRE == 12 && CLS < NFX_GL_NOSTAGE_CLS) ? 0 : NPRE, false>(ctx, job, lut, slots, lists, counts, CLS, top, col0); \
     }
     NFX_GL_CLASS(0, 512)
     NFX_GL_CLASS(1, 768)
@@ -1356,11 +1326,6 @@ hipError_t launch_glcm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
     const int only = job.n <= 768 ? glcm_class(job.ps * job.ps) : -1;
     hipLaunchKernelGGL(k_glcm_classify, dim3((unsigned)((job.n + 63) / 64)), dim3(256), 0, ctx->stream, job.n, job.ps, job.mask_rows, job.areas, lists, counts, only);
     if (job.patches_f32) launch_classes<float, 1>(ctx, job, lut, slots, lists, counts, col0, only);
-    else if (job.refs) { // the pixels of every nucleus where its PatchRef says (windows of a resident image)
-        if (job.ps <= 32) launch_classes<uint8_t, 3, true>(ctx, job, lut, slots, lists, counts, col0, only);
-        else if (job.ps <= 48) launch_classes<uint8_t, 7, true>(ctx, job, lut, slots, lists, counts, col0, only);
-        else launch_classes<uint8_t, 12, true>(ctx, job, lut, slots, lists, counts, col0, only);
-    }
     else if (job.ps <= 32) launch_classes<uint8_t, 3>(ctx, job, lut, slots, lists, counts, col0, only);
     else if (job.ps <= 48) launch_classes<uint8_t, 7>(ctx, job, lut, slots, lists, counts, col0, only);
     else launch_classes<uint8_t, 12>(ctx, job, lut, slots, lists, counts, col0, only);

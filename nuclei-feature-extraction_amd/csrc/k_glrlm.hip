@@ -164,11 +164,10 @@ static __device__ __forceinline__ void rl_features(const RlWeights &W, unsigned 
     }
 }
 
-// WIN: nucleus i's pixels lie where refs[i] says (PatchRef: a window of a resident image or a packed slot) -- same bytes, other addresses
-template <typename T, bool WIN = false>
+template <typename T>
 __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__restrict__ patches,
                                               const uint64_t *__restrict__ mask_rows, float *__restrict__ out, int F,
-                                              int col0, uint32_t *__restrict__ dbg_bins, const PatchRef *__restrict__ refs = nullptr)
+                                              int col0, uint32_t *__restrict__ dbg_bins)
 {
     constexpr int QS = 68; // byte-map row stride: lane = row reads of one column spread over the banks
     __shared__ uint8_t s_q_all[4][NFX_ROW_WORD_PS * QS];
@@ -183,27 +182,13 @@ __global__ __launch_bounds__(256) void k_glrlm(int64_t n, int ps, const T *__res
     const int P = ps * ps;
     // vector staging: rows are whole 16-byte pieces, every patch starts on a 16-byte boundary
     constexpr int NPC = NFX_ROW_WORD_PS * NFX_ROW_WORD_PS / 16 / 64; // pieces per lane and channel (4)
-    const bool vec = WIN || (sizeof(T) == 1 && (ps & 15) == 0 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0);
+    const bool vec = sizeof(T) == 1 && (ps & 15) == 0 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0;
     const int npieces = P / 16;
     uint4 pre[3][NPC];
     uint64_t row_next = 0ull;
     auto request = [&](int64_t i) {
         row_next = lane < ps ? mask_rows[i * ps + lane] : 0ull;
-        if constexpr (WIN) { // piece q of a channel = pixels [16 q, 16 q + 16): row q / (ps / 16), a whole number of pieces per row
-            static_assert(sizeof(T) == 1, "windows are u8");
-            const PatchRef rf = refs[i];
-            const uint8_t *wb = reinterpret_cast<const uint8_t *>((uintptr_t)rf.base);
-            const unsigned ppr = (unsigned)ps >> 4, inv = (65536u + ppr - 1u) / ppr; // (q inv) >> 16 == q / ppr for q < 256
-#pragma unroll
-            for (int k = 0; k < NPC; ++k)
-                if (lane + 64 * k < npieces) {
-                    const unsigned q = (unsigned)(lane + 64 * k), r = (q * inv) >> 16, c0 = (q - r * ppr) << 4;
-                    const uint8_t *src = wb + (size_t)r * rf.row_stride + c0; // a window's rows start anywhere: 16-byte loads at any alignment
-                    __builtin_memcpy(&pre[0][k], src, 16);
-                    __builtin_memcpy(&pre[1][k], src + rf.chan_stride, 16);
-                    __builtin_memcpy(&pre[2][k], src + 2 * (size_t)rf.chan_stride, 16);
-                }
-        } else if (vec) {
+        if (vec) {
             const uint4 *src = reinterpret_cast<const uint4 *>(patches + (size_t)i * 3 * P);
 #pragma unroll
             for (int k = 0; k < NPC; ++k)
@@ -504,14 +489,11 @@ hipError_t launch_glrlm(nfx_ctx *ctx, const Job &job, int col0, void *scratch)
     const int64_t maxb = 256 * 7 * 2, need = (job.n + 3) / 4; // 7 workgroups (28 waves) fit a CU's LDS
     const unsigned grid = (unsigned)(need < maxb ? need : maxb);
     if (job.patches_f32)
-        hipLaunchKernelGGL((k_glrlm<float, false>), dim3(grid), dim3(256), 0, ctx->stream, job.n, job.ps,
-                           reinterpret_cast<const float *>(job.patches), job.mask_rows, job.out, job.F, col0, job.dbg_glrlm, (const PatchRef *)nullptr);
-    else if (job.refs)
-        hipLaunchKernelGGL((k_glrlm<uint8_t, true>), dim3(grid), dim3(256), 0, ctx->stream, job.n, job.ps,
-                           reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, job.out, job.F, col0, job.dbg_glrlm, job.refs);
+        hipLaunchKernelGGL(k_glrlm<float>, dim3(grid), dim3(256), 0, ctx->stream, job.n, job.ps,
+                           reinterpret_cast<const float *>(job.patches), job.mask_rows, job.out, job.F, col0, job.dbg_glrlm);
     else
-        hipLaunchKernelGGL((k_glrlm<uint8_t, false>), dim3(grid), dim3(256), 0, ctx->stream, job.n, job.ps,
-                           reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, job.out, job.F, col0, job.dbg_glrlm, (const PatchRef *)nullptr);
+        hipLaunchKernelGGL(k_glrlm<uint8_t>, dim3(grid), dim3(256), 0, ctx->stream, job.n, job.ps,
+                           reinterpret_cast<const uint8_t *>(job.patches), job.mask_rows, job.out, job.F, col0, job.dbg_glrlm);
     return hipGetLastError();
 }
 

@@ -106,8 +106,7 @@ static __device__ __forceinline__ int64_t rust_f32_as_i64(float v)
 // only keeps a wrong plan from becoming an out-of-bounds read).
 __global__ __launch_bounds__(1024) void k_gather_patches(int64_t n, const uint32_t *__restrict__ sel, const float *__restrict__ centroids,
                                                         const uint8_t *__restrict__ image, int64_t H, int64_t W, int64_t wy0, int64_t wx0,
-                                                        int64_t wh, int64_t ww, int ps, int slide_addressing, uint8_t *__restrict__ patches,
-                                                        PatchRef *__restrict__ refs)
+                                                        int64_t wh, int64_t ww, int ps, int slide_addressing, uint8_t *__restrict__ patches)
 {
     const int64_t i = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;
     const float cx = centroids[2 * i], cy = centroids[2 * i + 1];
@@ -137,18 +136,6 @@ __global__ __launch_bounds__(1024) void k_gather_patches(int64_t n, const uint32
     W = ww;
     const int P = ps * ps;
     uint8_t *dst = patches + (size_t)i * 3 * P;
-    if (refs) { // block-uniform
-        // a box that lies wholly inside the window is read where it lies: no copy.  Everything else -- the nuclei at the image's border,
-        // whose patches are partly zeros -- is copied into its packed slot below, and the ref points there
-        const bool in_place = in_window && oy == 0 && ox == 0 && b0 - t0 == ps && r0 - l0 == ps;
-        if (threadIdx.x == 0) {
-            PatchRef r;
-            if (in_place) { r.base = (uint64_t)(uintptr_t)(image + (size_t)t0 * W + (size_t)l0); r.row_stride = (uint32_t)W; r.chan_stride = (uint32_t)((size_t)H * W); }
-            else { r.base = (uint64_t)(uintptr_t)dst; r.row_stride = (uint32_t)ps; r.chan_stride = (uint32_t)P; }
-            refs[i] = r;
-        }
-        if (in_place) return;
-    }
     // a window that lies wholly inside the image -- all but the border nuclei -- is 3 ps rows of ps consecutive bytes each
     // way: 16 bytes per thread and trip (one unaligned load, one aligned store) instead of one
     if (in_window && oy == 0 && ox == 0 && b0 - t0 == ps && r0 - l0 == ps && (ps & 15) == 0 && (reinterpret_cast<uintptr_t>(patches) & 15) == 0) {
@@ -214,10 +201,9 @@ hipError_t launch_unpack_masks(nfx_ctx *ctx, int64_t n, const uint64_t *rows, in
 }
 
 hipError_t launch_gather_patches_window(nfx_ctx *ctx, int64_t n_sel, const uint32_t *sel, const float *centroids, const uint8_t *window, int64_t H,
-                                        int64_t W, int64_t wy0, int64_t wx0, int64_t wh, int64_t ww, int ps, uint8_t *patches, PatchRef *refs)
+                                        int64_t W, int64_t wy0, int64_t wx0, int64_t wh, int64_t ww, int ps, uint8_t *patches)
 {
     if (n_sel == 0) return hipSuccess;
-    if (refs && !windows_in_place_ok(ps, wh, ww)) return hipErrorInvalidValue; // (the caller asks first)
     ScopedTiming t(ctx, KS_GATHER);
     // one block per nucleus; when the 16-byte path applies a thread moves four chunks (128 threads for 48x48, 192 for 64x64)
     int threads = 256;
@@ -227,7 +213,7 @@ hipError_t launch_gather_patches_window(nfx_ctx *ctx, int64_t n_sel, const uint3
         threads = threads > 1024 ? 1024 : threads;
     }
     hipLaunchKernelGGL(k_gather_patches, dim3((unsigned)n_sel), dim3((unsigned)threads), 0, ctx->stream, n_sel, sel, centroids, window, H, W, wy0, wx0,
-                       wh, ww, ps, ctx->addressing == NFX_ADDR_SLIDE ? 1 : 0, patches, refs);
+                       wh, ww, ps, ctx->addressing == NFX_ADDR_SLIDE ? 1 : 0, patches);
     return hipGetLastError();
 }
 

@@ -290,10 +290,7 @@ nfx_status nfx_ctx_create(int device, nfx_ctx **out)
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->gabor_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_gfork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_gjoin, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         nfx_ctx_destroy(c);
         return NFX_ERR_DEVICE;
     }
@@ -308,9 +305,6 @@ void nfx_ctx_destroy(nfx_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->own_stream) { (void)hipStreamSynchronize(ctx->own_stream); (void)hipStreamDestroy(ctx->own_stream); }
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
-    if (ctx->gabor_stream) { (void)hipStreamSynchronize(ctx->gabor_stream); (void)hipStreamDestroy(ctx->gabor_stream); }
-    if (ctx->ev_gfork) (void)hipEventDestroy(ctx->ev_gfork);
-    if (ctx->ev_gjoin) (void)hipEventDestroy(ctx->ev_gjoin);
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     if (ctx->alt_stream) { (void)hipStreamSynchronize(ctx->alt_stream); (void)hipStreamDestroy(ctx->alt_stream); }
     if (ctx->d2h_stream) { (void)hipStreamSynchronize(ctx->d2h_stream); (void)hipStreamDestroy(ctx->d2h_stream); }
@@ -384,6 +378,19 @@ int nfx_ctx_kernel_timing(nfx_ctx *ctx, int k, const char **name, int64_t *launc
     return KS_COUNT;
 }
 
+nfx_status nfx_ctx_set_option(nfx_ctx *ctx, int option, int64_t value)
+{
+    if (!ctx) return NFX_ERR_INVALID_ARGUMENT;
+    switch (option) {
+    case NFX_OPT_STREAM_ROWS_STAGED:
+        if (value != 0 && value != 1) return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "NFX_OPT_STREAM_ROWS_STAGED takes 0 or 1");
+        ctx->opt_stream_rows_staged = value == 1;
+        return NFX_OK;
+    default:
+        return fail(ctx, NFX_ERR_INVALID_ARGUMENT, "unknown option " + std::to_string(option));
+    }
+}
+
 nfx_status nfx_ctx_reset_timing(nfx_ctx *ctx)
 {
     if (!ctx) return NFX_ERR_INVALID_ARGUMENT;
@@ -452,7 +459,7 @@ size_t extract_ws_bytes(const int *sets, int n_sets, int64_t n, int64_t nv, int 
     if (any_pixel_set(sets, n_sets)) b += al(sizeof(uint64_t) * (size_t)n * ps * mask_words_per_row(ps));
     if (count_set(sets, n_sets, NFX_SET_GLCM)) b += al(sizeof(int) * (size_t)n); // mask areas
     if (count_set(sets, n_sets, NFX_SET_GEOMETRY)) b += al(polygon_scratch_bytes(n, nv));
-    if (gather) b += al((size_t)n * 3 * ps * ps) + al(sizeof(PatchRef) * (size_t)n); // packed slots (border nuclei only when windows are read in place) + the refs
+    if (gather) b += al((size_t)n * 3 * ps * ps); // packed patches gathered from the resident image
     Job j; j.n = n; j.ps = ps; j.batch_size = batch_size;
     b += (size_t)count_set(sets, n_sets, NFX_SET_COLOR) * al(color_scratch_bytes(j)); // a repeated "color" gets scratch of its own
     if (count_set(sets, n_sets, NFX_SET_GLCM)) b += al(glcm_scratch_bytes(j));
@@ -472,7 +479,7 @@ nfx_status prepare_sets(nfx_ctx *ctx, const int *sets, int n_sets)
 // everything on the device; ws already reserved.  `forked` tells the caller that the side stream holds work to be joined.
 static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_off,
                                       const float *ring_xy, const uint8_t *patches_u8, const uint8_t *image, int64_t H, int64_t W,
-                                      int ps, int batch_size, float *out_rows, float *out_centroids, const PatchRef *patch_refs, bool &forked, bool &gforked)
+                                      int ps, int batch_size, float *out_rows, float *out_centroids, bool &forked)
 {
     const int F = sets_total_columns(sets, n_sets);
     float *centred = (float *)ws_alloc(ctx, sizeof(float) * 2 * (size_t)nv);
@@ -500,18 +507,11 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
     }
     if (image && pix) {
         uint8_t *gp = (uint8_t *)ws_alloc(ctx, (size_t)n * 3 * ps * ps);
-        PatchRef *refs = (PatchRef *)ws_alloc(ctx, sizeof(PatchRef) * (size_t)n);
-        if (!gp || !refs) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
-        // WINDOWS IN PLACE (round 5, measured, OFF by default: NFX_TILE_WINDOWS=1 turns it on).  The image is resident, so the pixel kernels
-        // could read every window where it lies (PatchRef) and only the border nuclei's zero-padded patches would be copied.  Built, bit-identical
-        // (tests/test_tile_gpu.py) -- and slower: a window's rows start at any byte of an odd-pitch image, and the kernels' 16-byte loads at any
-        // alignment cost k_glrlm 9 ms and k_hue_batch 1.5 ms per 1.25 M nuclei where the one-off copy into aligned packed patches costs 7
-        // (profiles/r05_windows_in_place.txt: 187.9 against 181.6 ms).  Materialising the patches IS the cheaper form.
-        const char *wenv = getenv("NFX_TILE_WINDOWS");
-        const bool in_place = wenv && atoi(wenv) == 1 && windows_in_place_ok(ps, H, W);
-        NFX_HIP(ctx, launch_gather_patches_window(ctx, n, nullptr, centroids, image, H, W, 0, 0, H, W, ps, gp, in_place ? refs : nullptr));
+        if (!gp) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
+        // the windows are MATERIALISED as aligned packed patches: reading them in place was built and measured slower (the consumers' loads at
+        // any alignment cost more than the one copy saves: profiles/EXPERIMENTS.md, "windows in place")
+        NFX_HIP(ctx, launch_gather_patches_window(ctx, n, nullptr, centroids, image, H, W, 0, 0, H, W, ps, gp));
         patches_u8 = gp;
-        if (in_place) patch_refs = refs;
     }
     // rasterise once; the mask-derived geometry columns are produced in the same kernel
     int geo_col = -1;
@@ -523,16 +523,9 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
         }
     }
     NFX_HIP(ctx, launch_raster_shape(ctx, n, ring_off, centred, ps, rows, geo_col >= 0 ? out_rows : nullptr, F, geo_col >= 0 ? geo_col : 0, areas));
-    // k_gabor (VALU-bound, 76 KB of LDS per workgroup) beside the LDS-bound k_glcm and k_glrlm of the same call, on a stream of its own: only
-    // when both kinds are selected and the patches are of the row-word family.  Off by default (NFX_GABOR_SIDE=1 turns it on)
-    static const bool gabor_side_env = [] { const char *e = getenv("NFX_GABOR_SIDE"); return e && atoi(e) == 1; }();
-    const bool gabor_beside = gabor_side_env && ps <= NFX_ROW_WORD_PS && count_set(sets, n_sets, NFX_SET_GABOR) &&
-                              (count_set(sets, n_sets, NFX_SET_GLCM) || count_set(sets, n_sets, NFX_SET_GLRLM));
-    if (gabor_beside) NFX_HIP(ctx, hipEventRecord(ctx->ev_gfork, main_stream));
     Job job;
     job.n = n; job.ps = ps; job.batch_size = batch_size; job.poly_off = ring_off; job.poly_xy = centred;
     job.patches = patches_u8; job.patches_f32 = false; job.mask_rows = rows; job.areas = areas; job.out = out_rows; job.F = F;
-    job.refs = (ps <= NFX_ROW_WORD_PS && (ps & 15) == 0) ? patch_refs : nullptr;
 
     int col = 0;
     bool geo_done = false;
@@ -573,16 +566,7 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
         case NFX_SET_GABOR: {
             if (!gabor_scr) gabor_scr = ws_alloc(ctx, gabor_scratch_bytes(job)); // (a repeated "gabor" runs after the first on the same stream: shared)
             if (!gabor_scr && gabor_scratch_bytes(job)) return fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace exhausted");
-            if (gabor_beside) { // fork (once): everything k_gabor reads -- patches, mask rows -- exists when the rasteriser has run
-                if (!gforked) {
-                    NFX_HIP(ctx, hipStreamWaitEvent(ctx->gabor_stream, ctx->ev_gfork, 0));
-                    gforked = true;
-                }
-                ctx->stream = ctx->gabor_stream;
-            }
-            const hipError_t ge = launch_gabor(ctx, job, col, gabor_scr);
-            ctx->stream = main_stream;
-            NFX_HIP(ctx, ge);
+            NFX_HIP(ctx, launch_gabor(ctx, job, col, gabor_scr));
             break;
         }
         }
@@ -593,18 +577,13 @@ static nfx_status extract_device_body(nfx_ctx *ctx, const int *sets, int n_sets,
 
 nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_off,
                           const float *ring_xy, const uint8_t *patches_u8, const uint8_t *image, int64_t H, int64_t W,
-                                 int ps, int batch_size, float *out_rows, float *out_centroids, const PatchRef *patch_refs)
+                                 int ps, int batch_size, float *out_rows, float *out_centroids)
 {
-    bool forked = false, gforked = false;
+    bool forked = false;
     hipStream_t const main_stream = ctx->stream;
     nfx_status st = extract_device_body(ctx, sets, n_sets, n, nv, ring_off, ring_xy, patches_u8, image, H, W, ps, batch_size,
-                                        out_rows, out_centroids, patch_refs, forked, gforked);
+                                        out_rows, out_centroids, forked);
     ctx->stream = main_stream;
-    if (gforked) { // joined on every path, like the polygon kernel's stream below
-        const hipError_t e1 = hipEventRecord(ctx->ev_gjoin, ctx->gabor_stream);
-        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(main_stream, ctx->ev_gjoin, 0) : e1;
-        if (st == NFX_OK && e2 != hipSuccess) st = fail(ctx, NFX_ERR_DEVICE, std::string("joining the gabor stream: ") + hipGetErrorString(e2));
-    }
     if (forked) { // join on every path: an error return must not leave the side stream dangling off the caller's stream (or capture)
         const hipError_t e1 = hipEventRecord(ctx->ev_join, ctx->side_stream);
         const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(main_stream, ctx->ev_join, 0) : e1;

@@ -45,15 +45,6 @@ struct Arena {
     size_t cap = 0, off = 0;
 };
 
-// Where a nucleus's u8 pixels lie (row-word family, round 5): byte address of pixel (channel 0, row 0, column 0), bytes from one row to the
-// next, bytes from one channel to the next.  A PACKED patch [3][ps][ps] is (patches + i 3 ps^2, ps, ps^2); a WINDOW of a resident
-// [3][H][W] image -- every nucleus whose box lies inside the image -- is (image + top W + left, W, H W): the pixel kernels then read the
-// window where it lies and no packed copy of it is ever made (k_util.hip: k_gather_patches writes the refs and copies only border nuclei).
-struct PatchRef {
-    uint64_t base;
-    uint32_t row_stride, chan_stride;
-};
-
 }  // namespace nfx
 
 struct nfx_ctx {
@@ -63,9 +54,7 @@ struct nfx_ctx {
                                       // different host threads overlap on the GPU instead of queueing on the default stream
     hipStream_t side_stream = nullptr; // the polygon kernel (64 serial programs per wave: latency-bound, hardly any issue slots) runs
     hipEvent_t ev_fork = nullptr, ev_join = nullptr; // here, beside the rasteriser and the pixel kernels of the same call
-    hipStream_t gabor_stream = nullptr;                // k_gabor beside k_glcm / k_glrlm of the same call (NFX_GABOR_SIDE; nfx_api.cpp: extract_device_body)
-    hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr;
-    // nfx_extract_tile_streamed (nfx_stream.cpp): block copies + window gathers | rows back to the host, created on first use
+    // nfx_extract_tile_streamed_v2 (nfx_stream.cpp): block copies + window gathers | rows back to the host, created on first use
     hipStream_t copy_stream = nullptr, rows_stream = nullptr, d2h_stream = nullptr, alt_stream = nullptr;
     hipEvent_t ev_ready[3] = {}, ev_done[3] = {}, ev_rows[3] = {}, ev_bands[4] = {}, ev_pass = nullptr;
     hipEvent_t ev_front = nullptr, ev_front_up = nullptr, ev_front_cen = nullptr; // the centroid frontier: centroids home | rings up | centroids made
@@ -74,6 +63,7 @@ struct nfx_ctx {
     void *pin_cen = nullptr;  // grow-only pinned host staging: the centroids of a streamed call
     size_t pin_cen_cap = 0;
     nfx_addressing addressing = NFX_ADDR_IMAGE;
+    bool opt_stream_rows_staged = false; // nfx_ctx_set_option(NFX_OPT_STREAM_ROWS_STAGED)
     std::string err;
     // Two grow-only device workspaces with a bump pointer each, rewound at the start of every API call:
     //   dev_ws   everything a NFX_MEM_DEVICE call needs.  A HIP graph captured from such a call holds addresses inside it, so it is
@@ -111,7 +101,6 @@ struct Job {
     const float *poly_xy = nullptr;
     const void *patches = nullptr;      // [n,3,ps,ps] u8 or f32
     bool patches_f32 = false;
-    const PatchRef *refs = nullptr;     // [n] where each nucleus's u8 pixels really lie (nullptr: in `patches`); ps <= NFX_ROW_WORD_PS only
     const uint64_t *mask_rows = nullptr; // [n,ps]
     const int *areas = nullptr;          // [n] mask pixel counts when the rasteriser produced them (else counted from the rows)
     float *out = nullptr;               // [n,F]
@@ -144,7 +133,7 @@ nfx_status prepare_sets(nfx_ctx *ctx, const int *sets, int n_sets);
 // everything on the device, workspace reserved by the caller (bump-allocates from ctx->ws; joins its own side-stream fork)
 nfx_status extract_device(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_off, const float *ring_xy,
                           const uint8_t *patches_u8, const uint8_t *image, int64_t H, int64_t W, int ps, int batch_size, float *out_rows,
-                          float *out_centroids, const PatchRef *patch_refs = nullptr); // patch_refs: where each nucleus's u8 pixels lie (else in patches_u8)
+                          float *out_centroids);
 
 // A synchronous (host-memory) call runs on the context's own stream and in the context's host arena (its staging buffers and
 // scratch never touch the workspace of the device-memory calls, whose addresses a captured graph may hold).  It first waits
@@ -205,15 +194,8 @@ hipError_t launch_gather_patches(nfx_ctx *ctx, int64_t n, const float *centroids
                                  int64_t W, int ps, uint8_t *patches);
 // the same out of a WINDOW of the image (rows [wy0, wy0+wh) x columns [wx0, wx0+ww), stored [3][wh][ww]) for the nuclei sel[0..n_sel)
 // of the call (nullptr: nuclei 0..n_sel): patch of nucleus i lands at patches[i]
-// refs != nullptr: nucleus i's PatchRef is written too, and a nucleus whose box lies inside the window is NOT copied (its ref points into the window)
 hipError_t launch_gather_patches_window(nfx_ctx *ctx, int64_t n_sel, const uint32_t *sel, const float *centroids, const uint8_t *window, int64_t H,
-                                        int64_t W, int64_t wy0, int64_t wx0, int64_t wh, int64_t ww, int ps, uint8_t *patches, PatchRef *refs = nullptr);
-// whether the pixel kernels can read the windows of a stored [3][wh][ww] image in place: u8, the row-word family, rows of whole 16-byte
-// pieces, a channel stride that fits 32 bits
-static inline bool windows_in_place_ok(int ps, int64_t wh, int64_t ww)
-{
-    return ps <= NFX_ROW_WORD_PS && (ps & 15) == 0 && (uint64_t)wh * (uint64_t)ww <= 0xFFFFFFFFull;
-}
+                                        int64_t W, int64_t wy0, int64_t wx0, int64_t wh, int64_t ww, int ps, uint8_t *patches);
 
 hipError_t launch_color(nfx_ctx *ctx, const Job &job, int col0, void *scratch);
 size_t color_scratch_bytes(const Job &job);

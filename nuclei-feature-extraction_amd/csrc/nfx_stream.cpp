@@ -1,4 +1,4 @@
-// nfx_stream.cpp -- nfx_extract_tile_streamed: the slide streamed band by band, host -> device copies overlapped with compute.
+// nfx_stream.cpp -- nfx_extract_tile_streamed_v2: the slide streamed band by band, host -> device copies overlapped with compute.
 //
 // Replaces (reference file:line): the per-batch pipeline stage of main.rs:146-151 on a slide that does not have to be resident --
 // load_image_dataset's crop of every nucleus's window out of the image (utils.rs:141-206), move_tensors_to_device (utils.rs:211-224:
@@ -17,12 +17,14 @@
 // evicted is copied again; the device keeps as many bands as `cache_bytes` allows -- the whole slide, typically -- and never fewer
 // than one: a batch that touches more bands than that is gathered in several passes over its bands).
 //
-//   copy stream    : H2D bands of chunk k+1, k+2, ... back to back (nothing but copies: the link never waits for a kernel)
-//   rows stream    : gather the windows of chunk k+1 out of its bands into patches[(k+1)%3]
-//   compute streams: extract(chunk k) from patches[k%3] -> rows[k%3], chunks alternating between TWO streams: the first kernels of
-//                    chunk k+1 fill the CUs that the last workgroups of chunk k's kernels leave idle (every launch of a chunk ends
-//                    in such a tail; with one stream they add up to a fifth of a 200 k-nucleus chunk's time)
-//   d2h stream     : rows of chunk k-1 to the host
+//   copy stream    : the rings of the centroid frontier, then the H2D bands of chunks k+1, k+2 (`lead` chunks ahead of the extraction when
+//                    the whole slide keeps a cache slot, one chunk ahead otherwise), back to back: the link never waits for a kernel
+//   rows stream    : k_preprocess of the frontier's rings; the lists of chunk k+1 and the gather of its windows out of its bands into
+//                    patches[(k+1)%3] (waits on the DEVICE for extract(k-2), the buffer's last reader)
+//   compute streams: extract(chunk k) from patches[k%3], chunks alternating between TWO streams: the first kernels of chunk k+1 fill the
+//                    CUs that the last workgroups of chunk k's kernels leave idle.  The kernels write their rows straight into the
+//                    caller's out_rows when it is pinned (posted writes over the link); otherwise into rows[k%3]
+//   d2h stream     : the frontier's centroids home; rows[k%3] of chunk k home when out_rows is pageable (or the staged form was asked for)
 //
 // Results are bit-identical to nfx_extract_tile on the resident image: the same gather kernel fills the same packed patches, the
 // same extraction runs on the same batches.
@@ -102,15 +104,25 @@ nfx_status nfx_host_register(void *p, size_t bytes)
 }
 void nfx_host_unregister(void *p) { if (p && hipHostUnregister(p) != hipSuccess) (void)hipGetLastError(); }
 
-nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_offsets,
-                                     const float *ring_xy, const uint8_t *image_u8, int64_t H, int64_t W, int ps, int batch_size, int block,
-                                     int64_t chunk_nuclei, int64_t cache_bytes, float *out_rows, float *out_centroids_xy, nfx_stream_stats *stats)
+// The entry of ABI 0.3.0 / 0.4.0 under its old name: those callers' nfx_stream_stats has no struct_size (0.3.0) or may be shorter than this
+// library's -- they get an error, not memory written past their struct (include/nfx.h, NFX_VERSION 500)
+nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *, int, int64_t, int64_t, const uint32_t *, const float *, const uint8_t *, int64_t, int64_t,
+                                     int, int, int, int64_t, int64_t, float *, float *, void *)
+{
+    const nfx_status st = NFX_ERR_UNSUPPORTED;
+    return ctx ? api_fail(ctx, st, "nfx_extract_tile_streamed is the entry of ABI <= 0.4.0: rebuild against include/nfx.h 0.5.0 (nfx_extract_tile_streamed_v2)") : st;
+}
+
+nfx_status nfx_extract_tile_streamed_v2(nfx_ctx *ctx, const int *sets, int n_sets, int64_t n, int64_t nv, const uint32_t *ring_offsets,
+                                        const float *ring_xy, const uint8_t *image_u8, int64_t H, int64_t W, int ps, int batch_size, int block,
+                                        int64_t chunk_nuclei, int64_t cache_bytes, float *out_rows, float *out_centroids_xy, nfx_stream_stats *stats)
 {
     nfx_status st = check_common(ctx, n, nv, ps);
     if (st != NFX_OK) return st;
     // the caller says how large ITS nfx_stream_stats is: nothing is written past that (include/nfx.h)
     const int64_t stats_size = stats ? stats->struct_size : 0;
-    if (stats && (stats_size < 16 || (stats_size & 7))) return api_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "stats->struct_size must be sizeof(nfx_stream_stats) of the caller's header");
+    if (stats && (stats_size < 16 || stats_size > 4096 || (stats_size & 7))) // (an uninitialised first field is caught here, not as a write past the caller's struct)
+        return api_fail(ctx, NFX_ERR_INVALID_ARGUMENT, "stats->struct_size must be sizeof(nfx_stream_stats) of the caller's header");
     auto put_stats = [&](const nfx_stream_stats &full) {
         if (!stats) return;
         memcpy((char *)stats + 8, (const char *)&full + 8, (size_t)std::min<int64_t>(stats_size, (int64_t)sizeof(full)) - 8);
@@ -155,22 +167,29 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     if (!ctx->ev_pass) NFX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pass, hipEventDisableTiming));
     if (!ctx->alt_stream) NFX_HIP(ctx, hipStreamCreateWithFlags(&ctx->alt_stream, hipStreamNonBlocking));
     hipStream_t const compute = ctx->stream, copy = ctx->copy_stream, rows_s = ctx->rows_stream, d2h = ctx->d2h_stream;
-    // chunks alternate between two compute streams (NFX_STREAM_NCS=1: one stream, chunk after chunk -- experiments)
+    // chunks alternate between two compute streams
+#ifdef NFX_EXPERIMENTS // NFX_STREAM_NCS=1: one stream, chunk after chunk
     const bool one_cs = [] { const char *e = getenv("NFX_STREAM_NCS"); return e && atoi(e) == 1; }();
+#else
+    constexpr bool one_cs = false;
+#endif
     hipStream_t const cs[2] = {compute, one_cs ? compute : ctx->alt_stream};
     constexpr int NB = 3; // buffer sets (patches, rows, selection lists): one being filled, two being extracted
     const bool slide = ctx->addressing == NFX_ADDR_SLIDE;
     // Rows straight home.  When out_rows is pinned for this runtime the feature kernels write their columns into it themselves (the
     // mapped host pointer goes in as the rows' address): posted writes over the link, spread over the whole extraction, instead of a
     // device buffer per chunk and a copy behind it -- which the runtime carries with a copy KERNEL of one workgroup per CU while the
-    // bands hold the DMA engine (profiles/r03_stream_d2h.txt).  Same kernels, same rows.  NFX_STREAM_ROWS=copy keeps the staged form.
+    // bands hold the DMA engine (profiles/r03_stream_d2h.txt).  Same kernels, same rows.  nfx_ctx_set_option(NFX_OPT_STREAM_ROWS_STAGED, 1)
+    // keeps the staged form.
     float *rows_direct = nullptr;
-    const bool exp_rows_dev = [] { const char *e = getenv("NFX_EXP_STREAM_ROWS_DEVICE"); return e && atoi(e) == 1; }(); // MEASUREMENT ONLY: rows stay on the device
+#ifdef NFX_EXPERIMENTS // MEASUREMENT ONLY (out_rows is never written): the rows stay in a device matrix -- what the kernels' writes over the link cost
+    const bool exp_rows_dev = [] { const char *e = getenv("NFX_EXP_STREAM_ROWS_DEVICE"); return e && atoi(e) == 1; }();
+#else
+    constexpr bool exp_rows_dev = false;
+#endif
     {
-        const char *rm = getenv("NFX_STREAM_ROWS");
-        const bool want = !(rm && !strcmp(rm, "copy"));
         const size_t rows_bytes = 4 * (size_t)n * F;
-        if (want && rows_bytes && is_pinned(out_rows) && is_pinned((const char *)out_rows + rows_bytes - 1)) {
+        if (!ctx->opt_stream_rows_staged && rows_bytes && is_pinned(out_rows) && is_pinned((const char *)out_rows + rows_bytes - 1)) {
             void *dp = nullptr;
             if (hipHostGetDevicePointer(&dp, out_rows, 0) == hipSuccess && dp) rows_direct = (float *)dp;
             else (void)hipGetLastError();
@@ -207,16 +226,14 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     const size_t scratch = extract_ws_bytes(sets, n_sets, chunk_cap, (int64_t)max_chunk_nv, ps, batch_size, false, false);
     size_t need = al(4 * ((size_t)n + 1)) + al(8 * (size_t)nv + 8) + al(8 * (size_t)n + 8) + (size_t)n_slots * slot_bytes +
                   NB * al((size_t)chunk_cap * P3) + (rows_direct ? 0 : NB * al(4 * (size_t)chunk_cap * F + 8)) + NB * al(4 * (size_t)chunk_cap + 8) +
-                  NB * al(4 * ((size_t)chunk_cap + 1)) + 2 * al(scratch) + 8192 + (exp_rows_dev ? al(4 * (size_t)n * F + 8) : 0) +
-                  NB * al(sizeof(PatchRef) * (size_t)chunk_cap);
+                  NB * al(4 * ((size_t)chunk_cap + 1)) + 2 * al(scratch) + 8192 + (exp_rows_dev ? al(4 * (size_t)n * F + 8) : 0);
     if ((st = ws_reserve(ctx, need, NFX_MEM_HOST)) != NFX_OK) return st;
     uint32_t *d_off_all = (uint32_t *)ws_alloc(ctx, 4 * ((size_t)n + 1));
     float *d_xy = (float *)ws_alloc(ctx, 8 * (size_t)nv + 8);
     float *d_cen = (float *)ws_alloc(ctx, 8 * (size_t)n + 8);
     uint8_t *d_slots = (uint8_t *)ws_alloc(ctx, (size_t)n_slots * slot_bytes);
-    uint8_t *d_patches[NB]; float *d_rows[NB]; uint32_t *d_sel[NB], *d_off[NB]; PatchRef *d_refs[NB];
+    uint8_t *d_patches[NB]; float *d_rows[NB]; uint32_t *d_sel[NB], *d_off[NB];
     for (int b = 0; b < NB; ++b) {
-        d_refs[b] = (PatchRef *)ws_alloc(ctx, sizeof(PatchRef) * (size_t)chunk_cap);
         d_patches[b] = (uint8_t *)ws_alloc(ctx, (size_t)chunk_cap * P3);
         d_rows[b] = rows_direct ? rows_direct : (float *)ws_alloc(ctx, 4 * (size_t)chunk_cap * F + 8);
         d_sel[b] = (uint32_t *)ws_alloc(ctx, 4 * (size_t)chunk_cap + 8);
@@ -227,7 +244,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         if (!rows_direct) return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
         for (int b = 0; b < NB; ++b) d_rows[b] = rows_direct;
     }
-    if (!d_off_all || !d_xy || !d_cen || !d_slots || !d_refs[NB - 1] || !d_patches[NB - 1] || !d_rows[NB - 1] || !d_sel[NB - 1] || !d_off[NB - 1])
+    if (!d_off_all || !d_xy || !d_cen || !d_slots || !d_patches[NB - 1] || !d_rows[NB - 1] || !d_sel[NB - 1] || !d_off[NB - 1])
         return api_fail(ctx, NFX_ERR_OUT_OF_MEMORY, "workspace");
     // a chunk's extraction bump-allocates its scratch from one of two marks: two extractions are in flight, on two streams
     const size_t ws_mark[2] = {ctx->ws->off, ctx->ws->off + al(scratch)};
@@ -281,23 +298,12 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     // RAMP-UP.  The call's first chunks end where their nuclei would need a SECOND band that is not on the device yet: the first chunk
     // then waits for one band (302 MB at 47 703 pixels across: 5 ms) instead of two, and while it is extracted the link delivers exactly
     // the one band the next chunk needs.  After `ramp` chunks the link is ahead for good (it outruns the extraction) and chunks take
-    // their full size -- fewer launches, fewer tails.  NFX_STREAM_RAMP overrides (0: none).
+    // their full size -- fewer launches, fewer tails.
     int64_t ramp = 2;
+    auto cap_of = [&](int64_t) -> int64_t { return chunk_cap; };
+#ifdef NFX_EXPERIMENTS // NFX_STREAM_RAMP (0: none)
     if (const char *e = getenv("NFX_STREAM_RAMP")) ramp = atoll(e);
-    // GROWING CHUNKS (experiment, NFX_STREAM_GROW=g > 1 with NFX_STREAM_FIRST=nuclei): chunk k holds at most FIRST * g^k nuclei, up to
-    // chunk_cap -- few, large extractions (every launch of a chunk has a fixed cost: ramp-up, a tail of one or two nuclei-times per GLCM
-    // class) without a long wait for the first one; the link outruns the extraction by about 1.3, which bounds a useful g
-    double grow = 1.0;
-    int64_t first = 50000;
-    if (const char *e = getenv("NFX_STREAM_GROW")) grow = atof(e);
-    if (const char *e = getenv("NFX_STREAM_FIRST")) first = atoll(e);
-    auto cap_of = [&](int64_t k) -> int64_t {
-        if (!(grow > 1.0)) return chunk_cap;
-        double c = (double)first;
-        for (int64_t j = 0; j < k && c < (double)chunk_cap; ++j) c *= grow;
-        const int64_t r = ((int64_t)c / batch_size) * batch_size;
-        return std::min<int64_t>(chunk_cap, std::max<int64_t>(batch_size, r));
-    };
+#endif
     const int64_t ramp_min = std::min<int64_t>(chunk_cap, std::max<int64_t>(batch_size, (chunk_cap / 8 / batch_size) * batch_size)); // (never slivers)
     auto plan = [&](Chunk &c) {                        // a single batch that needs more bands than the cache holds is a chunk of its own
         c.i0 = plan_next; c.blocks.clear(); c.sel.clear(); c.sel_off.clear();
@@ -358,9 +364,12 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         for (int64_t j = 0; j <= m; ++j) ho[j] = ring_offsets[c.i0 + j] - v0;
     };
 
-    // MEASUREMENT ONLY (wrong rows unless the call before left the same bands in the same arena): NFX_EXP_STREAM_NOCOPY=1 enqueues no band copy --
-    // what the chunked extraction takes with the link silent (profiles/r05_stream_experiments.txt)
+#ifdef NFX_EXPERIMENTS // MEASUREMENT ONLY (wrong rows unless the call before left the same bands in the same arena): NFX_EXP_STREAM_NOCOPY=1 enqueues no
+    // band copy -- what the chunked extraction takes with the link silent (profiles/r05_stream_experiments.txt)
     const bool exp_nocopy = [] { const char *e = getenv("NFX_EXP_STREAM_NOCOPY"); return e && atoi(e) == 1; }();
+#else
+    constexpr bool exp_nocopy = false;
+#endif
     // ---- block cache ---------------------------------------------------------------------------------------------------------
     std::vector<int64_t> slot_block((size_t)n_slots, -1), slot_use((size_t)n_slots, -1);
     int64_t img_h2d = 0, blocks_copied = 0, rows_d2h = 0, use_tick = 0, gather_passes = 0;
@@ -454,14 +463,11 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
     // chunk's lists travel on the rows stream right in front of them.  A smaller cache keeps the fused form below (lead 1, enqueue_copy).
     const bool all_resident = n_slots >= nblocks;
     int64_t lead = all_resident ? 2 : 1;
+#ifdef NFX_EXPERIMENTS // NFX_STREAM_LEAD = 1..3
     if (const char *e = getenv("NFX_STREAM_LEAD")) lead = std::max<int64_t>(1, std::min<int64_t>(3, atoll(e)));
     if (!all_resident) lead = 1;
+#endif
     const bool split = lead > 1;
-    // WINDOWS IN PLACE (round 5, measured, OFF by default: NFX_STREAM_WINDOWS=1 turns it on): with every band resident for the rest of the call the
-    // pixel kernels can read each nucleus's window where it lies in its band (PatchRef; the "gather" then only writes the refs and copies the
-    // nuclei at the slide's border).  Bit-identical and slower -- 216.7 against 209.9 ms per shard: the kernels' loads at any alignment cost more
-    // than the one copy into aligned packed patches saves (nfx_api.cpp: extract_device_body, profiles/r05_windows_in_place.txt).
-    const bool in_place = split && windows_in_place_ok(ps, sh, W) && ([] { const char *e = getenv("NFX_STREAM_WINDOWS"); return e && atoi(e) == 1; }());
     auto send_bands = [&](int64_t k) -> nfx_status { // chunk k's bands that are not on the device yet: slot = band (nothing is evicted)
         const Chunk &c = plans[k & 3];
         for (size_t q = 0; q < c.blocks.size(); ++q) {
@@ -494,8 +500,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
             const int64_t wy0 = bid * B, wh = std::min<int64_t>(H - wy0, B + ps);
             ctx->stream = rows_s;
             const hipError_t ge = launch_gather_patches_window(ctx, c.sel_off[q + 1] - c.sel_off[q], d_sel[b] + c.sel_off[q], d_cen + 2 * c.i0,
-                                                               d_slots + (size_t)block_slot[bid] * slot_bytes, H, W, wy0, 0, wh, W, ps, d_patches[b],
-                                                               in_place ? d_refs[b] : nullptr);
+                                                               d_slots + (size_t)block_slot[bid] * slot_bytes, H, W, wy0, 0, wh, W, ps, d_patches[b]);
             ctx->stream = compute;
             NFX_HIP_S(ge);
         }
@@ -503,9 +508,10 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         return NFX_OK;
     };
 
-    // Order of the host's work per chunk k: enqueue extract(k) -- its windows were gathered while chunk k-1 ran --, THEN plan chunk
-    // k+1 and send its bands on their way (the host first waits for extract(k-2), whose buffers chunk k+1 takes over: two
-    // extractions are queued on the device at that moment, so it never runs dry while the host sleeps), and the rows of chunk k home.
+    // Order of the host's work per chunk k (the loop below): enqueue extract(k) -- its windows were gathered while chunk k-1 ran --, then plan
+    // chunk k + lead and send its bands on their way (split form; in the fused form enqueue_copy does that for chunk k+1 after a HOST wait for
+    // extract(k-2), whose buffers it takes over), then the lists and gathers of chunk k+1 on the rows stream, behind a DEVICE-side wait for
+    // their patch buffer's last reader.  Two extractions are always queued, so the device never runs dry while the host plans.
     // The centroid frontier runs two chunks ahead of the plan: plan(j) reads the centroids of [plan_next, plan_next + cap(j)); right
     // after it the frontier is pushed to plan_next + cap(j+1) + cap(j+2) -- enqueued AHEAD of chunk j's bands on the copy stream (25 MB of rings
     // before 300-600 MB of bands), so that by the time the host comes to plan(j + 1) it waits for nothing that lies behind those bands.
@@ -533,7 +539,7 @@ nfx_status nfx_extract_tile_streamed(nfx_ctx *ctx, const int *sets, int n_sets, 
         ctx->stream = cstream;
         const uint32_t v0 = ring_offsets[i0], v1 = ring_offsets[i1];
         st = extract_device(ctx, sets, n_sets, m, (int64_t)(v1 - v0), d_off[b], d_xy + 2 * (size_t)v0, d_patches[b], nullptr, 0, 0, ps, batch_size,
-                            rows_direct ? rows_direct + (size_t)i0 * F : d_rows[b], nullptr, in_place ? d_refs[b] : nullptr);
+                            rows_direct ? rows_direct + (size_t)i0 * F : d_rows[b], nullptr);
         ctx->stream = compute;
         if (st != NFX_OK) return fail_sync(st);
         NFX_HIP_S(hipEventRecord(ctx->ev_done[b], cstream));

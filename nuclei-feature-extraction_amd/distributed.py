@@ -213,6 +213,133 @@ class ShardedExtraction:
             self.cctx.close()
 
 
+# ---- NUMA placement of a rank ---------------------------------------------------------------------------------------
+# Every rank of the streamed configuration (BASELINE configs[4]) pulls its slide -- 6.8 GB per step -- out of pinned host memory and
+# writes 2 GB of rows back.  Pinned pages are placed where the pinning thread runs (first touch / local allocation), so a rank whose
+# CPU threads run on the other socket streams across the socket interconnect, and eight such ranks share it.  Before its first GPU
+# call a rank therefore binds itself to the CPUs of ITS GPU's NUMA node: `nfx.pinned_empty`, the registered slice of the shared row
+# matrix and the slide are then first-touched locally.  (The reference picks `gpus[thread % n]` per rayon worker, utils.rs:211-224,
+# and leaves placement to the OS.)
+def _read(path: str) -> Optional[str]:
+    try:
+        with open(path) as fh:
+            return fh.read().strip()
+    except OSError:
+        return None
+
+
+def parse_cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    cpus: List[int] = []
+    for part in (text or "").replace("\n", "").split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-", 1)
+            cpus.extend(range(int(a), int(b) + 1))
+        else:
+            cpus.append(int(part))
+    return sorted(set(cpus))
+
+
+def visible_device_index(local_index: int, env=None) -> int:
+    """The physical (KFD order) GPU behind HIP device `local_index`: ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES
+    re-number the devices a process sees.  Lists of plain integers are followed (ROCR first, then HIP / CUDA on top of it); anything
+    else (UUIDs) leaves the index as it is."""
+    env = os.environ if env is None else env
+    idx = local_index
+    for name in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):   # HIP's list indexes into ROCR's
+        val = env.get(name)
+        if not val:
+            continue
+        try:
+            ids = [int(x) for x in val.split(",") if x.strip() != ""]
+        except ValueError:
+            return idx
+        if 0 <= idx < len(ids):
+            idx = ids[idx]
+    return idx
+
+
+def gpu_numa_nodes(sysfs: str = "/sys") -> List[Optional[int]]:
+    """NUMA node of every GPU in the order HIP enumerates them (KFD topology order): for each KFD node with SIMDs, its
+    `drm_render_minor` names /sys/class/drm/renderD<minor>/device/numa_node.  -1 in sysfs (no affinity recorded) reads as None."""
+    top = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        nodes = sorted((d for d in os.listdir(top) if d.isdigit()), key=int)
+    except OSError:
+        nodes = []
+    out: List[Optional[int]] = []
+    for d in nodes:
+        props = {}
+        for ln in (_read(os.path.join(top, d, "properties")) or "").splitlines():
+            kv = ln.split()
+            if len(kv) == 2:
+                props[kv[0]] = kv[1]
+        if int(props.get("simd_count", "0") or 0) <= 0:
+            continue                                    # a CPU node of the topology
+        minor = props.get("drm_render_minor")
+        node = _read(os.path.join(sysfs, "class", "drm", f"renderD{minor}", "device", "numa_node")) if minor is not None else None
+        try:
+            out.append(int(node) if node is not None and int(node) >= 0 else None)
+        except ValueError:
+            out.append(None)
+    if out:
+        return out
+    # no KFD topology (or an unreadable one): the DRM cards of vendor 0x1002 in card order
+    drm = os.path.join(sysfs, "class", "drm")
+    try:
+        cards = sorted((c for c in os.listdir(drm) if c.startswith("card") and c[4:].isdigit()), key=lambda c: int(c[4:]))
+    except OSError:
+        cards = []
+    for c in cards:
+        if (_read(os.path.join(drm, c, "device", "vendor")) or "").lower() != "0x1002":
+            continue
+        node = _read(os.path.join(drm, c, "device", "numa_node"))
+        try:
+            out.append(int(node) if node is not None and int(node) >= 0 else None)
+        except ValueError:
+            out.append(None)
+    return out
+
+
+def bind_rank_to_gpu_numa(local_index: int, sysfs: str = "/sys", env=None, getaffinity=None, setaffinity=None) -> dict:
+    """Binds the calling process to the CPUs of the NUMA node of HIP device `local_index` (intersected with the CPUs it is allowed
+    to run on).  Call BEFORE the first GPU call and before any pinned allocation.  Touches nothing but sysfs and the scheduler.
+    Returns what it found and did -- bench.py records it per rank as `config.numa`:
+        {"gpu": physical index, "node": NUMA node or None, "cpus": CPUs bound to (count), "bound": bool, "why": text when not bound}"""
+    getaffinity = getaffinity or (lambda: os.sched_getaffinity(0))
+    setaffinity = setaffinity or (lambda cpus: os.sched_setaffinity(0, cpus))
+    gpu = visible_device_index(local_index, env)
+    rec = {"gpu": gpu, "node": None, "cpus": None, "bound": False, "why": None}
+    nodes = gpu_numa_nodes(sysfs)
+    if not (0 <= gpu < len(nodes)):
+        rec["why"] = f"sysfs lists {len(nodes)} GPU(s)"
+        return rec
+    node = nodes[gpu]
+    rec["node"] = node
+    if node is None:
+        rec["why"] = "the GPU's numa_node is -1 (one node, or no affinity recorded)"
+        return rec
+    cpus = parse_cpulist(_read(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")) or "")
+    allowed = set(getaffinity())
+    mine = sorted(allowed.intersection(cpus))
+    if not mine:
+        rec["why"] = f"none of node {node}'s {len(cpus)} CPUs is in this process's affinity mask ({len(allowed)} CPUs)"
+        return rec
+    if set(mine) == allowed:
+        rec.update(cpus=len(mine), bound=True, why="already confined to the node")
+        return rec
+    try:
+        setaffinity(mine)
+    except OSError as e:
+        rec["why"] = f"sched_setaffinity refused: {e!r}"
+        return rec
+    rec.update(cpus=len(mine), bound=True)
+    return rec
+
+
 # ---- process launch -----------------------------------------------------------------------------------------------
 def free_port() -> int:
     s = socket.socket()

@@ -8,7 +8,7 @@
 // Differences, all stated at run time: there is no CPU compute path (without -g the engine uses GPU 0);
 // rows come out in input order (the reference's order is batch-completion order); csv, json, parquet/pqt and
 // ipc/feather writers (columnar.hpp); only .png slides decode here (no JPEG / OpenSlide in this image).
-// Every GPU extracts its index shard through nfx_extract_tile_streamed: the slide travels block by block (only the blocks the
+// Every GPU extracts its index shard through nfx_extract_tile_streamed_v2: the slide travels block by block (only the blocks the
 // shard's nuclei touch), chunks of whole reference batches are extracted while the next chunk's blocks are on their way --
 // no `n x 3 ps^2` patch workspace and no per-GPU copy of the whole slide, whatever the number of nuclei.
 #include <algorithm>
@@ -237,7 +237,7 @@ int main(int argc, char **argv)
         std::vector<float> rows((size_t)n * F), cen((size_t)n * 2);
         // The decoded slide and the row matrix are PINNED for the extraction (hipHostRegister: 3-20 ms per GB on this host, scripts/pin_probe.hip --
         // an order of magnitude cheaper than allocating pinned memory, 185 ms per GB): the slide's bands then travel asynchronously, beside the
-        // kernels, and the feature kernels write the rows straight into `rows` (nfx.h: nfx_extract_tile_streamed, rows_direct) instead of
+        // kernels, and the feature kernels write the rows straight into `rows` (nfx.h: nfx_extract_tile_streamed_v2, rows_direct) instead of
         // into a device buffer that is copied home chunk by chunk.  NFX_CLI_PIN=0 leaves both pageable (the round 1-4 behaviour).
         struct Registered { // unregistered before the vectors go
             void *p = nullptr;
@@ -282,7 +282,7 @@ int main(int argc, char **argv)
                 for (int64_t i = i0; i <= i1; ++i) off[(size_t)(i - i0)] = poly.ring_offsets[(size_t)i] - base;
                 nfx_stream_stats ss{};
                 ss.struct_size = sizeof ss;
-                const nfx_status st = nfx_extract_tile_streamed(ctxs[(size_t)r], sets.data(), n_sets, i1 - i0, off.back(), off.data(),
+                const nfx_status st = nfx_extract_tile_streamed_v2(ctxs[(size_t)r], sets.data(), n_sets, i1 - i0, off.back(), off.data(),
                                                                 poly.ring_xy.data() + 2 * (size_t)base, img.data.data(), img.H, img.W, args.patch_size,
                                                                 args.batch_size, 0, 0, 0, rows.data() + (size_t)i0 * F, cen.data() + 2 * (size_t)i0, &ss);
                 if (st != NFX_OK) { errs[(size_t)r] = nfx_last_error(ctxs[(size_t)r]); return; }

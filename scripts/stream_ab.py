@@ -73,7 +73,6 @@ def gen(n, ps):
 
 
 def run(with_torch, rows_mode, chunk, block, reps=3):
-    os.environ["NFX_STREAM_ROWS"] = rows_mode
     if with_torch:
         import torch
         torch.cuda.init()
@@ -83,6 +82,7 @@ def run(with_torch, rows_mode, chunk, block, reps=3):
     off, xy = np.load(os.path.join(SHM, "off.npy")), np.load(os.path.join(SHM, "xy.npy"))
     ref = np.load(os.path.join(SHM, "ref.npy"), mmap_mode="r")
     ctx = nfx.Context(0)
+    ctx.set_option("stream_rows_staged", 1 if rows_mode == "copy" else 0)
     h_tile = nfx.pinned_empty((3, T, T), np.uint8)
     src = np.load(os.path.join(SHM, "tile.npy"), mmap_mode="r")
     for r0 in range(0, T, 2048):
@@ -95,8 +95,8 @@ def run(with_torch, rows_mode, chunk, block, reps=3):
         t0 = time.perf_counter()
         _, _, st = ctx.extract_tile_streamed(sets, off, xy, h_tile, ps, chunk_nuclei=chunk, block=block, out=rows)
         times.append(1e3 * (time.perf_counter() - t0))
-        if os.environ.get("AB_NOCOPY_AFTER_FIRST") == "1":   # measurement only: later calls find the bands where the first call left them
-            os.environ["NFX_EXP_STREAM_NOCOPY"] = "1"
+        if os.environ.get("AB_NOCOPY_AFTER_FIRST") == "1":   # measurement only, needs a library built with -DNFX_EXPERIMENTS (NFX_LIB_PATH, scripts/build_variant.sh):
+            os.environ["NFX_EXP_STREAM_NOCOPY"] = "1"        # later calls find the bands where the first call left them
         time.sleep(0.2)
     same = bool(np.array_equal(rows.view(np.uint32), np.asarray(ref).view(np.uint32)))
     print(f"run torch={with_torch} rows={rows_mode} chunk={chunk or 100000} block={block or 2048}: streamed calls {', '.join(f'{t:.1f}' for t in times)} ms "

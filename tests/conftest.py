@@ -14,11 +14,16 @@ PKG_NAME = "nuclei-feature-extraction_amd"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # a checkout without the built artefacts (they are git-ignored) is built once, exactly as __graft_entry__.build() does;
-    # the product itself never builds or falls back at run time -- it fails loudly when libnfx.so is missing
+    # a checkout without the built artefacts (they are git-ignored), or with a libnfx.so that was built from OTHER sources than the ones
+    # next to it (nfx_build_stamp() against csrc/stamp.py, asked of a child process), is built once, exactly as __graft_entry__.build()
+    # does; the product itself never builds or falls back at run time -- it fails loudly when libnfx.so is missing
     pkg = os.path.join(ROOT, PKG_NAME)
     built = [os.path.join(pkg, "libnfx.so"), os.path.join(pkg, "bin", "nuclei-feature-extraction"), os.path.join(pkg, "bin", "filter-geojson")]
-    if not all(os.path.exists(b) for b in built) and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+    fresh = all(os.path.exists(b) for b in built)
+    if fresh:
+        import bench
+        fresh = bench.library_is_fresh()
+    if not fresh and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
         import __graft_entry__
         __graft_entry__.build()
 

@@ -18,7 +18,77 @@ def test_library_exports_every_declared_symbol(nfx):
     L = nfx.lib()
     for sym in declared:
         assert hasattr(L, sym), sym
-    assert L.nfx_version() == 400
+    assert L.nfx_version() == 500
+    # the streamed entry of ABI <= 0.4.0 stays exported under its old name (it returns NFX_ERR_UNSUPPORTED: an old binary gets an error,
+    # not a write past its shorter nfx_stream_stats)
+    old = L.nfx_extract_tile_streamed
+    old.argtypes = [C.c_void_p] * 2 + [C.c_int] + [C.c_int64] * 2 + [C.c_void_p] * 3 + [C.c_int64] * 2 + [C.c_int] * 3 + [C.c_int64] * 2 + [C.c_void_p] * 3
+    assert old(None, None, 0, 0, 0, None, None, None, 0, 0, 0, 0, 0, 0, 0, None, None, None) == 2
+    assert L.nfx_ctx_set_option(None, 0, 0) == 1
+
+
+def test_the_binary_is_bound_to_the_sources_it_was_built_from(nfx, tmp_path):
+    """nfx_build_stamp() -- compiled in by csrc/Makefile -- equals the hash of the sources on disk (csrc/stamp.py): a stale prebuilt
+    libnfx.so cannot pass for a build of HEAD's sources.  The same comparison guards bench.py (it refuses to print a line on a
+    mismatch): shown here on a copy of the sources with one byte changed."""
+    import shutil
+    import sys
+    assert nfx.build_stamp() == nfx.source_stamp(), "libnfx.so is stale: run `make -C nuclei-feature-extraction_amd/csrc`"
+    assert re.fullmatch(r"[0-9a-f]{16}", nfx.build_stamp())
+    src = os.path.join(ROOT, "nuclei-feature-extraction_amd", "csrc")
+    dst = tmp_path / "pkg" / "csrc"
+    dst.parent.mkdir()
+    shutil.copytree(src, dst, ignore=shutil.ignore_patterns("_obj", "gpurun_out", "__pycache__"))
+    (tmp_path / "include").mkdir()
+    shutil.copy(os.path.join(ROOT, "include", "nfx.h"), tmp_path / "include" / "nfx.h")
+    sys.path.insert(0, str(dst))
+    try:
+        import importlib
+        stamp = importlib.import_module("stamp")
+        assert stamp.source_stamp(str(dst)) == nfx.build_stamp()          # an identical copy hashes the same
+        with open(dst / "k_color.hip", "ab") as fh:
+            fh.write(b"\n// edited after the build\n")
+        stale = stamp.source_stamp(str(dst))
+        assert stale != nfx.build_stamp()
+    finally:
+        sys.path.remove(str(dst))
+        sys.modules.pop("stamp", None)
+    sys.path.insert(0, ROOT)
+    import bench
+    bench.require_fresh_library(nfx)                                       # this tree: fine
+    with pytest.raises(SystemExit) as e:
+        bench.require_fresh_library(nfx, source_stamp=stale)               # the edited sources against this binary: refused
+    assert "stale" in str(e.value)
+
+
+def test_the_library_reads_no_environment_but_the_documented_name(nfx):
+    """The default build is steered through the C ABI only (nfx_ctx_set_option): no tuning or measurement switch can reach a product
+    process through its environment.  Every NFX_* string in the binary is one the header documents."""
+    import subprocess
+    out = subprocess.check_output(["strings", "-a", nfx.LIB_PATH]).decode(errors="replace")
+    names = set(re.findall(r"NFX_[A-Z0-9_]+", out))
+    hdr = open(os.path.join(ROOT, "include", "nfx.h")).read()
+    assert "NFX_RCCL_PATH" in names
+    env_like = {n for n in names if n not in ("NFX_OPT_STREAM_ROWS_STAGED",)}   # (an option's name inside an error text)
+    assert env_like == {"NFX_RCCL_PATH"}, env_like
+    assert all(n in hdr for n in names)
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", nfx.LIB_PATH]).decode()
+    if "getenv" in syms:   # one call site: nfx_comm.cpp, NFX_RCCL_PATH
+        src = os.path.join(ROOT, "nuclei-feature-extraction_amd", "csrc")
+        hits = [(fn, ln.strip()) for fn in sorted(os.listdir(src)) if fn.endswith((".hip", ".cpp", ".h"))
+                for ln in open(os.path.join(src, fn)) if "getenv(" in ln]
+        outside = []
+        for fn in sorted({h[0] for h in hits}):
+            guarded, depth = False, 0
+            for ln in open(os.path.join(src, fn)):
+                t = ln.strip()
+                if t.startswith("#ifdef NFX_EXPERIMENTS"):
+                    guarded = True
+                elif guarded and t.startswith(("#else", "#endif")):
+                    guarded = False
+                if "getenv(" in ln and not guarded:
+                    outside.append((fn, t))
+        assert [o for o in outside if "NFX_RCCL_PATH" not in o[1]] == [], outside
 
 
 def test_stream_stats_mirror_matches_the_header(nfx, tmp_path):

@@ -166,3 +166,84 @@ def test_launch_ranks_relays_one_json_line(tmp_path):
     assert "noise from a library" in r.stderr and "noise" not in r.stdout
     r = subprocess.run([sys.executable, "-c", code, "3"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == ""
+
+
+# ---- NUMA placement of a rank (distributed.bind_rank_to_gpu_numa): a fake sysfs tree, no GPU, no real scheduler call -------------------
+def _fake_sysfs(tmp_path, gpu_nodes, node_cpus, cpu_topology_nodes=2, with_kfd=True):
+    """A two-socket host as sysfs shows it: KFD topology nodes 0..cpu_topology_nodes-1 are the sockets (simd_count 0), the GPUs follow in
+    HIP's enumeration order, GPU g is /sys/class/drm/renderD{128+g} and sits on NUMA node gpu_nodes[g]."""
+    sysfs = tmp_path / "sys"
+    if with_kfd:
+        top = sysfs / "class" / "kfd" / "kfd" / "topology" / "nodes"
+        for c in range(cpu_topology_nodes):
+            (top / str(c)).mkdir(parents=True)
+            (top / str(c) / "properties").write_text("cpu_cores_count 64\nsimd_count 0\ndrm_render_minor 0\n")
+        for g in range(len(gpu_nodes)):
+            d = top / str(cpu_topology_nodes + g)
+            d.mkdir(parents=True)
+            (d / "properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor {128 + g}\n")
+    for g, node in enumerate(gpu_nodes):
+        for name in (f"renderD{128 + g}", f"card{g}"):
+            dev = sysfs / "class" / "drm" / name / "device"
+            dev.mkdir(parents=True)
+            (dev / "numa_node").write_text(f"{node}\n")
+            (dev / "vendor").write_text("0x1002\n")
+    for node, cpus in node_cpus.items():
+        d = sysfs / "devices" / "system" / "node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus + "\n")
+    return str(sysfs)
+
+
+def test_a_rank_binds_to_the_cpus_of_its_gpus_numa_node(tmp_path):
+    D = importlib.import_module(PKG + ".distributed")
+    sysfs = _fake_sysfs(tmp_path, gpu_nodes=[0, 0, 0, 0, 1, 1, 1, 1], node_cpus={0: "0-63,128-191", 1: "64-127,192-255"})
+    assert D.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and D.parse_cpulist("") == []
+    assert D.gpu_numa_nodes(sysfs) == [0, 0, 0, 0, 1, 1, 1, 1]
+    for local_rank, node, first_cpu in ((0, 0, 0), (3, 0, 0), (4, 1, 64), (7, 1, 64)):
+        calls = []
+        rec = D.bind_rank_to_gpu_numa(local_rank, sysfs=sysfs, env={}, getaffinity=lambda: set(range(256)), setaffinity=calls.append)
+        assert rec["bound"] and rec["node"] == node and rec["gpu"] == local_rank and rec["cpus"] == 128 and rec["why"] is None
+        assert len(calls) == 1 and calls[0][0] == first_cpu and len(calls[0]) == 128
+        assert set(calls[0]) == set(D.parse_cpulist({0: "0-63,128-191", 1: "64-127,192-255"}[node]))
+    # a cgroup that grants only some CPUs: the intersection is what the rank is bound to; none of the node's CPUs allowed -> left alone, and said
+    calls = []
+    rec = D.bind_rank_to_gpu_numa(5, sysfs=sysfs, env={}, getaffinity=lambda: set(range(60, 80)), setaffinity=calls.append)
+    assert rec["bound"] and rec["cpus"] == 16 and calls == [list(range(64, 80))]
+    calls = []
+    rec = D.bind_rank_to_gpu_numa(5, sysfs=sysfs, env={}, getaffinity=lambda: set(range(0, 16)), setaffinity=calls.append)
+    assert not rec["bound"] and calls == [] and "affinity mask" in rec["why"]
+    # already confined to the node: nothing to do
+    calls = []
+    rec = D.bind_rank_to_gpu_numa(0, sysfs=sysfs, env={}, getaffinity=lambda: set(range(0, 8)), setaffinity=calls.append)
+    assert rec["bound"] and calls == [] and rec["cpus"] == 8
+    # the scheduler refuses: reported, not raised
+    def refuse(cpus):
+        raise PermissionError(1, "Operation not permitted")
+    rec = D.bind_rank_to_gpu_numa(0, sysfs=sysfs, env={}, getaffinity=lambda: set(range(256)), setaffinity=refuse)
+    assert not rec["bound"] and "refused" in rec["why"]
+
+
+def test_numa_binding_follows_visible_devices_and_survives_missing_sysfs(tmp_path):
+    D = importlib.import_module(PKG + ".distributed")
+    sysfs = _fake_sysfs(tmp_path, gpu_nodes=[0, 0, 1, 1], node_cpus={0: "0-7", 1: "8-15"})
+    # ROCR_VISIBLE_DEVICES=2,3: HIP device 0 is physical GPU 2 (node 1); HIP_VISIBLE_DEVICES indexes into ROCR's list
+    assert D.visible_device_index(0, {"ROCR_VISIBLE_DEVICES": "2,3"}) == 2
+    assert D.visible_device_index(1, {"ROCR_VISIBLE_DEVICES": "2,3", "HIP_VISIBLE_DEVICES": "1,0"}) == 2
+    assert D.visible_device_index(1, {"HIP_VISIBLE_DEVICES": "GPU-deadbeef"}) == 1
+    calls = []
+    rec = D.bind_rank_to_gpu_numa(0, sysfs=sysfs, env={"ROCR_VISIBLE_DEVICES": "2,3"}, getaffinity=lambda: set(range(16)), setaffinity=calls.append)
+    assert rec["gpu"] == 2 and rec["node"] == 1 and calls == [list(range(8, 16))]
+    # numa_node -1 (a one-node host, or a VM that records no affinity): nothing bound, reason given
+    one = _fake_sysfs(tmp_path / "one", gpu_nodes=[-1], node_cpus={0: "0-15"})
+    rec = D.bind_rank_to_gpu_numa(0, sysfs=one, env={}, getaffinity=lambda: set(range(16)), setaffinity=calls.append)
+    assert not rec["bound"] and rec["node"] is None and "-1" in rec["why"]
+    # no KFD topology: the DRM cards of vendor 0x1002, in card order
+    drm = _fake_sysfs(tmp_path / "drm", gpu_nodes=[1, 0], node_cpus={0: "0-7", 1: "8-15"}, with_kfd=False)
+    assert D.gpu_numa_nodes(drm) == [1, 0]
+    # no sysfs at all (this container): nothing bound, nothing raised
+    rec = D.bind_rank_to_gpu_numa(0, sysfs=str(tmp_path / "nowhere"), env={}, getaffinity=lambda: set(range(4)), setaffinity=calls.append)
+    assert not rec["bound"] and "0 GPU(s)" in rec["why"]
+    # and against the real /sys of wherever this runs, with the real scheduler call stubbed out: a dict, never an exception
+    rec = D.bind_rank_to_gpu_numa(0, setaffinity=lambda cpus: None)
+    assert set(rec) == {"gpu", "node", "cpus", "bound", "why"}

@@ -1,4 +1,4 @@
-"""BASELINE configs[4]: the slide streamed band by band (nfx_extract_tile_streamed) must give the rows of the resident-image call
+"""BASELINE configs[4]: the slide streamed band by band (nfx_extract_tile_streamed_v2) must give the rows of the resident-image call
 bit for bit -- same windows (utils.rs:159-191 / 97-122), same reference batches (the hue mean couples them, color.rs:144-155) --
 whatever the order of the nuclei, the band height, the chunk size and the number of bands the device cache holds."""
 import ctypes as C
@@ -61,11 +61,32 @@ def test_streamed_rows_equal_resident_rows(nfx, synth, ps, slide_order, block, c
             assert st["split_gather_passes"] > 0, "a batch wider than the cache must have been gathered in several passes"
             assert st["blocks_copied"] > st["blocks_total"]
     assert st["image_bytes_h2d"] >= st["blocks_copied"] * 3 * 64 * 64
-    # the slide loader's addressing (utils.rs:97-122)
+    assert st["rows_direct"] == 0, "a pageable row matrix is staged on the device and copied home"
+    # ROWS STRAIGHT HOME (the default whenever out_rows is pinned: the command line and the bench's top line): the feature kernels write
+    # into the caller's pinned matrix over the link -- evictions, multi-pass gathers, odd and huge patch sizes included; k_gabor's REFINED
+    # launch reads its shifts back from those rows
+    rows_p = nfx.pinned_empty(want.shape, np.float32)
+    rows_p[...] = np.float32(-7.0)
+    got_p, cen_p, st_p = ctx.extract_tile_streamed(sets, off, xy, image, ps, batch_size=B, block=block, chunk_nuclei=chunk,
+                                                   cache_bytes=cache_slots * slot_bytes, out=rows_p)
+    assert st_p["rows_direct"] == 1 and got_p is rows_p
+    assert np.array_equal(cen_p, wcen, equal_nan=True)
+    assert np.array_equal(rows_p.view(np.uint32), want.view(np.uint32)), np.argwhere(rows_p.view(np.uint32) != want.view(np.uint32))[:5]
+    # ... and the staged form on the same pinned matrix when the option asks for it (nfx_ctx_set_option, NFX_OPT_STREAM_ROWS_STAGED)
+    ctx.set_option("stream_rows_staged", 1)
+    rows_p[...] = np.float32(-7.0)
+    _, _, st_c = ctx.extract_tile_streamed(sets, off, xy, image, ps, batch_size=B, block=block, chunk_nuclei=chunk,
+                                           cache_bytes=cache_slots * slot_bytes, out=rows_p)
+    ctx.set_option("stream_rows_staged", 0)
+    assert st_c["rows_direct"] == 0
+    assert np.array_equal(rows_p.view(np.uint32), want.view(np.uint32))
+    # the slide loader's addressing (utils.rs:97-122), rows straight home again
     ctx.set_patch_addressing("slide")
     want_s, _ = ctx.extract_tile(sets, off, xy, img, ps, batch_size=B)
-    got_s, _, _ = ctx.extract_tile_streamed(sets, off, xy, image, ps, batch_size=B, block=block, chunk_nuclei=chunk, cache_bytes=cache_slots * slot_bytes)
+    got_s, _, st_s = ctx.extract_tile_streamed(sets, off, xy, image, ps, batch_size=B, block=block, chunk_nuclei=chunk, cache_bytes=cache_slots * slot_bytes,
+                                               out=rows_p)
     ctx.set_patch_addressing("image")
+    assert st_s["rows_direct"] == 1
     assert np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32))
     assert not np.array_equal(got_s.view(np.uint32), got.view(np.uint32)), "border nuclei see the two loaders differently"
     ctx.close()
@@ -109,34 +130,22 @@ def test_geometry_alone_and_empty_calls_need_no_image(nfx, synth):
     L = nfx.lib()
     s = (C.c_int * 1)(1)
     o = off.astype(np.uint32)
-    st_ = L.nfx_extract_tile_streamed(ctx._h, s, 1, 50, int(o[-1]), o.ctypes.data_as(C.c_void_p), xy.ctypes.data_as(C.c_void_p), None, 8, 8, ps, 100, 0, 0, 0,
-                                      rows.ctypes.data_as(C.c_void_p), None, None)
+    st_ = L.nfx_extract_tile_streamed_v2(ctx._h, s, 1, 50, int(o[-1]), o.ctypes.data_as(C.c_void_p), xy.ctypes.data_as(C.c_void_p), None, 8, 8, ps, 100, 0, 0, 0,
+                                         rows.ctypes.data_as(C.c_void_p), None, None)
     assert st_ == 1 and b"image" in L.nfx_last_error(ctx._h)
-    ctx.close()
-
-
-@pytest.mark.parametrize("ps,W", [(48, 701), (64, 700), (32, 703)])
-def test_streamed_windows_read_in_place_give_the_same_bits(nfx, synth, ps, W):
-    """NFX_STREAM_WINDOWS=1 (round 5: built, measured slower, off by default): with every band resident the pixel kernels read each window where
-    it lies in its band (PatchRef) and only the border nuclei are copied.  Same bytes, same arithmetic: the rows of the shipped form, bit for
-    bit -- random order (windows of one chunk in many bands), odd image widths (rows at every alignment), edge-case rings incl. a full-patch one."""
-    import os
-    n, H = 260, 520
-    off, xy, img = _scene(synth, ps, n, H, W, 29, False)
-    e_off, e_xy = par.edge_case_rings(ps)
-    off, xy = par.concat_rings((off, xy), (e_off, e_xy))
-    sets = [0, 1, 2, 3, 4]
-    ctx = nfx.Context(0)
-    image = nfx.pinned_empty(img.shape, np.uint8)
-    image[...] = img
-    rows = nfx.pinned_empty((len(off) - 1, 418), np.float32)
-    want, wcen, st0 = ctx.extract_tile_streamed(sets, off, xy, image, ps, batch_size=10, block=64, chunk_nuclei=50)
-    os.environ["NFX_STREAM_WINDOWS"] = "1"
-    try:
-        got, cen, st = ctx.extract_tile_streamed(sets, off, xy, image, ps, batch_size=10, block=64, chunk_nuclei=50, out=rows)
-    finally:
-        del os.environ["NFX_STREAM_WINDOWS"]
-    assert st["rows_direct"] == 1 and st["chunks"] > 3
-    assert np.array_equal(cen, wcen, equal_nan=True)
-    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.argwhere(got.view(np.uint32) != want.view(np.uint32))[:5]
+    # a struct_size that cannot be a caller's sizeof (an uninitialised first field) is refused before anything is written
+    for bad in (0, 8, 20, 8192):
+        stats = (C.c_int64 * 16)(bad, *([-1] * 15))
+        st_ = L.nfx_extract_tile_streamed_v2(ctx._h, s, 1, 50, int(o[-1]), o.ctypes.data_as(C.c_void_p), xy.ctypes.data_as(C.c_void_p), None, 8, 8, ps, 100, 0, 0, 0,
+                                             rows.ctypes.data_as(C.c_void_p), None, stats)
+        assert st_ == 1 and b"struct_size" in L.nfx_last_error(ctx._h) and list(stats)[1:] == [-1] * 15
+    # the entry of ABI <= 0.4.0 under its old name: an error, never a write into an old caller's shorter struct
+    old = L.nfx_extract_tile_streamed
+    old.argtypes = L.nfx_extract_tile_streamed_v2.argtypes
+    stats = (C.c_int64 * 16)(*([-1] * 16))
+    assert old(ctx._h, s, 1, 50, int(o[-1]), o.ctypes.data_as(C.c_void_p), xy.ctypes.data_as(C.c_void_p), None, 8, 8, ps, 100, 0, 0, 0,
+               rows.ctypes.data_as(C.c_void_p), None, stats) == 2
+    assert b"0.5.0" in L.nfx_last_error(ctx._h) and list(stats) == [-1] * 16
+    # options: unknown option / value
+    assert L.nfx_ctx_set_option(ctx._h, 99, 1) == 1 and L.nfx_ctx_set_option(ctx._h, 0, 2) == 1 and L.nfx_ctx_set_option(ctx._h, 0, 0) == 0
     ctx.close()

@@ -66,20 +66,12 @@ def test_slide_addressing_shifts_border_windows_instead_of_padding(synth, ctx, p
 
 @pytest.mark.parametrize("ps,W", [(48, 340), (32, 341), (64, 343), (16, 337), (47, 340)])
 def test_tile_entry_equals_packed_entry_and_oracle(nfx, synth, ctx, ps, W):
-    """The tile entry gathers every window into a packed patch (the shipped form); with NFX_TILE_WINDOWS=1 (round 5: built, measured slower, kept as an
-    option) the pixel kernels read every window WHERE IT LIES in the resident image (PatchRef) and only the border nuclei's zero-padded patches are
-    copied.  Same bytes, same arithmetic: both must give the packed entry's bits -- at every row alignment (odd image widths), with windows at the
-    border, and on the sizes that always copy (47)."""
-    import os
+    """The tile entry gathers every window into a packed patch and runs the packed entry's kernels on it: it must give the packed entry's
+    bits -- at every row alignment (odd image widths: the gather's 16-byte loads start anywhere), with windows at the border, and on the
+    sizes that take the gather's byte path (47)."""
     off, xy, img = _scene(synth, ps, n=90, W=W)
     sets = [0, 1, 2, 3, 4]
     rows_t, cen_t = ctx.extract_tile(sets, off, xy, img, ps, batch_size=32)
-    os.environ["NFX_TILE_WINDOWS"] = "1"
-    try:
-        rows_w, cen_w = ctx.extract_tile(sets, off, xy, img, ps, batch_size=32)
-    finally:
-        del os.environ["NFX_TILE_WINDOWS"]
-    assert np.array_equal(rows_w, rows_t, equal_nan=True) and np.array_equal(cen_w, cen_t)
     patches = ctx.gather_patches(cen_t, img, ps)
     rows_p, cen_p = ctx.extract(sets, off, xy, patches, ps, batch_size=32)
     assert np.array_equal(rows_t, rows_p, equal_nan=True) and np.array_equal(cen_t, cen_p)
