@@ -92,6 +92,10 @@ def require_fresh_library(nfx, source_stamp=None):
     """The binary that is about to be measured IS a build of the sources next to it, or no line is printed: nfx_build_stamp() (compiled
     in by csrc/Makefile) against the hash of the sources on disk.  Returns the stamp that goes into config.csrc_stamp."""
     built, src = nfx.build_stamp(), (source_stamp or csrc_stamp())
+    if os.environ.get("NFX_LIB_PATH"):
+        # an explicitly named alternative build (kernel A/Bs: scripts/lib_exp.py): measured as what it is -- its own stamp goes into the line,
+        # next to the path, and the counters committed for the tree's sources are not applied to it
+        return built + " (NFX_LIB_PATH=" + os.environ["NFX_LIB_PATH"] + ")"
     if built != src:
         sys.exit(f"bench.py: libnfx.so is stale -- built from sources with stamp {built}, the sources on disk hash to {src}; "
                  f"run `make -C {os.path.join(PKG, 'csrc')}` (no line is printed for a binary that is not a build of these sources)")

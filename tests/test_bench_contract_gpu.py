@@ -51,12 +51,20 @@ def test_bench_line(workload):
     assert rf["traffic_step"] is None and rf["lds"] is None
     # the libtorch-shaped baseline on top, the C/OpenMP port beside it
     ct, cp = d["cpu_baseline"], d["cpu_baseline_port"]
+    assert ct["is"] == "cpu_baseline_aten_twin" and d["cpu_baseline_aten_twin"]["value"] == ct["value"]     # both baselines under explicit names
+    assert set(d["speedup_vs_cpu"]) == {"cpu_baseline_aten_twin", "cpu_baseline_port"}
+    assert abs(d["speedup_vs_cpu"]["cpu_baseline_port"] - d["value"] / cp["value"]) <= 0.06 * d["speedup_vs_cpu"]["cpu_baseline_port"] + 0.06
     assert ct["kind"] == "aten-twin" and ct["value"] > 0 and ct["cores"] >= 1 and "extrapolated" in ct["sample"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cp, key
     assert cp["kind"] == "port" and cp["cores"] >= 1 and cp["value"] > 0
     assert cp["parity_spot_check_worst_scaled_err"] <= 1e-5
     c = d["config"]
+    # the binary measured is a build of the sources next to it (nfx_build_stamp() == csrc/stamp.py over the tree; bench.py refuses otherwise)
+    import importlib
+    assert c["csrc_stamp"] == importlib.import_module("nuclei-feature-extraction_amd").source_stamp()
+    # the NUMA prologue ran before the first GPU call and says what it found (a one-node box may have nothing to bind to)
+    assert len(c["numa"]) == 1 and set(c["numa"][0]) >= {"gpu", "node", "bound", "why"}
     if workload == "config5":
         assert c["inputs_mode"] == "streamed" and c["columns"] == 418 and c["patch_size"] == 64
         assert c["rows_equal_resident_tile_rows"] is True and c["rows_written_by_the_kernels_into_host_memory"] is True and c["image_pinned"] is True
@@ -91,9 +99,14 @@ def test_bench_launches_its_own_ranks_and_checks_the_rows():
     assert c["inputs_mode"] == "streamed" and c["rows_equal_resident_tile_rows"] is True
     assert "shared by the ranks" in c["rows_destination"] and c["every_ranks_rows_in_the_shared_matrix_equal_its_resident_rows"] is True
     assert c["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "degraded" not in d
+    assert [x["rank"] for x in c["numa"]] == [0, 1] and all("bound" in x for x in c["numa"])
     a = d["also"]
     w = a["weak_config3_rccl_gather"]
     assert w["n_gpus"] == 2 and w["gather_checksums_match"] is True and w["value"] > 0
+    # the row gather's facts sit on the TOP LEVEL of an N > 1 line (config.*), not only under `also`
+    assert c["rccl_gather_ms_per_step"] == w["ms_per_step"] and c["rccl_gather_checksums_match"] is True
+    assert c["rccl_gather_cost_ms_per_step"] == w["gather"]["cost_ms_per_step"] and c["rccl_gather_bytes_per_step"] == 4 * 800 * 254
+    assert (c["rccl_ranks_seen"] == 2) == (torch.cuda.device_count() >= 2)     # a rehearsal on one GPU runs its gathers over gloo: no RCCL probe
     s = a["strong_scaling_config4"]
     assert s["scaling"] == "strong" and s["shard_nuclei"] == [1900, 1800]           # 37 batches of 100: 19 + 18
     assert s["gather_checksums_match"] is True and s["gathered_equals_single_gpu"] is True
@@ -124,6 +137,7 @@ def test_one_rank_over_rccl_and_gather_none():
             BENCH, "--gpus", "1", "--workload", "config3", "--nuclei", "4000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
     d = _one_line(subprocess.run(base, capture_output=True, text=True, timeout=900, env=env))
     assert d["n_gpus"] == 1 and d["also"]["gather_checksums_match"] is True and d["also"]["weak_scaling_compute_only"]["value"] > 0
+    assert d["config"]["rccl_ranks_seen"] == 1      # the probe all-reduce of ones over the RCCL group
     assert d["config"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and d["config"]["rccl_failure"] is None and "degraded" not in d
     assert d["config"]["transport"] == "torch.distributed.gather"
     # the streamed top line under the same one-rank group: rows into the shared host matrix
