@@ -93,37 +93,6 @@ static __device__ __forceinline__ void hue_sincos(float r, float g, float b, flo
     cs = fmaf(sc, pc, -(ss * ps));
 }
 
-// The same for TWO pixels of BYTE-valued channels (0..255 as floats), every multiply / add / FMA a packed one (v_pk_mul_f32 / v_pk_add_f32 /
-// v_pk_fma_f32: two pixels per issue slot) and no branch: element for element the arithmetic of hue_sincos, so the same bits.  Byte values
-// make two tests redundant: max - min is 0 or >= 1, so the reciprocal is taken of max(d, 1) (identical for d >= 1; for d == 0 the
-// numerator g - b is 0 and f = 0 as before), and d == 0 implies max == r, so "red sector or gray" is just "max == r".
-typedef float f2 __attribute__((ext_vector_type(2)));
-static __device__ __forceinline__ void hue_sincos2_bytes(f2 r, f2 g, f2 b, f2 &sn, f2 &cs)
-{
-    const f2 mx = {fmaxf(r.x, fmaxf(g.x, b.x)), fmaxf(r.y, fmaxf(g.y, b.y))};
-    const f2 mn = {fminf(r.x, fminf(g.x, b.x)), fminf(r.y, fminf(g.y, b.y))};
-    const f2 d = mx - mn, gb = g - b, br = b - r, rg = r - g;
-    const bool isr0 = mx.x == r.x, isg0 = !isr0 && mx.x == g.x, isr1 = mx.y == r.y, isg1 = !isr1 && mx.y == g.y;
-    const f2 num = {isr0 ? gb.x : (isg0 ? br.x : rg.x), isr1 ? gb.y : (isg1 ? br.y : rg.y)};
-    const f2 rc = {__builtin_amdgcn_rcpf(fmaxf(d.x, 1.0f)), __builtin_amdgcn_rcpf(fmaxf(d.y, 1.0f))};
-    const f2 f = num * rc;
-    const f2 ss = {isr0 ? 0.0f : (isg0 ? 0.86602540378443865f : -0.86602540378443865f), isr1 ? 0.0f : (isg1 ? 0.86602540378443865f : -0.86602540378443865f)};
-    const f2 sc = {isr0 ? 1.0f : -0.5f, isr1 ? 1.0f : -0.5f};
-    auto splat = [](float v) { return (f2){v, v}; };
-    const f2 x = f * splat(1.0471975511965976f), x2 = x * x;
-    f2 ps = __builtin_elementwise_fma(x2, splat(2.7557319223985893e-06f), splat(-1.9841269841269841e-04f));
-    ps = __builtin_elementwise_fma(x2, ps, splat(8.3333333333333333e-03f));
-    ps = __builtin_elementwise_fma(x2, ps, splat(-1.6666666666666667e-01f));
-    ps = __builtin_elementwise_fma(x2 * x, ps, x);
-    f2 pc = __builtin_elementwise_fma(x2, splat(-2.7557319223985888e-07f), splat(2.4801587301587302e-05f));
-    pc = __builtin_elementwise_fma(x2, pc, splat(-1.3888888888888889e-03f));
-    pc = __builtin_elementwise_fma(x2, pc, splat(4.1666666666666664e-02f));
-    pc = __builtin_elementwise_fma(x2, pc, splat(-0.5f));
-    pc = __builtin_elementwise_fma(x2, pc, splat(1.0f));
-    sn = __builtin_elementwise_fma(ss, pc, sc * ps);
-    cs = __builtin_elementwise_fma(sc, pc, -(ss * ps));
-}
-
 // optical density log(max(x,1e-6))/log(1e-6), evaluated in f64 and rounded (f32 inputs only;
 // u8 inputs use the 256-entry table built on the host with the same formula)
 static __device__ __forceinline__ float od_f32(float x)
@@ -180,22 +149,12 @@ __global__ __launch_bounds__(256) void k_hue_batch(int64_t n, int ps, int batch_
 #pragma unroll
             for (int q = 0; q < VEC; ++q) { r[q] = Px<T>::ld(p, px + q); g[q] = Px<T>::ld(p, P + px + q); bl[q] = Px<T>::ld(p, 2 * P + px + q); }
         }
-        if constexpr (sizeof(T) == 1 && VEC == 4) { // byte values: two pixels per packed instruction, the same bits (hue_sincos2_bytes)
 #pragma unroll
-            for (int q = 0; q < VEC; q += 2) {
-                f2 sn, cs;
-                hue_sincos2_bytes((f2){r[q], r[q + 1]}, (f2){g[q], g[q + 1]}, (f2){bl[q], bl[q + 1]}, sn, cs); // color.rs:147-149
-                S[q] += (double)sn.x; C[q] += (double)cs.x;
-                S[q + 1] += (double)sn.y; C[q + 1] += (double)cs.y;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) {
-                float sn, cs;
-                hue_sincos(r[q], g[q], bl[q], sn, cs); // color.rs:147-149
-                S[q] += (double)sn;
-                C[q] += (double)cs;
-            }
+        for (int q = 0; q < VEC; ++q) {
+            float sn, cs;
+            hue_sincos(r[q], g[q], bl[q], sn, cs); // color.rs:147-149
+            S[q] += (double)sn;
+            C[q] += (double)cs;
         }
     }
 #pragma unroll
@@ -231,18 +190,8 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
                                                float *__restrict__ out, int F, int col0)
 {
     __shared__ float s_od[256];
-    // u8 pixels: everything that depends on ONE byte of a pixel comes out of one 16-byte LDS entry per channel and byte value --
-    // (od M[c][0], od M[c][1], od M[c][2], byte / 255) with od = the optical density of the byte (od_lut) and M = kHedFromRgb: the three
-    // products of hed_from_od's channel-c term, rounded as hed_from_od rounds them, and u8_unit(byte).  One ds_read_b128 replaces a
-    // conversion, an exact division by 255 (three operations), a table look-up and three multiplications -- same bits.
-    __shared__ float4 s_lut[sizeof(T) == 1 ? 3 * 256 : 1];
     extern __shared__ __attribute__((aligned(16))) uint8_t s_patch_all[]; // 4 waves x min(ps*ps, COLOR_LIST_CAP) list entries
     s_od[threadIdx.x] = od_lut[threadIdx.x];
-    if constexpr (sizeof(T) == 1) {
-        const float od = od_lut[threadIdx.x], un = u8_unit(threadIdx.x);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) s_lut[c * 256 + threadIdx.x] = make_float4(od * kHedFromRgb[c][0], od * kHedFromRgb[c][1], od * kHedFromRgb[c][2], un);
-    }
     __syncthreads();
     // XCD-aware block -> (batch, slot) map: every block of a batch has the same blockIdx % 8
     const int64_t v = blockIdx.x;
@@ -344,77 +293,14 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
         }
     };
     const int Kl = K < cap ? K : cap;
-    // u8 pixels: the two list entries a lane has in flight are one PAIR -- every multiply / add / FMA of the pair is a packed one
-    // (v_pk_*_f32: two pixels per issue slot), the conversion is branch-free (byte / 255 is 0 or >= 1/255, so the two "is it zero" tests
-    // of hsv_from_rgb become a clamp of the divisor: the same quotients, and 0 where the numerator is 0), the per-byte terms come from
-    // s_lut.  Element for element the arithmetic of pixel_channels; the sums about the pivot are kept per entry of the pair and joined
-    // at the end (entries e and e + 64 of a lane's walk no longer share an accumulator).
-    f2 gh1 = {0.0f, 0.0f}, gh2 = gh1, gs1 = gh1, gs2 = gh1;  // h, s: (entry e, entry e + 64)
-    f2 ge1[2] = {gh1, gh1}, ge2[2] = {gh1, gh1};              // (he, eo) of entry e | of entry e + 64
-    float gd1[2] = {0.0f, 0.0f}, gd2[2] = {0.0f, 0.0f};       // da of entry e | of entry e + 64
-    auto pixel_pair_u8 = [&](bool on1, unsigned a0, unsigned a1, unsigned a2, unsigned c0, unsigned c1, unsigned c2, double sv0, double cv0, double sv1, double cv1) {
-        const float4 A0 = s_lut[a0], A1 = s_lut[256 + a1], A2 = s_lut[512 + a2], B0 = s_lut[c0], B1 = s_lut[256 + c1], B2 = s_lut[512 + c2];
-        const f2 r = {A0.w, B0.w}, g = {A1.w, B1.w}, b = {A2.w, B2.w}; // utils.rs:172
-        // hsv_from_rgb, both pixels
-        const f2 mx = {fmaxf(r.x, fmaxf(g.x, b.x)), fmaxf(r.y, fmaxf(g.y, b.y))};
-        const f2 mn = {fminf(r.x, fminf(g.x, b.x)), fminf(r.y, fminf(g.y, b.y))};
-        const f2 d = mx - mn, gb = g - b, br = b - r, rg = r - g;
-        const bool isr0 = mx.x == r.x, isg0 = !isr0 && mx.x == g.x, isr1 = mx.y == r.y, isg1 = !isr1 && mx.y == g.y;
-        const f2 num = {isr0 ? gb.x : (isg0 ? br.x : rg.x), isr1 ? gb.y : (isg1 ? br.y : rg.y)};
-        const f2 off = {isr0 ? 0.0f : (isg0 ? 2.0f : 4.0f), isr1 ? 0.0f : (isg1 ? 2.0f : 4.0f)};
-        const f2 rcd = {__builtin_amdgcn_rcpf(fmaxf(d.x, 1.0e-3f)), __builtin_amdgcn_rcpf(fmaxf(d.y, 1.0e-3f))};
-        const f2 rcm = {__builtin_amdgcn_rcpf(fmaxf(mx.x, 1.0e-3f)), __builtin_amdgcn_rcpf(fmaxf(mx.y, 1.0e-3f))};
-        f2 hh = num * rcd + off;                 // red sector: off = 0 (x + 0 = x); gray: num = 0
-        const f2 hh6 = hh + (f2){6.0f, 6.0f};
-        hh = (f2){hh.x < 0.0f ? hh6.x : hh.x, hh.y < 0.0f ? hh6.y : hh.y}; // only the red sector can be negative
-        const f2 h = hh * (f2){60.0f, 60.0f};
-        const f2 sat = d * rcm;                   // max == 0 -> d == 0 -> 0
-        ss += sv0; cc += cv0;
-        ss += on1 ? sv1 : 0.0;
-        cc += on1 ? cv1 : 0.0;
-        {
-            const unsigned m0 = a0 > a1 ? (a0 > a2 ? a0 : a2) : (a1 > a2 ? a1 : a2), m1 = c0 > c1 ? (c0 > c2 ? c0 : c2) : (c1 > c2 ? c1 : c2);
-            const unsigned keep = on1 ? 0xFFFFFFFFu : 0u;
-            const unsigned u0[4] = {a0, a1, a2, m0}, u1[4] = {c0 & keep, c1 & keep, c2 & keep, m1 & keep};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { iu[c] += u0[c] + u1[c]; iu2[c] += u0[c] * u0[c] + u1[c] * u1[c]; }
-        }
-        {   // h, s: the pair's two pixels side by side
-            f2 dh = h - (f2){pv[3], pv[3]}, ds = sat - (f2){pv[4], pv[4]};
-            dh.y = on1 ? dh.y : 0.0f;
-            ds.y = on1 ? ds.y : 0.0f;
-            gh1 += dh; gh2 = __builtin_elementwise_fma(dh, dh, gh2);
-            gs1 += ds; gs2 = __builtin_elementwise_fma(ds, ds, gs2);
-        }
-        // hed_from_od per pixel: ((o0 M0k) + (o1 M1k)) + (o2 M2k), clamped at 0 -- (he, eo) are the entry's .xy as they come out of the
-        // LDS (one packed add per term), da its .z
-        auto stains = [&](const float4 &L0, const float4 &L1, const float4 &L2, bool on, int q) {
-            f2 he = (f2){L0.x, L0.y} + (f2){L1.x, L1.y};
-            float da = L0.z + L1.z;
-            he = he + (f2){L2.x, L2.y};
-            da = da + L2.z;
-            he = (f2){he.x > 0.0f ? he.x : 0.0f, he.y > 0.0f ? he.y : 0.0f};
-            da = da > 0.0f ? da : 0.0f;
-            f2 de = he - (f2){pv[6], pv[7]};
-            float dd = da - pv[8];
-            if (!on) { de = (f2){0.0f, 0.0f}; dd = 0.0f; }
-            ge1[q] += de; ge2[q] = __builtin_elementwise_fma(de, de, ge2[q]);
-            gd1[q] += dd; gd2[q] = fmaf(dd, dd, gd2[q]);
-        };
-        stains(A0, A1, A2, true, 0);
-        stains(B0, B1, B2, on1, 1);
-    };
     for (int e = lane; e < Kl; e += 128) { // two entries per lane: ten loads in flight before the first use
         const bool on1 = e + 64 < Kl;
         const int p0 = s_list[e], p1 = on1 ? s_list[e + 64] : p0;
         unsigned a0 = 0, a1 = 0, a2 = 0, c0 = 0, c1 = 0, c2 = 0;
         float fa0 = 0, fa1 = 0, fa2 = 0, fc0 = 0, fc1 = 0, fc2 = 0;
-        if constexpr (sizeof(T) == 1) {
+        if (sizeof(T) == 1) {
             ld3(p0, a0, a1, a2);
             ld3(p1, c0, c1, c2);
-            const double sv0 = S[p0], cv0 = Cc[p0], sv1 = S[p1], cv1 = Cc[p1];
-            pixel_pair_u8(on1, a0, a1, a2, c0, c1, c2, sv0, cv0, sv1, cv1);
-            continue;
         } else {
             fa0 = Px<T>::ld(pp, p0); fa1 = Px<T>::ld(pp, P + p0); fa2 = Px<T>::ld(pp, 2 * P + p0);
             fc0 = Px<T>::ld(pp, p1); fc1 = Px<T>::ld(pp, P + p1); fc2 = Px<T>::ld(pp, 2 * P + p1);
@@ -422,13 +308,6 @@ __global__ __launch_bounds__(256) void k_color(int64_t n, int ps, int batch_size
         const double sv0 = S[p0], cv0 = Cc[p0], sv1 = S[p1], cv1 = Cc[p1];
         pixel(p0, true, a0, a1, a2, fa0, fa1, fa2, sv0, cv0);
         pixel(p1, on1, c0, c1, c2, fc0, fc1, fc2, sv1, cv1);
-    }
-    if constexpr (sizeof(T) == 1) { // the pair's halves join the accumulators the tail (and the finish) use
-        f1[3] = gh1.x + gh1.y; f2s[3] = gh2.x + gh2.y;
-        f1[4] = gs1.x + gs1.y; f2s[4] = gs2.x + gs2.y;
-        f1[6] = ge1[0].x + ge1[1].x; f2s[6] = ge2[0].x + ge2[1].x;
-        f1[7] = ge1[0].y + ge1[1].y; f2s[7] = ge2[0].y + ge2[1].y;
-        f1[8] = gd1[0] + gd1[1]; f2s[8] = gd2[0] + gd2[1];
     }
     if (K > cap) { // tail: pixels that found no room in the list, row by row
         for (int r = 0; r < ps; ++r) {
