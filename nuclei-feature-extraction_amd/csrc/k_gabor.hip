@@ -180,18 +180,22 @@ static __device__ __forceinline__ void taps2_fold2(const f2 (&xp)[XP], const flo
     for (int o = 0; o < TS; ++o) { acc0[o] = (f2){0.0f, 0.0f}; acc1[o] = (f2){0.0f, 0.0f}; }
 #pragma unroll
     for (int j = 0; j < HALF; ++j) {
+        // a tap's TS folds first, then its 2 TS FMAs: a fold feeds the two FMAs right behind it otherwise, and every one of them waits out the
+        // packed add's latency (two waves per SIMD hide little of it)
+        f2 sd[TS];
 #pragma unroll
         for (int o = 0; o < TS; ++o) {
-            constexpr int dummy = 0; (void)dummy;
-            const int ia = o + j, ib = o + GB_SIZE - 1 - j; // compile-time after unrolling
-            f2 sd;
-            // the halves are compile-time constants only through the unrolled indices: dispatch on their parities
-            if ((ia & 1) == 0 && (ib & 1) == 0) sd = fold_sum_diff<0, 0>(xp[ia >> 1], xp[ib >> 1]);
-            else if ((ia & 1) == 0) sd = fold_sum_diff<0, 1>(xp[ia >> 1], xp[ib >> 1]);
-            else if ((ib & 1) == 0) sd = fold_sum_diff<1, 0>(xp[ia >> 1], xp[ib >> 1]);
-            else sd = fold_sum_diff<1, 1>(xp[ia >> 1], xp[ib >> 1]);
-            acc0[o] = __builtin_elementwise_fma(wa[j], sd, acc0[o]);
-            acc1[o] = __builtin_elementwise_fma(wb[j], sd, acc1[o]);
+            const int ia = o + j, ib = o + GB_SIZE - 1 - j; // compile-time after unrolling: dispatch on the parities (which half of which pair)
+            if ((ia & 1) == 0 && (ib & 1) == 0) sd[o] = fold_sum_diff<0, 0>(xp[ia >> 1], xp[ib >> 1]);
+            else if ((ia & 1) == 0) sd[o] = fold_sum_diff<0, 1>(xp[ia >> 1], xp[ib >> 1]);
+            else if ((ib & 1) == 0) sd[o] = fold_sum_diff<1, 0>(xp[ia >> 1], xp[ib >> 1]);
+            else sd[o] = fold_sum_diff<1, 1>(xp[ia >> 1], xp[ib >> 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int o = 0; o < TS; ++o) {
+            acc0[o] = __builtin_elementwise_fma(wa[j], sd[o], acc0[o]);
+            acc1[o] = __builtin_elementwise_fma(wb[j], sd[o], acc1[o]);
         }
         // the folds are volatile and the accumulators are pinned at the end of every tap: left alone, all 15 TS folded pairs are computed up
         // front and kept alive -- in scratch memory -- for the FMAs (as column_passes_env found in round 4)
