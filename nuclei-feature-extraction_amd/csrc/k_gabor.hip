@@ -53,14 +53,6 @@ static_assert(GB_WAVES == 4, "four strips of TSR <= 16 columns tile the plane's 
 #ifndef NFX_GB_ENV_FUSED
 #define NFX_GB_ENV_FUSED 1
 #endif
-// Two diagonal groups share one folded row pass (taps2_fold2); 0 = every group its own row pass.  Strips wider than NFX_GB_FOLD2_MAX_TSR
-// columns keep the separate passes (register budget: two accumulator sets and the held plane beside the window)
-#ifndef NFX_GB_FOLD2
-#define NFX_GB_FOLD2 1
-#endif
-#ifndef NFX_GB_FOLD2_MAX_TSR
-#define NFX_GB_FOLD2_MAX_TSR 16
-#endif
 #ifndef NFX_GB_ENV_MAX_CT
 #define NFX_GB_ENV_MAX_CT 16 // strips of more rows than this take the generic passes (register budget: 6 CT accumulators beside the window)
 #endif
@@ -144,65 +136,6 @@ static __device__ __forceinline__ void taps2(const X (&x)[XN], const float *__re
             if constexpr (sizeof(X) == sizeof(float)) xv = (f2){x[o + j], x[o + j]};
             else xv = x[o + j];
             acc[o] = __builtin_elementwise_fma(wr[j], xv, acc[o]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// (x[a] + x[b], x[a] - x[b]) in ONE packed add: x[a] is half HA of the register pair pa, x[b] half HB of pb; both result halves take the
-// same source halves (op_sel = op_sel_hi), the high half negates its second operand.  (volatile: see taps2_fold2)
-template <int HA, int HB>
-static __device__ __forceinline__ f2 fold_sum_diff(f2 pa, f2 pb)
-{
-    f2 r;
-    if constexpr (HA == 0 && HB == 0) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(pa), "v"(pb));
-    else if constexpr (HA == 0 && HB == 1) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(pa), "v"(pb));
-    else if constexpr (HA == 1 && HB == 0) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(pa), "v"(pb));
-    else asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]" : "=v"(r) : "v"(pa), "v"(pb));
-    return r;
-}
-
-// ROW PASS OF TWO DIAGONAL GROUPS AT ONCE.  A diagonal group's row kernels (G cos Ax, G sin Ax) are even / odd about the middle of the
-// 30-tap grid (t_{29-j} = -t_j; build_tables makes the f32 taps mirror images by construction), so taps j and 29 - j share a
-// multiplication once the window is folded: (a, b)[o] = sum_{j<15} (ra, rb)[j] * (x[o+j] + x[o+29-j], x[o+j] - x[o+29-j]).  The fold is
-// one packed add per (o, j) and does not depend on the frequency: two groups share it -- 15 + 2 x 15 packed instructions per output
-// where two separate passes take 2 x 30.  The second group's plane stays in REGISTERS (`held`) while the first one's column pass
-// runs out of the LDS plane, and is put down afterwards: no second plane in LDS.  Tap-major order pinned as in taps2.
-template <int TS, int XP>
-static __device__ __forceinline__ void taps2_fold2(const f2 (&xp)[XP], const float *__restrict__ w0, const float *__restrict__ w1, f2 (&acc0)[TS], f2 (&acc1)[TS])
-{
-    static_assert(2 * XP >= TS + GB_SIZE - 1, "window");
-    constexpr int HALF = GB_SIZE / 2;
-    f2 wa[HALF], wb[HALF];
-#pragma unroll
-    for (int j = 0; j < HALF; ++j) { wa[j] = (f2){w0[2 * j], w0[2 * j + 1]}; wb[j] = (f2){w1[2 * j], w1[2 * j + 1]}; }
-#pragma unroll
-    for (int o = 0; o < TS; ++o) { acc0[o] = (f2){0.0f, 0.0f}; acc1[o] = (f2){0.0f, 0.0f}; }
-#pragma unroll
-    for (int j = 0; j < HALF; ++j) {
-        // a tap's TS folds first, then its 2 TS FMAs: a fold feeds the two FMAs right behind it otherwise, and every one of them waits out the
-        // packed add's latency (two waves per SIMD hide little of it)
-        f2 sd[TS];
-#pragma unroll
-        for (int o = 0; o < TS; ++o) {
-            const int ia = o + j, ib = o + GB_SIZE - 1 - j; // compile-time after unrolling: dispatch on the parities (which half of which pair)
-            if ((ia & 1) == 0 && (ib & 1) == 0) sd[o] = fold_sum_diff<0, 0>(xp[ia >> 1], xp[ib >> 1]);
-            else if ((ia & 1) == 0) sd[o] = fold_sum_diff<0, 1>(xp[ia >> 1], xp[ib >> 1]);
-            else if ((ib & 1) == 0) sd[o] = fold_sum_diff<1, 0>(xp[ia >> 1], xp[ib >> 1]);
-            else sd[o] = fold_sum_diff<1, 1>(xp[ia >> 1], xp[ib >> 1]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int o = 0; o < TS; ++o) {
-            acc0[o] = __builtin_elementwise_fma(wa[j], sd[o], acc0[o]);
-            acc1[o] = __builtin_elementwise_fma(wb[j], sd[o], acc1[o]);
-        }
-        // the folds are volatile and the accumulators are pinned at the end of every tap: left alone, all 15 TS folded pairs are computed up
-        // front and kept alive -- in scratch memory -- for the FMAs (as column_passes_env found in round 4)
-#pragma unroll
-        for (int o = 0; o < TS; ++o) {
-            asm volatile("" : "+v"(acc0[o]));
-            asm volatile("" : "+v"(acc1[o]));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -308,18 +241,12 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
         if (!item) mbits = 0u;
     }
 
-    f2 held[GB_MAX_TSR];    // the plane of the SECOND group of a fused pair of diagonal groups (taps2_fold2), in registers until the first one's column pass is done
-    bool have_held = false; // wave-uniform
 #pragma unroll 1
     for (int g = g_begin; g < g_end; ++g) {
         const float *__restrict__ img = tab->groups[g].image; // wave-uniform: the taps arrive through the scalar cache
         // ---- row pass ---------------------------------------------------------------------------------------------
-        const int env_flag = __float_as_int(img[GB_META + 1]);       // 0: a genuine kernel pair; 1: envelope group whose column taps are mirror-symmetric; 2: envelope group, taps not bit-symmetric; 4: diagonal group whose row taps are mirror images (even, odd)
-        const bool envelope = env_flag == 1 || env_flag == 2; // both row kernels are the bare envelope (90 / 0 degree groups)
-        // this group's plane was made by the fused row pass of the group before it | this group and the next are both foldable: one row pass for the two
-        const bool consume = have_held;
-        const bool fuse2 = NFX_GB_FOLD2 && !consume && !tr && env_flag == 4 && g + 1 < g_end && __float_as_int(tab->groups[g + 1].image[GB_META + 1]) == 4 && tsr <= NFX_GB_FOLD2_MAX_TSR; // wave-uniform
-        have_held = fuse2;
+        const int env_flag = __float_as_int(img[GB_META + 1]);       // 0: a genuine kernel pair; 1: envelope group whose column taps are mirror-symmetric; 2: envelope group, taps not bit-symmetric
+        const bool envelope = env_flag != 0; // both row kernels are the bare envelope (90 / 0 degree groups)
         const int n_pass = __float_as_int(img[GB_META]);
         const bool fused = NFX_GB_ENV_FUSED && env_flag == 1 && n_pass == GB_MAX_PASSES && ct <= NFX_GB_ENV_MAX_CT; // wave-uniform
         auto load_window = [&](auto win_tag, float (&x)[decltype(win_tag)::value]) {
@@ -381,59 +308,8 @@ static __device__ __forceinline__ void gabor_nucleus(const GaborShared &S, const
                 }
             }
         };
-        auto row_pass_fold2 = [&](auto ts_tag) { // (view 0 only: the diagonal groups are plain groups)
-            constexpr int TS = decltype(ts_tag)::value, WIN = TS + GB_SIZE - 1, XP = (WIN + 1) / 2;
-            f2 xp[XP];
-#pragma unroll
-            for (int q = 0; q < XP; ++q) xp[q] = (f2){src[2 * q], src[2 * q + 1]}; // (an odd window's last half lies inside the row's apron: read, not used)
-            f2 acc0[TS], acc1[TS];
-            taps2_fold2<TS>(xp, img, tab->groups[g + 1].image, acc0, acc1);
-#pragma unroll
-            for (int q = 0; q < TS; ++q) { du[q] = acc0[q]; held[q] = acc1[q]; }
-        };
-        auto put_held = [&](auto ts_tag) {
-            constexpr int TS = decltype(ts_tag)::value;
-#pragma unroll
-            for (int q = 0; q < TS; ++q) du[q] = held[q];
-        };
         if (!(dbg & 1)) {
-            if (consume) {
-                switch (tsr) {
-                NFX_GB_CASE(3, NFX_GB_FOLD2_MAX_TSR, put_held)
-                NFX_GB_CASE(4, NFX_GB_FOLD2_MAX_TSR, put_held)
-                NFX_GB_CASE(5, NFX_GB_FOLD2_MAX_TSR, put_held)
-                NFX_GB_CASE(6, NFX_GB_FOLD2_MAX_TSR, put_held)
-                NFX_GB_CASE(7, NFX_GB_FOLD2_MAX_TSR, put_held)
-                NFX_GB_CASE(8, NFX_GB_FOLD2_MAX_TSR, put_held)
-                NFX_GB_CASE(9, NFX_GB_FOLD2_MAX_TSR, put_held)
-                NFX_GB_CASE(10, NFX_GB_FOLD2_MAX_TSR, put_held)
-                NFX_GB_CASE(11, NFX_GB_FOLD2_MAX_TSR, put_held)
-                NFX_GB_CASE(12, NFX_GB_FOLD2_MAX_TSR, put_held)
-                NFX_GB_CASE(13, NFX_GB_FOLD2_MAX_TSR, put_held)
-                NFX_GB_CASE(14, NFX_GB_FOLD2_MAX_TSR, put_held)
-                NFX_GB_CASE(15, NFX_GB_FOLD2_MAX_TSR, put_held)
-                NFX_GB_CASE(16, NFX_GB_FOLD2_MAX_TSR, put_held)
-                default: break;
-                }
-            } else if (fuse2) {
-                switch (tsr) {
-                NFX_GB_CASE(3, NFX_GB_FOLD2_MAX_TSR, row_pass_fold2)
-                NFX_GB_CASE(4, NFX_GB_FOLD2_MAX_TSR, row_pass_fold2)
-                NFX_GB_CASE(5, NFX_GB_FOLD2_MAX_TSR, row_pass_fold2)
-                NFX_GB_CASE(6, NFX_GB_FOLD2_MAX_TSR, row_pass_fold2)
-                NFX_GB_CASE(7, NFX_GB_FOLD2_MAX_TSR, row_pass_fold2)
-                NFX_GB_CASE(8, NFX_GB_FOLD2_MAX_TSR, row_pass_fold2)
-                NFX_GB_CASE(9, NFX_GB_FOLD2_MAX_TSR, row_pass_fold2)
-                NFX_GB_CASE(10, NFX_GB_FOLD2_MAX_TSR, row_pass_fold2)
-                NFX_GB_CASE(11, NFX_GB_FOLD2_MAX_TSR, row_pass_fold2)
-                NFX_GB_CASE(12, NFX_GB_FOLD2_MAX_TSR, row_pass_fold2)
-                NFX_GB_CASE(13, NFX_GB_FOLD2_MAX_TSR, row_pass_fold2)
-                NFX_GB_CASE(14, NFX_GB_FOLD2_MAX_TSR, row_pass_fold2)
-                NFX_GB_CASE(15, NFX_GB_FOLD2_MAX_TSR, row_pass_fold2)
-                NFX_GB_CASE(16, NFX_GB_FOLD2_MAX_TSR, row_pass_fold2)
-                default: break;
-                }
-            } else if (envelope) {
+            if (envelope) {
                 switch (tsr) {
                 NFX_GB_CASE(3, GB_MAX_TSR, row_pass_envelope)
                 NFX_GB_CASE(4, GB_MAX_TSR, row_pass_envelope)
@@ -1049,17 +925,6 @@ static void build_tables(GaborTables &T)
         for (int j = 0; j < GB_SIZE; ++j) {
             set_row(*G, j, env(tk(j)) * cos(Aa * tk(j)), env(tk(j)) * sin(Aa * tk(j)));
             set_col(*G, 0, j, env(tk(j)) * cos(u.B * tk(j)), env(tk(j)) * sin(u.B * tk(j)));
-        }
-        // the row kernels are even / odd about the middle of the grid (t_{29-j} = -t_j); the f32 taps are MADE mirror images (tk(j) and
-        // tk(29 - j) are rounded independently, so a last bit may differ): the folded row pass (taps2_fold2) multiplies taps j and 29 - j by
-        // ONE weight.  Flag 4 tells the kernel; the generic row pass reads the same, symmetric, taps
-        for (int j = 0; j < GB_SIZE / 2; ++j) {
-            G->image[2 * (GB_SIZE - 1 - j)] = G->image[2 * j];
-            G->image[2 * (GB_SIZE - 1 - j) + 1] = -G->image[2 * j + 1];
-        }
-        {
-            const int flag = 4;
-            memcpy(&G->image[GB_META + 1], &flag, sizeof(int));
         }
         G->n_pass = 1; G->combine[0] = 1;
         G->filt[0][0] = plus ? plus->slot : -1;
