@@ -73,19 +73,25 @@ def csrc_stamp():
     return mod.source_stamp()
 
 
-def library_is_fresh():
-    """Whether the prebuilt libnfx.so was built from the sources on disk -- asked of a CHILD process, so that a stale library is never
-    mapped into this one (it could not be unloaded before the rebuilt one is loaded)."""
-    import subprocess
-    lib = os.path.join(ROOT, PKG, "libnfx.so")
-    if not os.path.exists(lib):
-        return False
-    code = "import ctypes,sys; L=ctypes.CDLL(sys.argv[1]); L.nfx_build_stamp.restype=ctypes.c_char_p; print(L.nfx_build_stamp().decode())"
+def library_stamp_on_disk(path=None):
+    """The stamp compiled into a libnfx.so, read out of the FILE (the marker string "NFX_BUILD_STAMP=<stamp>", csrc/nfx_stamp.cpp): no child
+    process, and a stale library is never mapped into this one (it could not be unloaded before the rebuilt one is loaded)."""
+    path = path or os.path.join(ROOT, PKG, "libnfx.so")
     try:
-        out = subprocess.run([sys.executable, "-c", code, lib], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
-        return out.returncode == 0 and out.stdout.strip() == csrc_stamp()
-    except Exception:
-        return False
+        with open(path, "rb") as fh:
+            blob = fh.read()
+    except OSError:
+        return None
+    at = blob.find(b"NFX_BUILD_STAMP=")
+    if at < 0:
+        return None
+    end = blob.find(b"\0", at)
+    return blob[at + 16:end].decode(errors="replace") if end > at else None
+
+
+def library_is_fresh():
+    """Whether the prebuilt libnfx.so was built from the sources on disk."""
+    return library_stamp_on_disk() == csrc_stamp()
 
 
 def require_fresh_library(nfx, source_stamp=None):

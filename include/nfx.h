@@ -102,7 +102,8 @@ int nfx_version(void);
 /* sha-256 (first 16 hex digits) of the library's sources -- csrc's *.hip, *.cpp, *.h and this header, in name order -- as
    csrc/Makefile computed it when the library was built (scripts/csrc_stamp.py is that computation).  bench.py prints it as
    config.csrc_stamp and refuses to run when it differs from the hash of the sources on disk: a stale prebuilt library cannot carry a
-   fresh stamp.  "unstamped" when the library was built without the Makefile. */
+   fresh stamp.  "unstamped" when the library was built without the Makefile.  The binary also holds the string
+   "NFX_BUILD_STAMP=<stamp>", so that a tool can read the stamp out of the file without loading it (not an environment variable). */
 const char *nfx_build_stamp(void);
 int nfx_feature_set_count(void);
 /* FeatureSet::name(): "geometry","color","GLCM","GLRLM","gabor filter"; NULL if out of range */
