@@ -55,11 +55,11 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles, 2.4 GHz
 VALU_ISSUE_PEAK = 256 * 4 * 0.5 * 2.4e9   # wave-instructions per second (nominal)
-# what back-to-back independent plain FMAs really reach on this chip (scripts/valu_probe.hip, DESIGN.md §6: 6.7e11 of the nominal
+# what back-to-back independent plain FMAs really reach on this chip (scripts/valu_probe.hip, profiles/NOTEBOOK_r1-r5.md §6: 6.7e11 of the nominal
 # 1.23e12, i.e. ~4 cycles per wave64 instruction and SIMD): the second basis `issue.frac_of_probe` is quoted against
 VALU_ISSUE_PROBE = 6.7e11
 LDS_CU_CYCLES_PEAK = 256 * 2.4e9          # CU-cycles per second: one LDS pipe per CU
-# which unit limits a kernel when its counters are at hand (DESIGN.md §3/§8); everything else on this path is VALU-issue-bound
+# which unit limits a kernel when its counters are at hand (DESIGN.md §3); everything else on this path is VALU-issue-bound
 LDS_BOUND_KERNELS = ("k_glcm",)
 PMC_NUCLEI = {"config2": 100_000, "config3": 1_000_000, "config5": 1_250_000}   # what scripts/profile_round.sh profiles (one launch per step)
 
