@@ -208,3 +208,44 @@ def test_one_hip_runtime_per_process_and_the_bad_order_is_refused():
     free = pre + "nfx = importlib.import_module('nuclei-feature-extraction_amd'); nfx.lib(); print(len(nfx.hip_runtimes_mapped()), 'torch' in sys.modules)"
     r = subprocess.run([sys.executable, "-c", free], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.split() == ["1", "False"], r.stdout + r.stderr[-500:]
+
+
+def test_a_plain_c_host_links_the_library_and_rebuilds_the_reference_frame_header(nfx, tmp_path):
+    """The boundary is a C ABI: a host written in C -- what a Rust `extern "C"` block compiles down to -- includes nfx.h,
+    links libnfx.so and rebuilds the reference's frame header (args.rs:18-73 expansion, column names in order, the centroid key) without a GPU;
+    a context on a box without one is an error status, not a crash."""
+    import subprocess
+    src = tmp_path / "host.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "nfx.h"
+int main(void) {
+    const char *names[] = {"geometry", "texture"};
+    int sets[8];
+    int n = nfx_parse_feature_sets(names, 2, sets, 8);
+    printf("version %d stamp %s sets %d:", nfx_version(), nfx_build_stamp(), n);
+    int cols = 0;
+    for (int i = 0; i < n; ++i) { printf(" %s", nfx_feature_set_name(sets[i])); cols += nfx_feature_set_num_columns(sets[i]); }
+    char buf[128];
+    nfx_feature_set_column_name(sets[1], 0, buf, sizeof buf);
+    printf("\ncolumns %d first-glcm %s", cols, buf);
+    nfx_centroid_key(2047.96875f, 100.0f, buf, sizeof buf);
+    printf(" key %s\n", buf);
+    nfx_ctx *ctx = NULL;
+    nfx_status st = nfx_ctx_create(0, &ctx);
+    printf("ctx_create %d %s\n", (int)st, ctx ? "ctx" : "null");
+    if (ctx) nfx_ctx_destroy(ctx);
+    return 0;
+}
+''')
+    exe = tmp_path / "host"
+    lib_dir = os.path.dirname(nfx.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", lib_dir, "-lnfx",
+                           f"-Wl,-rpath,{lib_dir}"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    lines = out.stdout.splitlines()
+    assert lines[0] == f"version 500 stamp {nfx.build_stamp()} sets 4: geometry GLCM GLRLM gabor filter"
+    assert lines[1] == "columns 400 first-glcm correlation_0_1_32 key 2047.9688,100"
+    assert lines[2].startswith("ctx_create ") and (lines[2].endswith(" ctx") == lines[2].startswith("ctx_create 0 "))
