@@ -312,8 +312,12 @@ def bind_rank_to_gpu_numa(local_index: int, sysfs: str = "/sys", env=None, getaf
     getaffinity = getaffinity or (lambda: os.sched_getaffinity(0))
     setaffinity = setaffinity or (lambda cpus: os.sched_setaffinity(0, cpus))
     gpu = visible_device_index(local_index, env)
-    rec = {"gpu": gpu, "node": None, "cpus": None, "bound": False, "why": None}
     nodes = gpu_numa_nodes(sysfs)
+    if not (0 <= gpu < len(nodes)) and 0 <= local_index < len(nodes):
+        # the visible-device list names GPUs this process cannot even see in sysfs (a container that hides the others' KFD nodes AND keeps the
+        # host's numbering in the variable): the readable GPU nodes are then exactly the visible devices, in order
+        gpu = local_index
+    rec = {"gpu": gpu, "node": None, "cpus": None, "bound": False, "why": None}
     if not (0 <= gpu < len(nodes)):
         rec["why"] = f"sysfs lists {len(nodes)} GPU(s)"
         return rec

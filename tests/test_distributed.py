@@ -234,6 +234,11 @@ def test_numa_binding_follows_visible_devices_and_survives_missing_sysfs(tmp_pat
     calls = []
     rec = D.bind_rank_to_gpu_numa(0, sysfs=sysfs, env={"ROCR_VISIBLE_DEVICES": "2,3"}, getaffinity=lambda: set(range(16)), setaffinity=calls.append)
     assert rec["gpu"] == 2 and rec["node"] == 1 and calls == [list(range(8, 16))]
+    # a container that hides the other GPUs' KFD nodes but keeps the host's numbering in the variable: the one readable GPU is device 0
+    hidden = _fake_sysfs(tmp_path / "hidden", gpu_nodes=[1], node_cpus={0: "0-7", 1: "8-15"})
+    calls = []
+    rec = D.bind_rank_to_gpu_numa(0, sysfs=hidden, env={"ROCR_VISIBLE_DEVICES": "5"}, getaffinity=lambda: set(range(16)), setaffinity=calls.append)
+    assert rec["bound"] and rec["gpu"] == 0 and rec["node"] == 1 and calls == [list(range(8, 16))]
     # numa_node -1 (a one-node host, or a VM that records no affinity): nothing bound, reason given
     one = _fake_sysfs(tmp_path / "one", gpu_nodes=[-1], node_cpus={0: "0-15"})
     rec = D.bind_rank_to_gpu_numa(0, sysfs=one, env={}, getaffinity=lambda: set(range(16)), setaffinity=calls.append)
