@@ -181,3 +181,58 @@ def test_glcm_rows_do_not_depend_on_the_class_a_nucleus_ran_in(nfx, ctx, ps):
         o = (off[i0:i0 + m + 1] - off[i0]).astype(np.uint32)
         small, _ = ctx.extract([2], o, xy[off[i0]:off[i0 + m]], pu8[i0:i0 + m], ps, batch_size=100)
         assert np.array_equal(small.view(np.uint32), big[i0:i0 + m].view(np.uint32)), np.argwhere(small.view(np.uint32) != big[i0:i0 + m].view(np.uint32))[:5]
+
+
+@pytest.mark.parametrize("batch", [1, 2, 1000, 317])
+def test_colour_at_every_batch_granularity(nfx, ctx, batch):
+    """The batch is the reference's par_chunks size (args.rs:107-108): any value >= 1.  mean_h couples the nuclei of a batch (color.rs:144-155), so one
+    nucleus per batch, two, one batch larger than the call and a batch that is exactly the call are all different results -- each the oracle's."""
+    ps, n = 48, 300
+    off, xy, pu8 = par.make_inputs(41, n + (17 if batch == 317 else 0), ps)
+    sets = [1, 0]
+    want, _ = orc.extract(sets, off, xy, pu8, ps, batch_size=batch)
+    got, _ = ctx.extract(sets, off, xy, pu8, ps, batch_size=batch)
+    par.assert_rows_close(got, want, par.column_scales(nfx, sets, ps), what=f"batch={batch}")
+
+
+def test_more_batches_than_one_launch_dimension_holds(nfx, ctx):
+    """k_hue_batch walks the batches in slabs of 65 535 (a grid's y dimension): 70 000 batches of one nucleus each take two slabs, and the second
+    slab's nuclei must get THEIR batch's sums."""
+    ps, n = 32, 70_000
+    off, xy, pu8 = par.make_inputs(43, n, ps)
+    want, _ = orc.extract([1], off, xy, pu8, ps, batch_size=1, threads=16)
+    got, _ = ctx.extract([1], off, xy, pu8, ps, batch_size=1)
+    par.assert_rows_close(got, want, par.column_scales(nfx, [1], ps), what="70 000 batches")
+    assert np.array_equal(got[65_530:65_545].view(np.uint32), ctx.extract([1], off[65_530:65_546] - off[65_530], xy[off[65_530]:off[65_545]],
+                                                                          pu8[65_530:65_545], ps, batch_size=1)[0].view(np.uint32)), "rows across the slab boundary"
+
+
+@pytest.mark.parametrize("ps", [48, 64, 33])
+def test_hostile_f32_pixels_stay_inside_their_own_nucleus(nfx, ctx, ps):
+    """The trait entry takes f32 tensors (features/mod.rs:21-27), so nothing guarantees values in [0, 1]: NaN, infinities, negatives, 1e30 and
+    denormals in every fourth nucleus's patch.  Levels and table indices are derived from those pixels inside the kernels; whatever the poisoned
+    nuclei's own rows become, every OTHER nucleus of the call must come out bit for bit as in the clean call (no index leaves its table, no
+    neighbouring wave's bins are touched) -- except mean_h, which the reference itself couples across the batch (color.rs:144-155)."""
+    n = 64
+    off, xy, pu8 = _inputs(ps, n, seed=77)
+    n = len(off) - 1
+    cen, ctr = ctx.preprocess_polygons(off, xy)
+    masks = ctx.rasterize_polygons(off, ctr, ps)
+    clean = (pu8.astype(np.float32) / np.float32(255.0)).astype(np.float32)
+    bad = clean.copy()
+    rng = np.random.default_rng(11)
+    poison = np.array([np.nan, np.inf, -np.inf, -5.0, 1e30, -1e30, 1e-42, 2.0, 255.0], np.float32)
+    hostile = np.arange(n) % 4 == 0
+    for i in np.nonzero(hostile)[0]:
+        k = rng.integers(0, bad[i].size, 200)
+        bad[i].reshape(-1)[k] = poison[rng.integers(0, len(poison), 200)]
+    for set_id in (1, 2, 3, 4):
+        a = ctx.compute_features_batched(set_id, off, ctr, clean, masks)
+        b = ctx.compute_features_batched(set_id, off, ctr, bad, masks)
+        keep = np.ones(a.shape[1], bool)
+        if set_id == 1:
+            keep[nfx.column_names(1).index("mean_h")] = False
+        same = a[~hostile][:, keep].view(np.uint32) == b[~hostile][:, keep].view(np.uint32)
+        assert same.all(), (nfx.feature_set_cli_name(set_id), np.argwhere(~same)[:5])
+        c = ctx.compute_features_batched(set_id, off, ctr, clean, masks)          # and nothing lingers in tables or LDS for the next call
+        assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), nfx.feature_set_cli_name(set_id)
