@@ -119,3 +119,34 @@ def test_tile_entry_with_an_empty_ring(nfx, synth, ctx):
     assert np.array_equal(wcen, cen, equal_nan=True)
     par.assert_rows_close(rows, want, par.column_scales(nfx, sets, ps), what="tile entry, empty ring")
     assert np.isnan(rows[10, 1]) and np.isnan(rows[10, 12])           # major_axis, mean_r: 0/0
+
+
+@pytest.mark.parametrize("ps,H,W", [(32, 20, 45), (48, 1, 1), (64, 70, 9), (17, 16, 16), (64, 64, 64)])
+def test_images_smaller_than_a_patch(nfx, synth, ctx, ps, H, W):
+    """load_image_dataset clips the box to the image and pastes what is left at (-min(top,0), -min(left,0)) of a zero patch (utils.rs:164-191): an image
+    narrower or lower than the patch -- down to one pixel -- is clipped on BOTH sides of an axis at once.  Byte-exact through the gather, the tile entry
+    and the streamed entry (one band lower than its own halo), in both addressing modes."""
+    rng = np.random.default_rng(ps * 1000 + H)
+    img = rng.integers(1, 256, (3, H, W), dtype=np.uint8)
+    n = 40
+    cen = np.stack([rng.uniform(-ps, W + ps, n), rng.uniform(-ps, H + ps, n)], 1).astype(np.float32)
+    cen[:4] = [[0.0, 0.0], [W / 2.0, H / 2.0], [W - 0.25, H - 0.25], [W / 2.0 + 0.5, -3.0]]
+    for mode in ("image", "slide"):
+        ctx.set_patch_addressing(mode)
+        got = ctx.gather_patches(cen, img, ps)
+        for i in range(n):
+            want = orc.crop_patch(img, cen[i, 0], cen[i, 1], ps, slide=(mode == "slide"))
+            assert np.array_equal(got[i], want), (mode, i, cen[i])
+    ctx.set_patch_addressing("image")
+    # the same windows under rings: tile entry == packed entry on the oracle's crops, streamed entry == tile entry
+    off = np.arange(0, 5 * n + 1, 5, dtype=np.uint32)
+    d = np.array([[-3, -2], [4, -3], [5, 4], [-4, 3], [-3, -2]], np.float32) * (ps / 16.0)
+    xy = (cen[:, None, :] + d[None] - d[:4].mean(0) * 0).reshape(-1, 2).astype(np.float32)
+    sets = [0, 1, 2, 3, 4]
+    rows_t, cen_t = ctx.extract_tile(sets, off, xy, img, ps, batch_size=16)
+    patches = np.stack([orc.crop_patch(img, c[0], c[1], ps) for c in cen_t])
+    rows_p, _ = ctx.extract(sets, off, xy, patches, ps, batch_size=16)
+    assert np.array_equal(rows_t.view(np.uint32), rows_p.view(np.uint32))
+    rows_s, cen_s, st = ctx.extract_tile_streamed(sets, off, xy, img, ps, batch_size=16, block=64, chunk_nuclei=16)
+    assert np.array_equal(cen_s, cen_t, equal_nan=True) and np.array_equal(rows_s.view(np.uint32), rows_t.view(np.uint32))
+    assert st["blocks_total"] == -(-H // 64)
